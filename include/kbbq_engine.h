@@ -1,0 +1,247 @@
+/* kbbq_engine.h -- C ABI of the MI355X k-mer BQSR engine (libkbbq_engine.so).
+ *
+ * This is the drop-in boundary for kbbq's hot path.  The reference has no FFI;
+ * its seam is the five pass functions main() calls (recalibrateutils.hh:29-44,
+ * covariateutils.hh:171, called at kbbq.cc:280,337,366,407,457).  Each entry
+ * point below is the batch-level equivalent of one of them and cites what it
+ * replaces.  Plain pointers and sizes only; no exceptions cross the boundary;
+ * every function returns 0 (KBBQ_OK) or a negative errno-style code, and
+ * kbbq_last_error() gives the text.
+ *
+ * Threading: one host thread per engine (the reference's passes are
+ * single-threaded and non-reentrant).  All device work of
+ * an engine runs on its own HIP stream (kbbq_engine_stream()).
+ *
+ * Results are independent of batch size, batch order inside a pass (given each
+ * batch's first_kmer_ordinal) and GPU count: Bloom inserts are bitwise ORs and
+ * histograms are integer sums.
+ */
+#ifndef KBBQ_ENGINE_H
+#define KBBQ_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KBBQ_OK 0
+#define KBBQ_EINVAL (-22)   /* bad argument */
+#define KBBQ_ENOMEM (-12)   /* host or device allocation failed (reference: std::bad_alloc, bloom.hh:49-51) */
+#define KBBQ_EIO (-5)       /* HIP runtime error */
+#define KBBQ_ERANGE (-34)   /* read longer than KBBQ_MAX_READ_LEN, k out of 1..32, ... */
+#define KBBQ_ENODEV (-19)   /* no usable GPU */
+#define KBBQ_ESTATE (-1)    /* call out of order (e.g. trusted pass before thresholds are set) */
+
+#define KBBQ_MAX_KMER 32        /* bloom.hh:15 */
+#define KBBQ_MAXQ 93            /* covariateutils.hh:3 */
+#define KBBQ_NQ 94
+#define KBBQ_MAX_READ_LEN 512   /* device kernels keep per-read bit masks in registers/LDS */
+#define KBBQ_DEFAULT_BLOOM_SEED 0xA5A5A5A55A5A5A5AULL   /* bloom.hh:389 */
+
+#define KBBQ_SAMPLED 0
+#define KBBQ_TRUSTED 1
+
+typedef struct kbbq_engine kbbq_engine;
+
+/* Replaces the scalar set-up in main(), kbbq.cc:251-271. */
+typedef struct kbbq_params {
+    int32_t k;              /* --ksize, 1..32 (kbbq.cc:82,101) */
+    int32_t device;         /* HIP device ordinal */
+    double alpha;           /* sampling rate as the double KmerSubsampler receives (htsiter.hh:143) */
+    uint32_t seed;          /* sampler seed (kbbq.cc:86,268-271); must be given: the engine never draws one */
+    int32_t n_rg;           /* number of read groups (>= 1): first dimension of the histograms */
+    uint64_t approx_kmers;  /* genomelen*coverage*alpha (kbbq.cc:264) */
+    double fpr_sampled;     /* (double)0.01L  (kbbq.cc:155,265) */
+    double fpr_trusted;     /* (double)0.0005L (kbbq.cc:156,266) */
+    uint64_t bloom_seed;    /* KBBQ_DEFAULT_BLOOM_SEED unless testing */
+    int32_t max_read_len;   /* longest read that will be submitted: cycle dimension of the histograms */
+    int32_t flags;          /* KBBQ_F_* */
+} kbbq_params;
+
+#define KBBQ_F_PROFILE 1    /* time every kernel with HIP events (kbbq_profile_get) */
+
+/* One batch of reads, structure of arrays.  All pointers are device pointers if
+ * on_device != 0, host pointers otherwise (the engine then stages them through
+ * pinned memory with hipMemcpyAsync).
+ *   bases   2 bits per base, base i of the batch in bits [2*(i%32), +2) of word
+ *           i/32; A=0 C=1 G=2 T=3 (seq_nt16_int[seq_nt16_table[ch]], bloom.hh:351);
+ *           anything else is stored as 0 with its nmask bit set.
+ *   nmask   1 bit per base, bit i%64 of word i/64.
+ *   qual    phred value per base (FASTQ char - 33, readutils.cc:70-71).
+ *   offsets n_reads+1 base offsets, or NULL for uniform reads of read_len bases.
+ *   flags   per read: bit 0 = second-in-pair (readutils.cc:59,89-97); NULL = 0.
+ *   rg      per read dense read-group index (order of first appearance,
+ *           readutils.cc:54-58,100-103); NULL = 0.
+ * bases and nmask must be allocated with at least one extra zero u64 word past
+ * the last used one (the kernels read unaligned 64-bit windows). */
+typedef struct kbbq_reads {
+    uint64_t n_reads;
+    uint64_t n_bases;
+    const uint64_t *bases;
+    const uint64_t *nmask;
+    const uint8_t *qual;
+    const uint64_t *offsets;
+    const uint8_t *flags;
+    const uint16_t *rg;
+    uint32_t read_len;
+    int32_t on_device;
+} kbbq_reads;
+
+typedef struct kbbq_filter_info {
+    uint64_t bits;            /* blocked size: multiple of 512 (bloom.hh:44) */
+    uint64_t bits_unblocked;  /* bloom_parameters::optimal_parameters.table_size */
+    uint64_t n_blocks;
+    uint64_t random_seed;     /* bloom.hh:39 */
+    uint64_t inserted;        /* inserted_element_count_ (counts duplicates) */
+    uint32_t n_hash;          /* optimal_parameters.number_of_hashes */
+    uint32_t n_salt;          /* max(n_hash, 2) */
+    uint32_t salt[128];
+} kbbq_filter_info;
+
+/* ---- engine life cycle ------------------------------------------------ */
+
+/* Replaces `bloom::Bloom subsampled(...), trusted(...)` (kbbq.cc:265-266) and
+ * `KmerSubsampler subsampler(file, k, alpha, seed)` (kbbq.cc:277). */
+int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out);
+void kbbq_engine_destroy(kbbq_engine *e);
+/* Zero both filters, counters, histograms, delta-Q tables (a new run). */
+int kbbq_engine_reset(kbbq_engine *e);
+/* Block until everything submitted so far has finished. */
+int kbbq_engine_sync(kbbq_engine *e);
+/* hipStream_t of the engine, as void*. */
+void *kbbq_engine_stream(kbbq_engine *e);
+const char *kbbq_last_error(void);
+
+int kbbq_filter_info_get(kbbq_engine *e, int which, kbbq_filter_info *out);
+/* Device address of a filter's bit array (n_blocks * 64 bytes), for collectives. */
+void *kbbq_filter_device_table(kbbq_engine *e, int which);
+/* Device address of the 8-byte insert counter of a filter. */
+void *kbbq_filter_device_counter(kbbq_engine *e, int which);
+int kbbq_filter_download(kbbq_engine *e, int which, uint64_t *host_words, uint64_t n_words);
+int kbbq_filter_patterns_download(kbbq_engine *e, int which, uint64_t *host_words /* 65536*8 */);
+/* dst |= src over the whole bit array of a filter; src is a device buffer of the
+ * same size (the OR step of the multi-GPU all-reduce; RCCL has no bitwise OR). */
+int kbbq_filter_or_from(kbbq_engine *e, int which, const void *src_device, uint64_t word_offset, uint64_t n_words);
+int kbbq_filter_set_inserted(kbbq_engine *e, int which, uint64_t inserted);
+
+/* ---- read staging ------------------------------------------------------ */
+
+/* Host helper: ASCII FASTQ-style arrays -> the packed layout above.
+ * seq/qual_ascii hold n_bases characters; bases_out/nmask_out must have
+ * n_bases/32+2 and n_bases/64+2 words; qual_out n_bases bytes (qual_ascii-33). */
+int kbbq_pack_bases(const uint8_t *seq, uint64_t n_bases, uint64_t *bases_out, uint64_t *nmask_out);
+/* Copy a host batch to device memory owned by the engine library; *dev gets
+ * device pointers (on_device=1).  Free with kbbq_reads_free. */
+int kbbq_reads_upload(kbbq_engine *e, const kbbq_reads *host, kbbq_reads *dev);
+int kbbq_reads_free(kbbq_engine *e, kbbq_reads *dev);
+
+/* ---- pass 1: recalibrateutils::subsample_kmers (recalibrateutils.cc:7-13) -- */
+
+/* first_kmer_ordinal = number of k-mer positions (sum of max(0,len-k+1)) in all
+ * reads of the file that precede this batch: the sampler consumes exactly one
+ * draw per k-mer position in file order (htsiter.cc:89-129). */
+int kbbq_sample_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t first_kmer_ordinal);
+/* Number of k-mer positions in a batch (to advance first_kmer_ordinal). */
+int kbbq_count_kmer_positions(kbbq_engine *e, const kbbq_reads *reads, uint64_t *out);
+/* Syncs; *inserted = Bloom::inserted_elements() of the sampled filter (kbbq.cc:283). */
+int kbbq_sample_finish(kbbq_engine *e, uint64_t *inserted);
+
+/* ---- between passes: kbbq.cc:304-313 ------------------------------------ */
+
+/* fpr = subsampled.fprate(); p = calculate_phit(subsampled, alpha);
+ * thresholds = calculate_thresholds(k, p).  alpha_text is the long double alpha
+ * as decimal text (the reference keeps alpha in long double, kbbq.cc:83,251).
+ * thresholds_out: k+1 ints.  Returns 1 when fpr > .15 (the reference exits 1,
+ * kbbq.cc:306-310), 0 otherwise; thresholds are installed either way. */
+int kbbq_compute_thresholds(kbbq_engine *e, const char *alpha_text, int32_t *thresholds_out, double *fpr_out,
+                            char *p_text_out, size_t p_text_len);
+int kbbq_set_thresholds(kbbq_engine *e, const int32_t *thresholds, int32_t n);
+
+/* ---- pass 2: recalibrateutils::find_trusted_kmers (recalibrateutils.cc:15-40) */
+
+/* infer_errors_out (optional, device or host like the batch): 1 bit per base,
+ * CReadData::infer_read_errors' flags, same bit layout as nmask. */
+int kbbq_trusted_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *infer_errors_out);
+int kbbq_trusted_finish(kbbq_engine *e, uint64_t *inserted);
+
+/* ---- pass 3: recalibrateutils::get_covariatedata (recalibrateutils.cc:42-89) */
+
+/* get_errors(trusted, k, 6) then CCovariateData::consume_read for every read.
+ * errors_out (optional): 1 bit per base, CReadData::errors. */
+int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_out);
+/* --fixed mode (kbbq.cc:367-378): tally with caller-supplied error bits. */
+int kbbq_tally_batch(kbbq_engine *e, const kbbq_reads *reads, const uint64_t *errors);
+
+/* Dense covariate histograms, {errors,total} pairs of u64:
+ *   rg    [n_rg][2]                 q     [n_rg][94][2]
+ *   cycle [n_rg][94][2][max_read_len][2]   (third index: 0 first-in-pair, 1 second)
+ *   dinuc [n_rg][94][16][2]         (dinuc = 4*prev + cur, covariateutils.hh:92-96) */
+typedef struct kbbq_covariates {
+    uint64_t n_rg, n_cycle;
+    uint64_t *rg, *q, *cycle, *dinuc;   /* caller-allocated host arrays */
+} kbbq_covariates;
+int kbbq_covariates_get(kbbq_engine *e, kbbq_covariates *out);
+/* Device addresses + word counts of the two tallied histograms (cycle, dinuc),
+ * contiguous, for the multi-GPU sum all-reduce. */
+void *kbbq_covariates_device(kbbq_engine *e, uint64_t *n_words);
+
+/* ---- CCovariateData::get_dqs (covariateutils.cc:204-230) ------------------ */
+
+typedef struct kbbq_dq {
+    uint64_t n_rg, n_cycle;
+    int32_t *meanq;   /* [n_rg] */
+    int32_t *rgdq;    /* [n_rg] */
+    int32_t *qdq;     /* [n_rg][94] */
+    int32_t *cycledq; /* [n_rg][94][2][n_cycle] */
+    int32_t *dinucdq; /* [n_rg][94][16] */
+} kbbq_dq;
+/* Host-side model on the engine's histograms; installs the tables on the device. */
+int kbbq_train(kbbq_engine *e);
+int kbbq_dq_get(kbbq_engine *e, kbbq_dq *out);      /* caller-allocated arrays */
+int kbbq_set_dq(kbbq_engine *e, const kbbq_dq *dq); /* e.g. tables computed on another rank */
+
+/* ---- pass 4: CReadData::recalibrate (readutils.cc:572-595) ---------------- */
+
+/* qual_out: n_bases bytes, device or host like the batch. */
+int kbbq_recalibrate_batch(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qual_out);
+
+/* ---- synthetic input and measurement ------------------------------------- */
+
+typedef struct kbbq_synth_params {
+    uint64_t seed;
+    uint64_t genome_len;
+    uint64_t n_reads;
+    uint32_t read_len;
+    uint32_t n_rg;
+    uint32_t paired;      /* second-in-pair flag = read index & 1 */
+    uint32_t n_per_million; /* N bases per million */
+} kbbq_synth_params;
+/* Threshold tables of the synthetic generator (quality profile per cycle, error
+ * probability per quality), so that the host twin uses the very same numbers. */
+int kbbq_synth_tables(const kbbq_synth_params *sp, uint32_t *qcum /* [read_len][4] */, uint32_t *errthr /* [94] */);
+/* Generate reads [first_read, first_read+n) of the synthetic data set straight
+ * into device memory (uniform-length layout); identical to kbbq_amd.synth on
+ * the host.  Free with kbbq_reads_free. */
+int kbbq_synth_reads(kbbq_engine *e, const kbbq_synth_params *sp, uint64_t first_read, uint64_t n, kbbq_reads *dev);
+
+typedef struct kbbq_profile_entry {
+    char name[48];
+    uint64_t launches;
+    double total_ms;
+} kbbq_profile_entry;
+int kbbq_profile_get(kbbq_engine *e, kbbq_profile_entry *out, int32_t max_entries, int32_t *n_out);
+int kbbq_profile_reset(kbbq_engine *e);
+/* Counters of the last pass-3 work: reads sent to the correction kernel, Bloom
+ * queries issued there. */
+int kbbq_stats_get(kbbq_engine *e, uint64_t *out, int32_t n);
+
+/* Test hook: xoshiro256** state after `ordinal` draws of a sampler seeded with
+ * `seed` (jump-ahead used by pass 1). */
+int kbbq_rng_state_at(uint32_t seed, uint64_t ordinal, uint64_t state_out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KBBQ_ENGINE_H */

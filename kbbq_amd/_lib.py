@@ -1,0 +1,150 @@
+"""ctypes binding of libkbbq_engine.so (include/kbbq_engine.h).
+
+The product path has no CPU fallback: if the HIP library is missing or does not
+load, importing the engine fails loudly.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkbbq_engine.so")
+
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+c_u16p = ctypes.POINTER(ctypes.c_uint16)
+c_u32p = ctypes.POINTER(ctypes.c_uint32)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_u64p = ctypes.POINTER(ctypes.c_uint64)
+c_u64 = ctypes.c_uint64
+c_vp = ctypes.c_void_p
+
+KBBQ_OK = 0
+KBBQ_F_PROFILE = 1
+DEFAULT_BLOOM_SEED = 0xA5A5A5A55A5A5A5A
+NQ = 94
+MAX_READ_LEN = 512
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("k", ctypes.c_int32), ("device", ctypes.c_int32), ("alpha", ctypes.c_double),
+                ("seed", ctypes.c_uint32), ("n_rg", ctypes.c_int32), ("approx_kmers", c_u64),
+                ("fpr_sampled", ctypes.c_double), ("fpr_trusted", ctypes.c_double), ("bloom_seed", c_u64),
+                ("max_read_len", ctypes.c_int32), ("flags", ctypes.c_int32)]
+
+
+class Reads(ctypes.Structure):
+    _fields_ = [("n_reads", c_u64), ("n_bases", c_u64), ("bases", c_vp), ("nmask", c_vp), ("qual", c_vp),
+                ("offsets", c_vp), ("flags", c_vp), ("rg", c_vp), ("read_len", ctypes.c_uint32),
+                ("on_device", ctypes.c_int32)]
+
+
+class FilterInfo(ctypes.Structure):
+    _fields_ = [("bits", c_u64), ("bits_unblocked", c_u64), ("n_blocks", c_u64), ("random_seed", c_u64),
+                ("inserted", c_u64), ("n_hash", ctypes.c_uint32), ("n_salt", ctypes.c_uint32),
+                ("salt", ctypes.c_uint32 * 128)]
+
+
+class Covariates(ctypes.Structure):
+    _fields_ = [("n_rg", c_u64), ("n_cycle", c_u64), ("rg", c_vp), ("q", c_vp), ("cycle", c_vp), ("dinuc", c_vp)]
+
+
+class Dq(ctypes.Structure):
+    _fields_ = [("n_rg", c_u64), ("n_cycle", c_u64), ("meanq", c_vp), ("rgdq", c_vp), ("qdq", c_vp),
+                ("cycledq", c_vp), ("dinucdq", c_vp)]
+
+
+class SynthParams(ctypes.Structure):
+    _fields_ = [("seed", c_u64), ("genome_len", c_u64), ("n_reads", c_u64), ("read_len", ctypes.c_uint32),
+                ("n_rg", ctypes.c_uint32), ("paired", ctypes.c_uint32), ("n_per_million", ctypes.c_uint32)]
+
+
+class ProfileEntry(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 48), ("launches", c_u64), ("total_ms", ctypes.c_double)]
+
+
+# every symbol include/kbbq_engine.h declares: (restype, argtypes)
+SYMBOLS = {
+    "kbbq_engine_create": (ctypes.c_int, [ctypes.POINTER(Params), ctypes.POINTER(c_vp)]),
+    "kbbq_engine_destroy": (None, [c_vp]),
+    "kbbq_engine_reset": (ctypes.c_int, [c_vp]),
+    "kbbq_engine_sync": (ctypes.c_int, [c_vp]),
+    "kbbq_engine_stream": (c_vp, [c_vp]),
+    "kbbq_last_error": (ctypes.c_char_p, []),
+    "kbbq_filter_info_get": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.POINTER(FilterInfo)]),
+    "kbbq_filter_device_table": (c_vp, [c_vp, ctypes.c_int]),
+    "kbbq_filter_device_counter": (c_vp, [c_vp, ctypes.c_int]),
+    "kbbq_filter_download": (ctypes.c_int, [c_vp, ctypes.c_int, c_u64p, c_u64]),
+    "kbbq_filter_patterns_download": (ctypes.c_int, [c_vp, ctypes.c_int, c_u64p]),
+    "kbbq_filter_or_from": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_u64, c_u64]),
+    "kbbq_filter_set_inserted": (ctypes.c_int, [c_vp, ctypes.c_int, c_u64]),
+    "kbbq_pack_bases": (ctypes.c_int, [c_u8p, c_u64, c_u64p, c_u64p]),
+    "kbbq_reads_upload": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads), ctypes.POINTER(Reads)]),
+    "kbbq_reads_free": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads)]),
+    "kbbq_sample_batch": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads), c_u64]),
+    "kbbq_count_kmer_positions": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads), c_u64p]),
+    "kbbq_sample_finish": (ctypes.c_int, [c_vp, c_u64p]),
+    "kbbq_compute_thresholds": (ctypes.c_int, [c_vp, ctypes.c_char_p, c_i32p, ctypes.POINTER(ctypes.c_double),
+                                               ctypes.c_char_p, ctypes.c_size_t]),
+    "kbbq_set_thresholds": (ctypes.c_int, [c_vp, c_i32p, ctypes.c_int32]),
+    "kbbq_trusted_batch": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads), c_vp]),
+    "kbbq_trusted_finish": (ctypes.c_int, [c_vp, c_u64p]),
+    "kbbq_errors_batch": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads), c_vp]),
+    "kbbq_tally_batch": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads), c_vp]),
+    "kbbq_covariates_get": (ctypes.c_int, [c_vp, ctypes.POINTER(Covariates)]),
+    "kbbq_covariates_device": (c_vp, [c_vp, c_u64p]),
+    "kbbq_train": (ctypes.c_int, [c_vp]),
+    "kbbq_dq_get": (ctypes.c_int, [c_vp, ctypes.POINTER(Dq)]),
+    "kbbq_set_dq": (ctypes.c_int, [c_vp, ctypes.POINTER(Dq)]),
+    "kbbq_recalibrate_batch": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads), c_vp]),
+    "kbbq_synth_tables": (ctypes.c_int, [ctypes.POINTER(SynthParams), c_u32p, c_u32p]),
+    "kbbq_synth_reads": (ctypes.c_int, [c_vp, ctypes.POINTER(SynthParams), c_u64, c_u64, ctypes.POINTER(Reads)]),
+    "kbbq_profile_get": (ctypes.c_int, [c_vp, ctypes.POINTER(ProfileEntry), ctypes.c_int32, c_i32p]),
+    "kbbq_profile_reset": (ctypes.c_int, [c_vp]),
+    "kbbq_stats_get": (ctypes.c_int, [c_vp, c_u64p, ctypes.c_int32]),
+    "kbbq_rng_state_at": (ctypes.c_int, [ctypes.c_uint32, c_u64, c_u64p]),
+}
+
+_LIB = None
+
+
+def build(force=False):
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", src, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", src], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "kbbq_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or make -C kbbq_amd/csrc). There is no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: PyTorch ships its own libamdhip64 with the
+        # same SONAME; loading torch first makes the engine bind to that copy.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is plumbing, not required by the C ABI
+            pass
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+class KbbqError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("kbbq engine error %d: %s" % (code, text))
+        self.code = code
+
+
+def check(rc):
+    if rc < 0:
+        raise KbbqError(rc, lib().kbbq_last_error().decode(errors="replace"))
+    return rc

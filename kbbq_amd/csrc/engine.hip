@@ -1,0 +1,1537 @@
+// engine.hip -- MI355X (gfx950) kernels and the C ABI of include/kbbq_engine.h.
+//
+// Pass structure (one kernel or kernel group per reference loop):
+//   pass 1  k_draw_mask        one xoshiro256** draw per k-mer position (htsiter.cc:113-129)
+//           k_sample_insert    sampled & valid k-mers -> sampled filter   (recalibrateutils.cc:7-13)
+//   pass 2  k_trusted          infer_read_errors + trusted inserts        (recalibrateutils.cc:15-40)
+//   pass 3  k_scan_trusted     trusted mask of every k-mer; clean reads finish here
+//           k_compact          work list of reads that need the correction walk
+//           k_correct          get_errors, one read per lane             (readutils.cc:238-570)
+//           k_tally            covariate histograms                      (covariateutils.cc:30-164,193-202)
+//   pass 4  k_recalibrate      delta-Q apply                             (readutils.cc:572-595)
+// Integer / hash / bit work throughout: no MFMA.  The Bloom traffic (random
+// 64-byte blocks of a multi-GB array) is what bounds passes 1-3.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/kbbq_engine.h"
+#include "correct.h"
+#include "device_common.h"
+#include "host_model.h"
+
+using namespace kbbq;
+
+// ============================================================ error plumbing
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return fail(_e == hipErrorOutOfMemory ? KBBQ_ENOMEM : KBBQ_EIO, "%s: %s (%s:%d)", #expr,   \
+                        hipGetErrorString(_e), __FILE__, __LINE__);                                    \
+    } while (0)
+
+// ============================================================ kernels
+
+// ---- pass 1a: the sampler's draw stream ------------------------------------
+// The reference draws serially (one std::bernoulli_distribution call per k-mer
+// position, htsiter.cc:113-129).  xoshiro256 is linear over GF(2), so the state
+// after n draws is (x^n mod P)(M) applied to the seed state; each lane jumps to
+// its own chunk of DRAWS_PER_LANE consecutive draws and emits a bit mask.
+constexpr int DRAWS_PER_LANE = 2048;   // multiple of 64: each lane owns whole mask words
+
+__constant__ uint64_t c_jump[64][4];
+
+__device__ __forceinline__ uint64_t xo_next(uint64_t (&s)[4]) {
+    uint64_t x = s[1] * 5;
+    x = (x << 7) | (x >> 57);
+    x *= 9;
+    const uint64_t t = s[1] << 17;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = (s[3] << 45) | (s[3] >> 19);
+    return x;
+}
+
+__global__ void __launch_bounds__(256) k_draw_mask(uint64_t s0, uint64_t s1, uint64_t s2, uint64_t s3,
+                                                    uint64_t first_ordinal, uint64_t n_draws, uint64_t threshold,
+                                                    int always, uint64_t *mask) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t begin = t * DRAWS_PER_LANE;
+    if (begin >= n_draws) return;
+    uint64_t s[4] = {s0, s1, s2, s3};
+    const uint64_t ordinal = first_ordinal + begin;
+    for (int b = 0; b < 64; ++b) {
+        if (!((ordinal >> b) & 1)) continue;
+        uint64_t acc[4] = {0, 0, 0, 0};
+        for (int w = 0; w < 4; ++w) {
+            const uint64_t poly = c_jump[b][w];
+            for (int i = 0; i < 64; ++i) {
+                const uint64_t m = 0 - ((poly >> i) & 1);
+                acc[0] ^= s[0] & m; acc[1] ^= s[1] & m; acc[2] ^= s[2] & m; acc[3] ^= s[3] & m;
+                xo_next(s);
+            }
+        }
+        s[0] = acc[0]; s[1] = acc[1]; s[2] = acc[2]; s[3] = acc[3];
+    }
+    const uint64_t end = min(begin + (uint64_t)DRAWS_PER_LANE, n_draws);
+    uint64_t *out = mask + begin / 64;
+    for (uint64_t o = begin; o < end; o += 64) {
+        uint64_t bits = 0;
+        const int cnt = (int)min((uint64_t)64, end - o);
+        for (int i = 0; i < cnt; ++i) {
+            const uint64_t u = xo_next(s);
+            bits |= (uint64_t)((always || u < threshold) ? 1 : 0) << i;
+        }
+        *out++ = bits;
+    }
+}
+
+// exclusive prefix of max(0, len-k+1) over the reads of a ragged batch
+__global__ void k_kmer_counts(ReadsDev R, int k, uint64_t *counts) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R.n_reads) return;
+    uint64_t off; uint32_t len;
+    read_span(R, r, off, len);
+    counts[r] = len >= (uint32_t)k ? len - k + 1 : 0;
+}
+// single-block exclusive scan, in place, `n` up to a few tens of millions (test/ragged path)
+__global__ void __launch_bounds__(1024) k_exclusive_scan(uint64_t *data, uint64_t n, uint64_t *total) {
+    __shared__ uint64_t part[1024];
+    const int tid = threadIdx.x;
+    const uint64_t per = (n + 1023) / 1024;
+    const uint64_t b = min(n, per * tid), e = min(n, b + per);
+    uint64_t s = 0;
+    for (uint64_t i = b; i < e; ++i) s += data[i];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t run = 0;
+        for (int i = 0; i < 1024; ++i) { const uint64_t v = part[i]; part[i] = run; run += v; }
+        *total = run;
+    }
+    __syncthreads();
+    uint64_t run = part[tid];
+    for (uint64_t i = b; i < e; ++i) { const uint64_t v = data[i]; data[i] = run; run += v; }
+}
+
+__device__ __forceinline__ uint64_t kmer_base(const uint64_t *kofs, uint64_t r, uint32_t read_len, int k) {
+    if (kofs) return kofs[r];
+    return r * (uint64_t)(read_len >= (uint32_t)k ? read_len - k + 1 : 0);
+}
+
+// ---- pass 1b: insert the sampled k-mers -------------------------------------
+// One wavefront per read, one lane per k-mer start.
+template <int NW>
+__global__ void __launch_bounds__(256) k_sample_insert(ReadsDev R, KParams K, FiltDev F, const uint64_t *mask,
+                                                        const uint64_t *kofs, unsigned long long *inserted) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    unsigned long long mine = 0;
+    for (uint64_t r = wave; r < R.n_reads; r += n_waves) {
+        uint64_t off; uint32_t len;
+        read_span(R, r, off, len);
+        if (len < (uint32_t)K.k) continue;
+        const int nk = (int)len - K.k + 1;
+        const uint64_t kb = kmer_base(kofs, r, R.read_len, K.k);
+#pragma unroll 1
+        for (int c = 0; c * 64 < nk; ++c) {
+            const int s = c * 64 + lane;
+            bool take = false;
+            uint32_t blk = 0, pat = 0;
+            if (s < nk) {
+                const uint64_t o = kb + s;
+                const bool drawn = (mask[o >> 6] >> (o & 63)) & 1;
+                bool valid;
+                const uint64_t key = kmer_at(R, K, off + s, valid);
+                take = drawn && valid;
+                blk = block_of(F, key);
+                pat = pattern_of(F, key);
+            }
+            bloom_coop<true>(F, take, blk, pat);
+            mine += __popcll(__ballot(take));
+        }
+    }
+    if (lane == 0 && mine) atomicAdd(inserted, mine);
+}
+
+// ---- pass 2 ------------------------------------------------------------------
+// overlapping_kmers_in_bf (bloom.cc:28-67) + infer_read_errors (readutils.cc:173-193)
+// + the trusted-insert loop of find_trusted_kmers (recalibrateutils.cc:26-38).
+// Wave per read.  present[] and err[] live as wave-uniform bit words produced
+// by __ballot; the sliding counters in[i]/possible[i] and the "k clean bases"
+// window become range pop-counts on those words.
+struct Thresholds { int v[KBBQ_MAX_KMER + 1]; };
+
+template <int NW>
+__global__ void __launch_bounds__(256) k_trusted(ReadsDev R, KParams K, FiltDev S, FiltDev T, Thresholds thr,
+                                                  unsigned long long *inserted, uint32_t *err_out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const int k = K.k;
+    unsigned long long mine = 0;
+    for (uint64_t r = wave; r < R.n_reads; r += n_waves) {
+        uint64_t off; uint32_t len;
+        read_span(R, r, off, len);
+        if (len < (uint32_t)k) continue;   // engine-defined: the reference underflows size_t here
+        const int L = (int)len, nk = L - k + 1;
+        uint64_t P[NW], E[NW], V[NW], key[NW];
+#pragma unroll
+        for (int c = 0; c < NW; ++c) {
+            P[c] = 0; E[c] = 0; V[c] = 0; key[c] = 0;
+            if (c * 64 < nk) {
+                const int s = c * 64 + lane;
+                bool valid = false;
+                uint32_t blk = 0, pat = 0;
+                if (s < nk) {
+                    key[c] = kmer_at(R, K, off + s, valid);
+                    blk = block_of(S, key[c]);
+                    pat = pattern_of(S, key[c]);
+                }
+                const bool present = bloom_coop<false>(S, valid, blk, pat) && valid;
+                P[c] = __ballot(present);
+                V[c] = __ballot(valid);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NW; ++c) {
+            if (c * 64 < L) {
+                const int i = c * 64 + lane;
+                bool err = false;
+                if (i < L) {
+                    const int lo = max(0, i - k + 1), hi = min(i, nk - 1);
+                    const int possible = hi - lo + 1;
+                    const int in = range_popc<NW>(P, lo, hi);
+                    err = in <= thr.v[possible] || R.qual[off + i] <= 2;
+                }
+                E[c] = __ballot(err);
+            }
+        }
+        if (err_out) {
+            // flat bit array shared with neighbouring reads: OR in 32-bit pieces
+#pragma unroll
+            for (int c = 0; c < NW; ++c) {
+                if (c * 64 < L && lane < 2) {
+                    const uint32_t v = (uint32_t)(E[c] >> (32 * lane));
+                    const uint64_t g = off + (uint64_t)c * 64 + 32 * lane;
+                    if (v) {
+                        atomicOr(&err_out[g >> 5], v << (g & 31));
+                        if (g & 31) atomicOr(&err_out[(g >> 5) + 1], v >> (32 - (g & 31)));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NW; ++c) {
+            if (c * 64 < nk) {
+                const int s = c * 64 + lane;
+                bool take = false;
+                uint32_t blk = 0, pat = 0;
+                if (s < nk) {
+                    const bool valid = (V[c] >> lane) & 1;
+                    take = valid && range_popc<NW>(E, s, s + k - 1) == 0;
+                    blk = block_of(T, key[c]);
+                    pat = pattern_of(T, key[c]);
+                }
+                bloom_coop<true>(T, take, blk, pat);
+                mine += __popcll(__ballot(take));
+            }
+        }
+    }
+    if (lane == 0 && mine) atomicAdd(inserted, mine);
+}
+
+// ---- pass 3a: trusted mask of every k-mer ------------------------------------
+// Wave per read.  A read whose k-mers are all trusted has no errors
+// (readutils.cc:263-265) and needs nothing more than the tally; the others get
+// their mask stored and a flag for the correction kernel.
+template <int NW>
+__global__ void __launch_bounds__(256) k_scan_trusted(ReadsDev R, KParams K, FiltDev T, uint64_t *tmask,
+                                                       uint8_t *dirty) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const int k = K.k;
+    for (uint64_t r = wave; r < R.n_reads; r += n_waves) {
+        uint64_t off; uint32_t len;
+        read_span(R, r, off, len);
+        if (len < (uint32_t)k) { if (lane == 0) dirty[r] = 0; continue; }
+        const int nk = (int)len - k + 1;
+        uint64_t M[NW];
+        int trusted = 0;
+#pragma unroll
+        for (int c = 0; c < NW; ++c) {
+            M[c] = 0;
+            if (c * 64 < nk) {
+                const int s = c * 64 + lane;
+                bool valid = false;
+                uint32_t blk = 0, pat = 0;
+                if (s < nk) {
+                    const uint64_t key = kmer_at(R, K, off + s, valid);
+                    blk = block_of(T, key);
+                    pat = pattern_of(T, key);
+                }
+                const bool ok = bloom_coop<false>(T, valid, blk, pat) && valid;
+                M[c] = __ballot(ok);
+                trusted += __popcll(M[c]);
+            }
+        }
+        const bool is_dirty = trusted != nk;
+        if (lane == 0) dirty[r] = is_dirty ? 1 : 0;
+        if (is_dirty && lane < NW) tmask[r * NW + lane] = sel_word<NW>(M, lane);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_compact(const uint8_t *dirty, uint64_t n, uint32_t *list,
+                                                  unsigned long long *count) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool d = i < n && dirty[i];
+    const unsigned long long bal = __ballot(d);
+    const int lane = threadIdx.x & 63;
+    unsigned long long base = 0;
+    if (lane == 0 && bal) base = atomicAdd(count, (unsigned long long)__popcll(bal));
+    base = __shfl(base, 0);
+    if (d) list[base + __popcll(bal & ((1ULL << lane) - 1))] = (uint32_t)i;
+}
+
+// ---- pass 3b: the correction walk, one read per lane ---------------------------
+template <int MAXL, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_correct(ReadsDev R, KParams K, FiltDev T, const uint32_t *list,
+                                                    const unsigned long long *n_list, const uint64_t *tmask,
+                                                    int tmask_words, uint32_t *err_bits, uint32_t *patch,
+                                                    unsigned long long *stats) {
+    typedef Corrector<MAXL> C;
+    extern __shared__ uint32_t lds[];
+    const uint64_t n = *n_list;
+    unsigned long long q_total = 0;
+    for (uint64_t slot = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; slot < n; slot += (uint64_t)gridDim.x * BLOCK) {
+        const uint64_t r = list[slot];
+        uint64_t off; uint32_t len32;
+        read_span(R, r, off, len32);
+        const int len = (int)len32;
+        C cx;
+        cx.L = lds + threadIdx.x;
+        cx.stride = BLOCK;
+        cx.f = T;
+        cx.K = K;
+        cx.qual = R.qual + off;
+        cx.t_ok = true;
+        cx.queries = 0;
+        // stage the read: 2-bit bases, non-ACGT mask, trusted mask; clear flags
+        for (int w = 0; w < C::NWB; ++w)
+            cx.word(C::OFF_W, w) = w * 16 < len ? (uint32_t)window64(R.bases, 2 * (off + (uint64_t)w * 16)) : 0u;
+        for (int w = 0; w < C::NWN; ++w) {
+            cx.word(C::OFF_NM, w) = w * 32 < len ? (uint32_t)window64(R.nmask, off + (uint64_t)w * 32) : 0u;
+            cx.word(C::OFF_E, w) = 0;
+            const int tw = w >> 1;
+            cx.word(C::OFF_T, w) = tw < tmask_words ? (uint32_t)(tmask[r * tmask_words + tw] >> (32 * (w & 1))) : 0u;
+        }
+        // bits past the read end must not look like bases
+        if (len & 31) cx.word(C::OFF_NM, len >> 5) &= (1u << (len & 31)) - 1;
+        if (len & 15) cx.word(C::OFF_W, len >> 4) &= (1u << ((len & 15) * 2)) - 1;
+
+        const int k = K.k;
+        const CallResult top = cx.run_call(0, len, true, 6);
+        if (top.patch_pos >= 0) patch[r] = 0x80000000u | ((uint32_t)top.patch_pos << 8) | (uint32_t)top.patch_base;
+        // readutils.cc:547-563
+        if (top.bad_prefix > 0 && (top.bad_prefix >= len / 2 || top.bad_prefix >= 2 * k))
+            cx.run_call(0, top.bad_prefix + 1, false, 6);
+        if (top.bad_suffix >= 0 && top.bad_suffix < len &&
+            (len - top.bad_suffix > len / 2 || len - top.bad_suffix > 2 * k))
+            cx.run_call(top.bad_suffix, len - top.bad_suffix, false, 6);
+        // publish the flags into the batch-wide bit array
+        for (int w = 0; w * 32 < len; ++w) {
+            const uint32_t v = cx.word(C::OFF_E, w);
+            if (!v) continue;
+            const uint64_t g = off + (uint64_t)w * 32;
+            atomicOr(&err_bits[g >> 5], v << (g & 31));
+            if (g & 31) atomicOr(&err_bits[(g >> 5) + 1], v >> (32 - (g & 31)));
+        }
+        q_total += cx.queries;
+    }
+    // per-wave reduction of the query counter
+    for (int o = 32; o > 0; o >>= 1) q_total += __shfl_down(q_total, o);
+    if ((threadIdx.x & 63) == 0 && q_total) atomicAdd(&stats[1], q_total);
+}
+
+// ---- pass 3c: covariate tally ---------------------------------------------------
+// CCovariateData::consume_read (covariateutils.cc:193-202).  Only the cycle and
+// dinucleotide tables are tallied: qcov[rg][q] and rgcov[rg] are exact sums of
+// the cycle table (every base is counted in all three, :30-42, :65-76, :102-116)
+// and are formed once at the end.  Totals go through an LDS-private table
+// (16-bit counters, packed two per word, flushed before they can wrap) for the
+// read group of the block's first read; error counts and anything outside the
+// LDS table go straight to 64-bit global atomics (rare).
+struct HistDev {
+    unsigned long long *cycle;   // [n_rg][94][2][n_cycle][2]
+    unsigned long long *dinuc;   // [n_rg][94][16][2]
+    int n_rg, n_cycle;
+};
+
+__device__ __forceinline__ uint64_t cyc_index(const HistDev &H, int rg, int q, int s, int c) {
+    return ((((uint64_t)rg * KBBQ_NQ + q) * 2 + s) * H.n_cycle + c) * 2;
+}
+
+__global__ void __launch_bounds__(256) k_tally(ReadsDev R, HistDev H, const uint32_t *err_bits, const uint32_t *patch,
+                                                int ccap, int minscore) {
+    extern __shared__ uint32_t lds[];
+    // layout: cycle totals [2][ccap][94] u16 (packed), then dinuc totals [94][16] u32
+    const int cyc_words = (2 * ccap * KBBQ_NQ + 1) / 2;
+    uint32_t *l_cyc = lds;
+    uint32_t *l_di = lds + cyc_words;
+    const int lds_words = cyc_words + KBBQ_NQ * 16;
+    for (int i = threadIdx.x; i < lds_words; i += blockDim.x) lds[i] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    const int lds_rg = R.rg ? (int)R.rg[0] : 0;
+    int since_flush = 0;
+    // every wave of a block runs the same number of iterations so that the
+    // flush barriers below are reached by all of them
+    const uint64_t iters = (R.n_reads + n_waves - 1) / n_waves;
+    for (uint64_t it = 0; it < iters; ++it) {
+        const uint64_t r = wave + it * n_waves;
+        if (r < R.n_reads) {
+            uint64_t off; uint32_t len;
+            read_span(R, r, off, len);
+            const int rg = R.rg ? (int)R.rg[r] : 0;
+            const int second = R.flags ? (R.flags[r] & 1) : 0;
+            const uint32_t pt = patch ? patch[r] : 0u;
+            const int p_pos = (pt >> 31) ? (int)((pt >> 8) & 0xFFFF) : -1;
+            const int p_base = (int)(pt & 3);
+            if (rg < H.n_rg) {
+                for (int c0 = 0; c0 < (int)len; c0 += 64) {
+                    const int i = c0 + lane;
+                    if (i < (int)len && i < H.n_cycle) {
+                        const uint64_t g = off + i;
+                        const int q = R.qual[g];
+                        if (q < KBBQ_NQ) {
+                            const int e = (err_bits[g >> 5] >> (g & 31)) & 1;
+                            if (rg == lds_rg && i < ccap) {
+                                const int idx = (second * ccap + i) * KBBQ_NQ + q;
+                                atomicAdd(&l_cyc[idx >> 1], 1u << (16 * (idx & 1)));
+                            } else {
+                                atomicAdd(&H.cycle[cyc_index(H, rg, q, second, i) + 1], 1ULL);
+                            }
+                            if (e) atomicAdd(&H.cycle[cyc_index(H, rg, q, second, i)], 1ULL);
+                            if (i >= 1 && q >= minscore) {
+                                int b1 = (int)((R.bases[g >> 5] >> ((g & 31) * 2)) & 3);
+                                int n1 = (int)((R.nmask[g >> 6] >> (g & 63)) & 1);
+                                const uint64_t gp = g - 1;
+                                int b0 = (int)((R.bases[gp >> 5] >> ((gp & 31) * 2)) & 3);
+                                int n0 = (int)((R.nmask[gp >> 6] >> (gp & 63)) & 1);
+                                if (i == p_pos) { b1 = p_base; n1 = 0; }
+                                if (i - 1 == p_pos) { b0 = p_base; n0 = 0; }
+                                if (!n0 && !n1) {
+                                    const int d = (b0 << 2) | b1;
+                                    if (rg == lds_rg) atomicAdd(&l_di[q * 16 + d], 1u);
+                                    else atomicAdd(&H.dinuc[(((uint64_t)rg * KBBQ_NQ + q) * 16 + d) * 2 + 1], 1ULL);
+                                    if (e) atomicAdd(&H.dinuc[(((uint64_t)rg * KBBQ_NQ + q) * 16 + d) * 2], 1ULL);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        since_flush += waves_per_block;
+        if (since_flush >= 60000 || it + 1 == iters) {
+            __syncthreads();
+            for (int w = threadIdx.x; w < cyc_words; w += blockDim.x) {
+                const uint32_t v = l_cyc[w];
+                if (!v) continue;
+                l_cyc[w] = 0;
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t cnt = (v >> (16 * h)) & 0xFFFFu;
+                    if (!cnt) continue;
+                    const int idx = 2 * w + h;
+                    const int q = idx % KBBQ_NQ, rest = idx / KBBQ_NQ;
+                    const int c = rest % ccap, s = rest / ccap;
+                    atomicAdd(&H.cycle[cyc_index(H, lds_rg, q, s, c) + 1], (unsigned long long)cnt);
+                }
+            }
+            for (int w = threadIdx.x; w < KBBQ_NQ * 16; w += blockDim.x) {
+                const uint32_t v = l_di[w];
+                if (!v) continue;
+                l_di[w] = 0;
+                atomicAdd(&H.dinuc[((uint64_t)lds_rg * KBBQ_NQ * 16 + w) * 2 + 1], (unsigned long long)v);
+            }
+            __syncthreads();
+            since_flush = 0;
+        }
+    }
+}
+
+// ---- pass 4: delta-Q apply -------------------------------------------------------
+// CReadData::recalibrate (readutils.cc:572-595).  One lane per 16 consecutive
+// bases of the batch: 16-byte quality load and store, 4-byte base load.
+struct DqDev {
+    const int16_t *base;   // [n_rg][94]  meanq + rgdq + qscoredq
+    const int8_t *cycle;   // [n_rg][94][2][n_cycle]
+    const int8_t *dinuc;   // [n_rg][94][16]
+    int n_rg, n_cycle;
+};
+
+__global__ void __launch_bounds__(256) k_recalibrate(ReadsDev R, DqDev D, uint8_t *out, int minqual, int vec_ok) {
+    const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (g0 >= R.n_bases) return;
+    // read containing g0
+    uint64_t r, start, end;
+    if (R.offsets) {
+        uint64_t lo = 0, hi = R.n_reads;   // last r with offsets[r] <= g0
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (R.offsets[mid] <= g0) lo = mid; else hi = mid;
+        }
+        r = lo;
+        start = R.offsets[r];
+        end = R.offsets[r + 1];
+        while (end <= g0) { ++r; start = end; end = R.offsets[r + 1]; }   // skip empty reads
+    } else {
+        r = g0 / R.read_len;
+        start = r * R.read_len;
+        end = start + R.read_len;
+    }
+    const int n = (int)min((uint64_t)16, R.n_bases - g0);
+    uint8_t qv[16];
+    if (n == 16 && vec_ok) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(R.qual + g0);
+        memcpy(qv, &v, 16);
+    } else {
+        for (int i = 0; i < 16; ++i) qv[i] = i < n ? R.qual[g0 + i] : 0;
+    }
+    const uint32_t bw = (uint32_t)(R.bases[g0 >> 5] >> ((g0 & 31) * 2));
+    const uint32_t nw = (uint32_t)(R.nmask[g0 >> 6] >> (g0 & 63)) & 0xFFFFu;
+    int prev_b = 0, prev_n = 1;
+    if (g0 > 0) {
+        const uint64_t gp = g0 - 1;
+        prev_b = (int)((R.bases[gp >> 5] >> ((gp & 31) * 2)) & 3);
+        prev_n = (int)((R.nmask[gp >> 6] >> (gp & 63)) & 1);
+    }
+    int rg = R.rg ? (int)R.rg[r] : 0;
+    int second = R.flags ? (R.flags[r] & 1) : 0;
+    uint8_t res[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint64_t g = g0 + i;
+        if (i < n) {
+            while (g >= end) {
+                ++r; start = end;
+                end = R.offsets ? R.offsets[r + 1] : end + R.read_len;
+                rg = R.rg ? (int)R.rg[r] : 0;
+                second = R.flags ? (R.flags[r] & 1) : 0;
+            }
+        }
+        const int cyc = (int)(g - start);
+        const int b = (int)((bw >> (2 * i)) & 3), nn = (int)((nw >> i) & 1);
+        const int q = qv[i];
+        int v = q;
+        if (i < n && q >= minqual && q < KBBQ_NQ && rg < D.n_rg && cyc < D.n_cycle) {
+            const int cell = rg * KBBQ_NQ + q;
+            v = D.base[cell] + D.cycle[((uint64_t)cell * 2 + second) * D.n_cycle + cyc];
+            if (cyc > 0 && !nn && !prev_n) v += D.dinuc[cell * 16 + ((prev_b << 2) | b)];
+        }
+        res[i] = (uint8_t)(v < 0 ? 0 : (v > KBBQ_MAXQ ? KBBQ_MAXQ : v));
+        prev_b = b;
+        prev_n = nn;
+    }
+    if (n == 16 && vec_ok) {
+        uint4 v;
+        memcpy(&v, res, 16);
+        *reinterpret_cast<uint4 *>(out + g0) = v;
+    } else {
+        for (int i = 0; i < n; ++i) out[g0 + i] = res[i];
+    }
+}
+
+// ---- helpers ----------------------------------------------------------------------
+__global__ void k_or_words(uint64_t *dst, const uint64_t *src, uint64_t n) {
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i + 1 < n) {
+        ulonglong2 a = *reinterpret_cast<ulonglong2 *>(dst + i);
+        const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(src + i);
+        a.x |= b.x; a.y |= b.y;
+        *reinterpret_cast<ulonglong2 *>(dst + i) = a;
+    } else if (i < n) {
+        dst[i] |= src[i];
+    }
+}
+
+// synthetic data set (kbbq_amd/synth.py is the host twin, bit for bit)
+struct SynthDev {
+    uint64_t seed, genome_len, first_read, n_reads;
+    uint32_t read_len, n_rg, paired, n_thr;   // n_thr: N threshold on 20 bits
+    const uint32_t *qcum;     // [read_len][4] cumulative 32-bit thresholds for Q2,Q12,Q22,Q32 (else Q37)
+    const uint32_t *errthr;   // [94] 32-bit error thresholds
+};
+__device__ __host__ __forceinline__ uint64_t synth_hash(uint64_t seed, uint64_t stream, uint64_t idx) {
+    return mix64(mix64(seed + stream * 0x9e3779b97f4a7c15ULL) + idx * 0xD1342543DE82EF95ULL);
+}
+__device__ __forceinline__ int synth_genome(uint64_t seed, uint64_t pos) { return (int)(synth_hash(seed, 0, pos) >> 62); }
+
+__global__ void __launch_bounds__(256) k_synth(SynthDev S, uint64_t *bases, uint64_t *nmask, uint8_t *qual,
+                                                uint8_t *flags, uint16_t *rg) {
+    // one lane per 32 consecutive bases of the batch (one 2-bit word)
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t total = S.n_reads * S.read_len;
+    const uint64_t g0 = w * 32;
+    if (g0 >= total) return;
+    uint64_t bword = 0;
+    uint32_t nbits = 0;
+    for (int i = 0; i < 32; ++i) {
+        const uint64_t g = g0 + i;
+        if (g >= total) break;
+        const uint64_t lr = g / S.read_len;
+        const uint32_t c = (uint32_t)(g - lr * S.read_len);
+        const uint64_t r = S.first_read + lr;
+        const uint64_t h1 = synth_hash(S.seed, 1, r);
+        const uint64_t start = (h1 >> 1) % (S.genome_len - S.read_len + 1);
+        const int strand = (int)(h1 & 1);
+        int b = strand ? 3 - synth_genome(S.seed, start + S.read_len - 1 - c) : synth_genome(S.seed, start + c);
+        const uint64_t hb = synth_hash(S.seed, 3, r * S.read_len + c);
+        const uint32_t uq = (uint32_t)hb, ue = (uint32_t)(hb >> 32);
+        const uint32_t *qc = S.qcum + 4 * c;
+        int q = uq < qc[0] ? 2 : uq < qc[1] ? 12 : uq < qc[2] ? 22 : uq < qc[3] ? 32 : 37;
+        if (ue < S.errthr[q]) b = (b + 1 + (int)(synth_hash(S.seed, 4, r * S.read_len + c) % 3)) & 3;
+        const bool isn = (synth_hash(S.seed, 5, r * S.read_len + c) & 0xFFFFF) < S.n_thr;
+        if (isn) { b = 0; q = 2; nbits |= 1u << i; }
+        bword |= (uint64_t)b << (2 * i);
+        qual[g] = (uint8_t)q;
+        if (c == 0) {
+            flags[lr] = S.paired ? (uint8_t)(r & 1) : 0;
+            rg[lr] = (uint16_t)((synth_hash(S.seed, 6, r) >> 32) % S.n_rg);
+        }
+    }
+    bases[w] = bword;
+    // two lanes share one mask word
+    uint32_t *nm32 = reinterpret_cast<uint32_t *>(nmask);
+    nm32[w] = nbits;
+}
+
+// ============================================================ engine object
+
+struct FilterHost {
+    FilterSpec spec;
+    uint64_t *d_table = nullptr;
+    uint64_t *d_patterns = nullptr;
+    unsigned long long *d_inserted = nullptr;
+    FiltDev dev() const {
+        FiltDev f;
+        f.table = d_table;
+        f.patterns = d_patterns;
+        f.n_blocks = spec.n_blocks;
+        f.mod_magic = spec.n_blocks > 0xFFFFFFFFULL ? 0 : (~0ULL / spec.n_blocks + 1);
+        f.salt0 = spec.salt[0];
+        f.salt1 = spec.salt[1];
+        return f;
+    }
+};
+
+struct ProfileSlot {
+    std::string name;
+    uint64_t launches = 0;
+    double ms = 0;
+};
+struct PendingEvent {
+    int slot;
+    hipEvent_t a, b;
+};
+
+struct kbbq_engine {
+    kbbq_params p;
+    KParams K;
+    hipStream_t stream = nullptr;
+    FilterHost filt[2];
+    Xoshiro256 seed_state;
+    uint64_t draw_threshold = 0;
+    bool draw_always = false;
+    bool thresholds_set = false;
+    std::vector<int32_t> thresholds;
+    // histograms and delta-Q tables
+    unsigned long long *d_hist = nullptr;   // cycle then dinuc, contiguous
+    uint64_t hist_cycle_words = 0, hist_dinuc_words = 0;
+    DqTables dq;
+    bool dq_set = false;
+    int16_t *d_dq_base = nullptr;
+    int8_t *d_dq_cycle = nullptr;
+    int8_t *d_dq_dinuc = nullptr;
+    // scratch
+    void *scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long *d_counters = nullptr;   // [0] work-list length, [1] correction queries, [2] scan total
+    std::vector<void *> staged;   // device copies of host batches, freed at the next sync
+    uint64_t stats[4] = {0, 0, 0, 0};
+    // profiling
+    std::vector<ProfileSlot> prof;
+    std::vector<PendingEvent> pending;
+    uint32_t *d_qcum = nullptr, *d_errthr = nullptr;
+    uint32_t qcum_len = 0;
+};
+
+namespace {
+
+int ensure_scratch(kbbq_engine *e, int idx, size_t bytes) {
+    if (e->scratch_bytes[idx] >= bytes) return KBBQ_OK;
+    if (e->scratch[idx]) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipFree(e->scratch[idx]));
+        e->scratch[idx] = nullptr;
+        e->scratch_bytes[idx] = 0;
+    }
+    const size_t want = bytes + bytes / 8 + 256;
+    HIP_TRY(hipMalloc(&e->scratch[idx], want));
+    e->scratch_bytes[idx] = want;
+    return KBBQ_OK;
+}
+
+struct Timed {
+    kbbq_engine *e;
+    int slot = -1;
+    hipEvent_t a = nullptr, b = nullptr;
+    Timed(kbbq_engine *e_, const char *name) : e(e_) {
+        if (!(e->p.flags & KBBQ_F_PROFILE)) return;
+        for (size_t i = 0; i < e->prof.size(); ++i)
+            if (e->prof[i].name == name) slot = (int)i;
+        if (slot < 0) {
+            ProfileSlot s;
+            s.name = name;
+            e->prof.push_back(s);
+            slot = (int)e->prof.size() - 1;
+        }
+        hipEventCreate(&a);
+        hipEventCreate(&b);
+        hipEventRecord(a, e->stream);
+    }
+    ~Timed() {
+        if (slot < 0) return;
+        hipEventRecord(b, e->stream);
+        PendingEvent pe = {slot, a, b};
+        e->pending.push_back(pe);
+    }
+};
+
+void drain_profile(kbbq_engine *e) {
+    for (size_t i = 0; i < e->pending.size(); ++i) {
+        PendingEvent &pe = e->pending[i];
+        float ms = 0;
+        if (hipEventSynchronize(pe.b) == hipSuccess && hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
+            e->prof[pe.slot].ms += ms;
+            e->prof[pe.slot].launches += 1;
+        }
+        hipEventDestroy(pe.a);
+        hipEventDestroy(pe.b);
+    }
+    e->pending.clear();
+}
+
+int sync_engine(kbbq_engine *e) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    drain_profile(e);
+    for (size_t i = 0; i < e->staged.size(); ++i) hipFree(e->staged[i]);
+    e->staged.clear();
+    return KBBQ_OK;
+}
+
+template <typename T>
+int stage_array(kbbq_engine *e, const T *host, size_t count, size_t pad_count, const T **dev) {
+    if (!host) { *dev = nullptr; return KBBQ_OK; }
+    void *d = nullptr;
+    HIP_TRY(hipMalloc(&d, (count + pad_count) * sizeof(T)));
+    e->staged.push_back(d);
+    if (pad_count) HIP_TRY(hipMemsetAsync((char *)d + count * sizeof(T), 0, pad_count * sizeof(T), e->stream));
+    HIP_TRY(hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, e->stream));
+    *dev = (const T *)d;
+    return KBBQ_OK;
+}
+
+// device view of a batch; host batches are copied (freed at the next sync)
+int device_view(kbbq_engine *e, const kbbq_reads *in, ReadsDev *out, int *max_len) {
+    if (!in) return fail(KBBQ_EINVAL, "null batch");
+    if (in->n_reads == 0) return fail(KBBQ_EINVAL, "empty batch");
+    if (!in->offsets && in->read_len == 0) return fail(KBBQ_EINVAL, "batch has neither offsets nor read_len");
+    if (!in->offsets && in->n_bases != in->n_reads * (uint64_t)in->read_len)
+        return fail(KBBQ_EINVAL, "uniform batch: n_bases != n_reads * read_len");
+    if (in->n_reads > 0xFFFFFFFFULL) return fail(KBBQ_ERANGE, "more than 2^32-1 reads in one batch");
+    ReadsDev R;
+    R.n_reads = in->n_reads;
+    R.n_bases = in->n_bases;
+    R.read_len = in->read_len;
+    if (in->on_device) {
+        R.bases = in->bases; R.nmask = in->nmask; R.qual = in->qual;
+        R.offsets = in->offsets; R.flags = in->flags; R.rg = in->rg;
+    } else {
+        int rc;
+        if ((rc = stage_array(e, in->bases, in->n_bases / 32 + 1, 1, &R.bases))) return rc;
+        if ((rc = stage_array(e, in->nmask, in->n_bases / 64 + 1, 1, &R.nmask))) return rc;
+        if ((rc = stage_array(e, in->qual, in->n_bases, 16, &R.qual))) return rc;
+        if ((rc = stage_array(e, in->offsets, in->offsets ? in->n_reads + 1 : 0, 0, &R.offsets))) return rc;
+        if ((rc = stage_array(e, in->flags, in->flags ? in->n_reads : 0, 0, &R.flags))) return rc;
+        if ((rc = stage_array(e, in->rg, in->rg ? in->n_reads : 0, 0, &R.rg))) return rc;
+    }
+    if (!in->on_device && in->offsets) {
+        if (in->offsets[0] != 0 || in->offsets[in->n_reads] != in->n_bases) return fail(KBBQ_EINVAL, "offsets do not span n_bases");
+        for (uint64_t r = 0; r < in->n_reads; ++r) {
+            if (in->offsets[r + 1] < in->offsets[r]) return fail(KBBQ_EINVAL, "offsets are not monotone");
+            if (in->offsets[r + 1] - in->offsets[r] > (uint64_t)e->p.max_read_len)
+                return fail(KBBQ_ERANGE, "read %llu is longer than params.max_read_len %d", (unsigned long long)r, e->p.max_read_len);
+        }
+    }
+    *out = R;
+    // longest read: uniform => read_len; ragged => the engine's declared maximum
+    *max_len = in->offsets ? e->p.max_read_len : (int)in->read_len;
+    if (*max_len > KBBQ_MAX_READ_LEN) return fail(KBBQ_ERANGE, "read length %d > %d", *max_len, KBBQ_MAX_READ_LEN);
+    if (*max_len > e->p.max_read_len) return fail(KBBQ_ERANGE, "read length %d > params.max_read_len %d", *max_len, e->p.max_read_len);
+    return KBBQ_OK;
+}
+
+inline int wave_grid(uint64_t n_reads) {
+    const uint64_t blocks = (n_reads + 3) / 4;
+    return (int)std::min<uint64_t>(blocks, 256 * 16);
+}
+
+// exclusive k-mer-position prefix for ragged batches (scratch slot 1); null for uniform ones
+int kmer_prefix(kbbq_engine *e, const ReadsDev &R, const uint64_t **kofs, uint64_t *total) {
+    if (!R.offsets) {
+        *kofs = nullptr;
+        const uint64_t nk = R.read_len >= (uint32_t)e->p.k ? R.read_len - e->p.k + 1 : 0;
+        *total = nk * R.n_reads;
+        return KBBQ_OK;
+    }
+    int rc = ensure_scratch(e, 1, (R.n_reads + 1) * 8);
+    if (rc) return rc;
+    uint64_t *d = (uint64_t *)e->scratch[1];
+    hipLaunchKernelGGL(k_kmer_counts, dim3((unsigned)((R.n_reads + 255) / 256)), dim3(256), 0, e->stream, R, e->p.k, d);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, e->stream, d, R.n_reads, (uint64_t *)&e->d_counters[2]);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(total, &e->d_counters[2], 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    *kofs = d;
+    return KBBQ_OK;
+}
+
+int upload_dq(kbbq_engine *e) {
+    const DqTables &d = e->dq;
+    const size_t nb = d.n_rg * kNQ, nc = d.n_rg * kNQ * 2 * d.n_cycle, nd = d.n_rg * kNQ * 16;
+    std::vector<int16_t> base(nb);
+    std::vector<int8_t> cyc(nc), di(nd);
+    for (uint64_t r = 0; r < d.n_rg; ++r)
+        for (int q = 0; q < kNQ; ++q) base[r * kNQ + q] = (int16_t)(d.meanq[r] + d.rgdq[r] + d.qdq[r * kNQ + q]);
+    for (size_t i = 0; i < nc; ++i) cyc[i] = (int8_t)d.cycledq[i];
+    for (size_t i = 0; i < nd; ++i) di[i] = (int8_t)d.dinucdq[i];
+    HIP_TRY(hipMemcpyAsync(e->d_dq_base, base.data(), nb * 2, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_dq_cycle, cyc.data(), nc, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_dq_dinuc, di.data(), nd, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->dq_set = true;
+    return KBBQ_OK;
+}
+
+}  // namespace
+
+// ============================================================ C ABI
+
+extern "C" {
+
+const char *kbbq_last_error(void) { return g_err; }
+
+int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
+    if (!params || !out) return fail(KBBQ_EINVAL, "null argument");
+    if (params->k < 1 || params->k > KBBQ_MAX_KMER) return fail(KBBQ_ERANGE, "k must be <= %d and > 0", KBBQ_MAX_KMER);
+    if (params->n_rg < 1 || params->n_rg > 65535) return fail(KBBQ_EINVAL, "n_rg must be in 1..65535");
+    if (params->max_read_len < 1 || params->max_read_len > KBBQ_MAX_READ_LEN)
+        return fail(KBBQ_ERANGE, "max_read_len must be in 1..%d", KBBQ_MAX_READ_LEN);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(KBBQ_ENODEV, "no HIP device visible");
+    if (params->device < 0 || params->device >= ndev) return fail(KBBQ_ENODEV, "device %d of %d", params->device, ndev);
+    HIP_TRY(hipSetDevice(params->device));
+    kbbq_engine *e = new kbbq_engine;
+    e->p = *params;
+    e->K.k = params->k;
+    e->K.shift = 2u * (unsigned)(params->k - 1);
+    e->K.mask = params->k < 32 ? ((1ULL << (2 * params->k)) - 1) : ~0ULL;
+    e->K.nmask_bits = params->k < 32 ? ((1u << params->k) - 1) : 0xFFFFFFFFu;
+    const double fprs[2] = {params->fpr_sampled, params->fpr_trusted};
+    for (int w = 0; w < 2; ++w) {
+        if (!make_filter_spec(params->approx_kmers, fprs[w], params->bloom_seed, e->filt[w].spec)) {
+            delete e;
+            // bloom.cc:18-21 throws std::invalid_argument
+            return fail(KBBQ_EINVAL, "Error: Invalid bloom filter parameters. Adjust parameters and try again.");
+        }
+    }
+    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (he != hipSuccess) { delete e; return fail(KBBQ_EIO, "hipStreamCreate: %s", hipGetErrorString(he)); }
+#define CREATE_TRY(expr)                                                                           \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            int code = _e == hipErrorOutOfMemory ? KBBQ_ENOMEM : KBBQ_EIO;                         \
+            fail(code, "%s: %s", #expr, hipGetErrorString(_e));                                    \
+            kbbq_engine_destroy(e);                                                                \
+            return code;                                                                           \
+        }                                                                                          \
+    } while (0)
+    CREATE_TRY(hipMalloc(&e->d_counters, 64));
+    CREATE_TRY(hipMemset(e->d_counters, 0, 64));
+    for (int w = 0; w < 2; ++w) {
+        FilterHost &f = e->filt[w];
+        CREATE_TRY(hipMalloc(&f.d_table, f.spec.n_blocks * 64));
+        CREATE_TRY(hipMalloc(&f.d_patterns, kNumPatterns * 64));
+        CREATE_TRY(hipMalloc(&f.d_inserted, 8));
+        CREATE_TRY(hipMemcpy(f.d_patterns, f.spec.patterns.data(), kNumPatterns * 64, hipMemcpyHostToDevice));
+    }
+    e->hist_cycle_words = (uint64_t)params->n_rg * kNQ * 2 * params->max_read_len * 2;
+    e->hist_dinuc_words = (uint64_t)params->n_rg * kNQ * 16 * 2;
+    CREATE_TRY(hipMalloc(&e->d_hist, (e->hist_cycle_words + e->hist_dinuc_words) * 8));
+    CREATE_TRY(hipMalloc(&e->d_dq_base, (size_t)params->n_rg * kNQ * 2));
+    CREATE_TRY(hipMalloc(&e->d_dq_cycle, (size_t)params->n_rg * kNQ * 2 * params->max_read_len));
+    CREATE_TRY(hipMalloc(&e->d_dq_dinuc, (size_t)params->n_rg * kNQ * 16));
+    CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_jump), xoshiro_jump_table(), 64 * 4 * 8));
+    e->seed_state.seed32(params->seed);   // KmerSubsampler ctor: rng.Seed(seed), htsiter.hh:143
+    e->draw_threshold = bernoulli_threshold(params->alpha, &e->draw_always);
+    int rc = kbbq_engine_reset(e);
+    if (rc) { kbbq_engine_destroy(e); return rc; }
+    CREATE_TRY(hipDeviceSynchronize());
+    *out = e;
+    return KBBQ_OK;
+}
+
+void kbbq_engine_destroy(kbbq_engine *e) {
+    if (!e) return;
+    if (e->stream) { hipStreamSynchronize(e->stream); }
+    drain_profile(e);
+    for (size_t i = 0; i < e->staged.size(); ++i) hipFree(e->staged[i]);
+    for (int w = 0; w < 2; ++w) {
+        hipFree(e->filt[w].d_table);
+        hipFree(e->filt[w].d_patterns);
+        hipFree(e->filt[w].d_inserted);
+    }
+    hipFree(e->d_hist);
+    hipFree(e->d_dq_base);
+    hipFree(e->d_dq_cycle);
+    hipFree(e->d_dq_dinuc);
+    hipFree(e->d_counters);
+    hipFree(e->d_qcum);
+    hipFree(e->d_errthr);
+    for (int i = 0; i < 8; ++i) hipFree(e->scratch[i]);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int kbbq_engine_reset(kbbq_engine *e) {
+    if (!e) return fail(KBBQ_EINVAL, "null engine");
+    for (int w = 0; w < 2; ++w) {
+        HIP_TRY(hipMemsetAsync(e->filt[w].d_table, 0, e->filt[w].spec.n_blocks * 64, e->stream));
+        HIP_TRY(hipMemsetAsync(e->filt[w].d_inserted, 0, 8, e->stream));
+    }
+    HIP_TRY(hipMemsetAsync(e->d_hist, 0, (e->hist_cycle_words + e->hist_dinuc_words) * 8, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_counters, 0, 64, e->stream));
+    e->thresholds_set = false;
+    e->dq_set = false;
+    memset(e->stats, 0, sizeof e->stats);
+    return sync_engine(e);
+}
+
+int kbbq_engine_sync(kbbq_engine *e) {
+    if (!e) return fail(KBBQ_EINVAL, "null engine");
+    return sync_engine(e);
+}
+
+void *kbbq_engine_stream(kbbq_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+int kbbq_filter_info_get(kbbq_engine *e, int which, kbbq_filter_info *out) {
+    if (!e || !out || which < 0 || which > 1) return fail(KBBQ_EINVAL, "bad argument");
+    const FilterSpec &s = e->filt[which].spec;
+    memset(out, 0, sizeof *out);
+    out->bits = s.bits;
+    out->bits_unblocked = s.bits_unblocked;
+    out->n_blocks = s.n_blocks;
+    out->random_seed = s.random_seed;
+    out->n_hash = s.n_hash;
+    out->n_salt = s.n_salt;
+    for (uint32_t i = 0; i < s.n_salt; ++i) out->salt[i] = s.salt[i];
+    int rc = sync_engine(e);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(&out->inserted, e->filt[which].d_inserted, 8, hipMemcpyDeviceToHost));
+    return KBBQ_OK;
+}
+
+void *kbbq_filter_device_table(kbbq_engine *e, int which) { return e && which >= 0 && which < 2 ? e->filt[which].d_table : nullptr; }
+void *kbbq_filter_device_counter(kbbq_engine *e, int which) { return e && which >= 0 && which < 2 ? e->filt[which].d_inserted : nullptr; }
+
+int kbbq_filter_download(kbbq_engine *e, int which, uint64_t *host_words, uint64_t n_words) {
+    if (!e || !host_words || which < 0 || which > 1) return fail(KBBQ_EINVAL, "bad argument");
+    if (n_words != e->filt[which].spec.n_blocks * 8) return fail(KBBQ_EINVAL, "filter has %llu words", (unsigned long long)e->filt[which].spec.n_blocks * 8);
+    int rc = sync_engine(e);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(host_words, e->filt[which].d_table, n_words * 8, hipMemcpyDeviceToHost));
+    return KBBQ_OK;
+}
+
+int kbbq_filter_patterns_download(kbbq_engine *e, int which, uint64_t *host_words) {
+    if (!e || !host_words || which < 0 || which > 1) return fail(KBBQ_EINVAL, "bad argument");
+    HIP_TRY(hipMemcpy(host_words, e->filt[which].d_patterns, kNumPatterns * 64, hipMemcpyDeviceToHost));
+    return KBBQ_OK;
+}
+
+int kbbq_filter_or_from(kbbq_engine *e, int which, const void *src_device, uint64_t word_offset, uint64_t n_words) {
+    if (!e || !src_device || which < 0 || which > 1) return fail(KBBQ_EINVAL, "bad argument");
+    const uint64_t total = e->filt[which].spec.n_blocks * 8;
+    if (word_offset > total || n_words > total - word_offset || (word_offset & 1)) return fail(KBBQ_EINVAL, "range outside the filter");
+    if (!n_words) return KBBQ_OK;
+    Timed t(e, "k_or_words");
+    hipLaunchKernelGGL(k_or_words, dim3((unsigned)((n_words / 2 + 256) / 256)), dim3(256), 0, e->stream,
+                       e->filt[which].d_table + word_offset, (const uint64_t *)src_device, n_words);
+    HIP_TRY(hipGetLastError());
+    return KBBQ_OK;
+}
+
+int kbbq_filter_set_inserted(kbbq_engine *e, int which, uint64_t inserted) {
+    if (!e || which < 0 || which > 1) return fail(KBBQ_EINVAL, "bad argument");
+    HIP_TRY(hipMemcpyAsync(e->filt[which].d_inserted, &inserted, 8, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return KBBQ_OK;
+}
+
+// ---- staging
+int kbbq_pack_bases(const uint8_t *seq, uint64_t n_bases, uint64_t *bases_out, uint64_t *nmask_out) {
+    if (!seq || !bases_out || !nmask_out) return fail(KBBQ_EINVAL, "null argument");
+    // seq_nt16_int[seq_nt16_table[ch]] (bloom.hh:351): A/a=0 C/c=1 G/g=2 T/t=3 and '0'..'3'; all else non-ACGT
+    uint8_t lut[256];
+    memset(lut, 4, sizeof lut);
+    lut['A'] = lut['a'] = 0; lut['C'] = lut['c'] = 1; lut['G'] = lut['g'] = 2; lut['T'] = lut['t'] = 3;
+    lut['0'] = 0; lut['1'] = 1; lut['2'] = 2; lut['3'] = 3;
+    memset(bases_out, 0, (n_bases / 32 + 2) * 8);
+    memset(nmask_out, 0, (n_bases / 64 + 2) * 8);
+    for (uint64_t i = 0; i < n_bases; ++i) {
+        const uint8_t c = lut[seq[i]];
+        if (c < 4) bases_out[i >> 5] |= (uint64_t)c << ((i & 31) * 2);
+        else nmask_out[i >> 6] |= 1ULL << (i & 63);
+    }
+    return KBBQ_OK;
+}
+
+int kbbq_reads_upload(kbbq_engine *e, const kbbq_reads *host, kbbq_reads *dev) {
+    if (!e || !host || !dev) return fail(KBBQ_EINVAL, "null argument");
+    if (host->on_device) return fail(KBBQ_EINVAL, "batch is already on the device");
+    *dev = *host;
+    dev->on_device = 1;
+    dev->bases = nullptr; dev->nmask = nullptr; dev->qual = nullptr; dev->offsets = nullptr; dev->flags = nullptr; dev->rg = nullptr;
+#define UP(field, type, count, pad)                                                               \
+    if (host->field) {                                                                            \
+        void *d = nullptr;                                                                        \
+        HIP_TRY(hipMalloc(&d, ((count) + (pad)) * sizeof(type)));                                 \
+        HIP_TRY(hipMemset(d, 0, ((count) + (pad)) * sizeof(type)));                               \
+        HIP_TRY(hipMemcpy(d, host->field, (count) * sizeof(type), hipMemcpyHostToDevice));        \
+        dev->field = (const type *)d;                                                             \
+    }
+    UP(bases, uint64_t, host->n_bases / 32 + 1, 1)
+    UP(nmask, uint64_t, host->n_bases / 64 + 1, 1)
+    UP(qual, uint8_t, host->n_bases, 16)
+    UP(offsets, uint64_t, host->n_reads + 1, 0)
+    UP(flags, uint8_t, host->n_reads, 0)
+    UP(rg, uint16_t, host->n_reads, 0)
+#undef UP
+    HIP_TRY(hipDeviceSynchronize());
+    return KBBQ_OK;
+}
+
+int kbbq_reads_free(kbbq_engine *e, kbbq_reads *dev) {
+    if (!e || !dev) return fail(KBBQ_EINVAL, "null argument");
+    if (!dev->on_device) return fail(KBBQ_EINVAL, "not a device batch");
+    int rc = sync_engine(e);
+    if (rc) return rc;
+    hipFree((void *)dev->bases); hipFree((void *)dev->nmask); hipFree((void *)dev->qual);
+    hipFree((void *)dev->offsets); hipFree((void *)dev->flags); hipFree((void *)dev->rg);
+    memset(dev, 0, sizeof *dev);
+    return KBBQ_OK;
+}
+
+// ---- pass 1
+int kbbq_count_kmer_positions(kbbq_engine *e, const kbbq_reads *reads, uint64_t *out) {
+    if (!e || !reads || !out) return fail(KBBQ_EINVAL, "null argument");
+    ReadsDev R; int max_len;
+    int rc = device_view(e, reads, &R, &max_len);
+    if (rc) return rc;
+    const uint64_t *kofs;
+    return kmer_prefix(e, R, &kofs, out);
+}
+
+}  // extern "C"
+template <template <int> class Launcher, typename... Args>
+static int dispatch_nw(int max_len, Args... args) {
+    if (max_len <= 192) return Launcher<3>::go(args...);
+    if (max_len <= 320) return Launcher<5>::go(args...);
+    return Launcher<8>::go(args...);
+}
+
+extern "C" {
+
+}  // extern "C"
+template <int NW> struct LaunchSample {
+    static int go(kbbq_engine *e, ReadsDev R, const uint64_t *mask, const uint64_t *kofs) {
+        Timed t(e, "k_sample_insert");
+        hipLaunchKernelGGL(k_sample_insert<NW>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
+                           e->filt[0].dev(), mask, kofs, e->filt[0].d_inserted);
+        HIP_TRY(hipGetLastError());
+        return KBBQ_OK;
+    }
+};
+
+extern "C" {
+
+int kbbq_sample_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t first_kmer_ordinal) {
+    if (!e) return fail(KBBQ_EINVAL, "null engine");
+    ReadsDev R; int max_len;
+    int rc = device_view(e, reads, &R, &max_len);
+    if (rc) return rc;
+    const uint64_t *kofs; uint64_t n_draws;
+    if ((rc = kmer_prefix(e, R, &kofs, &n_draws))) return rc;
+    if (n_draws == 0) return KBBQ_OK;
+    if ((rc = ensure_scratch(e, 0, (n_draws / 64 + 2) * 8))) return rc;
+    uint64_t *mask = (uint64_t *)e->scratch[0];
+    {
+        Timed t(e, "k_draw_mask");
+        const uint64_t lanes = (n_draws + DRAWS_PER_LANE - 1) / DRAWS_PER_LANE;
+        hipLaunchKernelGGL(k_draw_mask, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, e->stream,
+                           e->seed_state.s[0], e->seed_state.s[1], e->seed_state.s[2], e->seed_state.s[3],
+                           first_kmer_ordinal, n_draws, e->draw_threshold, e->draw_always ? 1 : 0, mask);
+        HIP_TRY(hipGetLastError());
+    }
+    return dispatch_nw<LaunchSample>(max_len, e, R, (const uint64_t *)mask, kofs);
+}
+
+int kbbq_sample_finish(kbbq_engine *e, uint64_t *inserted) {
+    if (!e) return fail(KBBQ_EINVAL, "null engine");
+    int rc = sync_engine(e);
+    if (rc) return rc;
+    if (inserted) HIP_TRY(hipMemcpy(inserted, e->filt[0].d_inserted, 8, hipMemcpyDeviceToHost));
+    return KBBQ_OK;
+}
+
+// ---- between passes
+int kbbq_compute_thresholds(kbbq_engine *e, const char *alpha_text, int32_t *thresholds_out, double *fpr_out,
+                            char *p_text_out, size_t p_text_len) {
+    if (!e || !alpha_text) return fail(KBBQ_EINVAL, "null argument");
+    int rc = sync_engine(e);
+    if (rc) return rc;
+    uint64_t inserted = 0;
+    HIP_TRY(hipMemcpy(&inserted, e->filt[0].d_inserted, 8, hipMemcpyDeviceToHost));
+    if (inserted == 0) return fail(KBBQ_ESTATE, "no k-mers were sampled");   // the reference divides by zero (bloom.hh:319)
+    double fpr = 0;
+    std::string p_text;
+    e->thresholds = thresholds_from_counts(e->p.k, e->filt[0].spec.bits, inserted, e->filt[0].spec.n_salt, alpha_text, &fpr, &p_text);
+    if (fpr_out) *fpr_out = fpr;
+    if (p_text_out && p_text_len) snprintf(p_text_out, p_text_len, "%s", p_text.c_str());
+    if (thresholds_out) memcpy(thresholds_out, e->thresholds.data(), (e->p.k + 1) * 4);
+    rc = kbbq_set_thresholds(e, e->thresholds.data(), e->p.k + 1);
+    if (rc) return rc;
+    return fpr > .15 ? 1 : 0;   // kbbq.cc:306
+}
+
+int kbbq_set_thresholds(kbbq_engine *e, const int32_t *thresholds, int32_t n) {
+    if (!e || !thresholds) return fail(KBBQ_EINVAL, "null argument");
+    if (n != e->p.k + 1) return fail(KBBQ_EINVAL, "expected k+1 = %d thresholds", e->p.k + 1);
+    if (thresholds != e->thresholds.data()) e->thresholds.assign(thresholds, thresholds + n);
+    e->thresholds_set = true;
+    return KBBQ_OK;
+}
+
+// ---- pass 2
+}  // extern "C"
+template <int NW> struct LaunchTrusted {
+    static int go(kbbq_engine *e, ReadsDev R, uint32_t *err_out) {
+        Timed t(e, "k_trusted");
+        Thresholds thr;
+        memset(&thr, 0, sizeof thr);
+        for (size_t i = 0; i < e->thresholds.size() && i <= KBBQ_MAX_KMER; ++i) thr.v[i] = e->thresholds[i];
+        hipLaunchKernelGGL(k_trusted<NW>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
+                           e->filt[0].dev(), e->filt[1].dev(), thr, e->filt[1].d_inserted, err_out);
+        HIP_TRY(hipGetLastError());
+        return KBBQ_OK;
+    }
+};
+
+extern "C" {
+
+static int bit_out_begin(kbbq_engine *e, const kbbq_reads *reads, uint64_t *user, int slot, uint32_t **dev) {
+    *dev = nullptr;
+    if (!user) return KBBQ_OK;
+    const size_t bytes = (reads->n_bases / 64 + 2) * 8;
+    if (reads->on_device) {
+        *dev = (uint32_t *)user;
+    } else {
+        int rc = ensure_scratch(e, slot, bytes);
+        if (rc) return rc;
+        *dev = (uint32_t *)e->scratch[slot];
+    }
+    HIP_TRY(hipMemsetAsync(*dev, 0, (reads->n_bases / 64 + 1) * 8, e->stream));
+    return KBBQ_OK;
+}
+static int bit_out_end(kbbq_engine *e, const kbbq_reads *reads, uint64_t *user, uint32_t *dev) {
+    if (!user || reads->on_device) return KBBQ_OK;
+    HIP_TRY(hipMemcpyAsync(user, dev, (reads->n_bases / 64 + 1) * 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return KBBQ_OK;
+}
+
+int kbbq_trusted_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *infer_errors_out) {
+    if (!e) return fail(KBBQ_EINVAL, "null engine");
+    if (!e->thresholds_set) return fail(KBBQ_ESTATE, "thresholds are not set");
+    ReadsDev R; int max_len;
+    int rc = device_view(e, reads, &R, &max_len);
+    if (rc) return rc;
+    uint32_t *d_err;
+    if ((rc = bit_out_begin(e, reads, infer_errors_out, 2, &d_err))) return rc;
+    if ((rc = dispatch_nw<LaunchTrusted>(max_len, e, R, d_err))) return rc;
+    return bit_out_end(e, reads, infer_errors_out, d_err);
+}
+
+int kbbq_trusted_finish(kbbq_engine *e, uint64_t *inserted) {
+    if (!e) return fail(KBBQ_EINVAL, "null engine");
+    int rc = sync_engine(e);
+    if (rc) return rc;
+    if (inserted) HIP_TRY(hipMemcpy(inserted, e->filt[1].d_inserted, 8, hipMemcpyDeviceToHost));
+    return KBBQ_OK;
+}
+
+// ---- pass 3
+}  // extern "C"
+template <int NW> struct LaunchScan {
+    static int go(kbbq_engine *e, ReadsDev R, uint64_t *tmask, uint8_t *dirty) {
+        Timed t(e, "k_scan_trusted");
+        hipLaunchKernelGGL(k_scan_trusted<NW>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
+                           e->filt[1].dev(), tmask, dirty);
+        HIP_TRY(hipGetLastError());
+        return KBBQ_OK;
+    }
+};
+
+extern "C" {
+
+}  // extern "C"
+template <int MAXL, int BLOCK>
+static int launch_correct(kbbq_engine *e, ReadsDev R, const uint32_t *list, const uint64_t *tmask, int tw,
+                          uint32_t *err_bits, uint32_t *patch) {
+    typedef Corrector<MAXL> C;
+    const size_t lds = (size_t)C::WORDS * BLOCK * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_correct<MAXL, BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    Timed t(e, "k_correct");
+    // the work-list length is only known on the device: size the grid for the batch and let lanes stride
+    const int blocks = (int)std::min<uint64_t>((R.n_reads + BLOCK - 1) / BLOCK, 256 * 8);
+    hipLaunchKernelGGL((k_correct<MAXL, BLOCK>), dim3(blocks), dim3(BLOCK), lds, e->stream, R, e->K, e->filt[1].dev(), list,
+                       (const unsigned long long *)&e->d_counters[0], tmask, tw, err_bits, patch, e->d_counters);
+    HIP_TRY(hipGetLastError());
+    return KBBQ_OK;
+}
+
+extern "C" {
+
+static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits, const uint32_t *patch, int max_len) {
+    HistDev H;
+    H.cycle = e->d_hist;
+    H.dinuc = e->d_hist + e->hist_cycle_words;
+    H.n_rg = e->p.n_rg;
+    H.n_cycle = e->p.max_read_len;
+    int ccap = std::min(((max_len + 31) / 32) * 32, 384);
+    const size_t lds = ((size_t)(2 * ccap * KBBQ_NQ + 1) / 2 + KBBQ_NQ * 16) * 4;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_tally, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    Timed t(e, "k_tally");
+    const int blocks = (int)std::min<uint64_t>((R.n_reads + 3) / 4, 256 * 2);
+    hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(256), lds, e->stream, R, H, err_bits, patch, ccap, 6);
+    HIP_TRY(hipGetLastError());
+    return KBBQ_OK;
+}
+
+int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_out) {
+    if (!e) return fail(KBBQ_EINVAL, "null engine");
+    ReadsDev R; int max_len;
+    int rc = device_view(e, reads, &R, &max_len);
+    if (rc) return rc;
+    const int NW = max_len <= 192 ? 3 : max_len <= 320 ? 5 : 8;
+    // scratch: 3 = trusted masks, 4 = dirty flags, 5 = work list, 6 = error bits, 7 = seq patches
+    if ((rc = ensure_scratch(e, 3, R.n_reads * NW * 8))) return rc;
+    if ((rc = ensure_scratch(e, 4, R.n_reads))) return rc;
+    if ((rc = ensure_scratch(e, 5, R.n_reads * 4))) return rc;
+    if ((rc = ensure_scratch(e, 7, R.n_reads * 4))) return rc;
+    uint32_t *d_err;
+    const bool own_err = !(errors_out && reads->on_device);
+    if (own_err) {
+        if ((rc = ensure_scratch(e, 6, (R.n_bases / 64 + 2) * 8))) return rc;
+        d_err = (uint32_t *)e->scratch[6];
+    } else {
+        d_err = (uint32_t *)errors_out;
+    }
+    HIP_TRY(hipMemsetAsync(d_err, 0, (R.n_bases / 64 + 1) * 8, e->stream));
+    HIP_TRY(hipMemsetAsync(e->scratch[7], 0, R.n_reads * 4, e->stream));
+    HIP_TRY(hipMemsetAsync(&e->d_counters[0], 0, 16, e->stream));
+    uint64_t *tmask = (uint64_t *)e->scratch[3];
+    uint8_t *dirty = (uint8_t *)e->scratch[4];
+    uint32_t *list = (uint32_t *)e->scratch[5];
+    uint32_t *patch = (uint32_t *)e->scratch[7];
+    if ((rc = dispatch_nw<LaunchScan>(max_len, e, R, tmask, dirty))) return rc;
+    {
+        Timed t(e, "k_compact");
+        hipLaunchKernelGGL(k_compact, dim3((unsigned)((R.n_reads + 255) / 256)), dim3(256), 0, e->stream, dirty, R.n_reads, list, &e->d_counters[0]);
+        HIP_TRY(hipGetLastError());
+    }
+    if (max_len <= 160) rc = launch_correct<160, 256>(e, R, list, tmask, NW, d_err, patch);
+    else if (max_len <= 320) rc = launch_correct<320, 128>(e, R, list, tmask, NW, d_err, patch);
+    else rc = launch_correct<512, 64>(e, R, list, tmask, NW, d_err, patch);
+    if (rc) return rc;
+    if ((rc = run_tally(e, R, d_err, patch, max_len))) return rc;
+    {
+        unsigned long long c[2];
+        HIP_TRY(hipMemcpyAsync(c, e->d_counters, 16, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        e->stats[0] += c[0];
+        e->stats[1] += c[1];
+        e->stats[2] += R.n_reads;
+    }
+    if (errors_out && !reads->on_device) {
+        HIP_TRY(hipMemcpyAsync(errors_out, d_err, (R.n_bases / 64 + 1) * 8, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    return KBBQ_OK;
+}
+
+int kbbq_tally_batch(kbbq_engine *e, const kbbq_reads *reads, const uint64_t *errors) {
+    if (!e || !errors) return fail(KBBQ_EINVAL, "null argument");
+    ReadsDev R; int max_len;
+    int rc = device_view(e, reads, &R, &max_len);
+    if (rc) return rc;
+    const uint32_t *d_err = (const uint32_t *)errors;
+    if (!reads->on_device) {
+        const uint64_t *tmp;
+        if ((rc = stage_array(e, errors, reads->n_bases / 64 + 1, 1, &tmp))) return rc;
+        d_err = (const uint32_t *)tmp;
+    }
+    return run_tally(e, R, d_err, nullptr, max_len);
+}
+
+void *kbbq_covariates_device(kbbq_engine *e, uint64_t *n_words) {
+    if (!e) return nullptr;
+    if (n_words) *n_words = e->hist_cycle_words + e->hist_dinuc_words;
+    return e->d_hist;
+}
+
+static int fetch_hist(kbbq_engine *e, std::vector<uint64_t> &cyc, std::vector<uint64_t> &di) {
+    int rc = sync_engine(e);
+    if (rc) return rc;
+    cyc.resize(e->hist_cycle_words);
+    di.resize(e->hist_dinuc_words);
+    HIP_TRY(hipMemcpy(cyc.data(), e->d_hist, e->hist_cycle_words * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(di.data(), e->d_hist + e->hist_cycle_words, e->hist_dinuc_words * 8, hipMemcpyDeviceToHost));
+    return KBBQ_OK;
+}
+
+int kbbq_covariates_get(kbbq_engine *e, kbbq_covariates *out) {
+    if (!e || !out) return fail(KBBQ_EINVAL, "null argument");
+    std::vector<uint64_t> cyc, di, q, rg;
+    int rc = fetch_hist(e, cyc, di);
+    if (rc) return rc;
+    derive_q_rg(e->p.n_rg, e->p.max_read_len, cyc.data(), q, rg);
+    out->n_rg = e->p.n_rg;
+    out->n_cycle = e->p.max_read_len;
+    if (out->rg) memcpy(out->rg, rg.data(), rg.size() * 8);
+    if (out->q) memcpy(out->q, q.data(), q.size() * 8);
+    if (out->cycle) memcpy(out->cycle, cyc.data(), cyc.size() * 8);
+    if (out->dinuc) memcpy(out->dinuc, di.data(), di.size() * 8);
+    return KBBQ_OK;
+}
+
+int kbbq_train(kbbq_engine *e) {
+    if (!e) return fail(KBBQ_EINVAL, "null engine");
+    std::vector<uint64_t> cyc, di, q, rg;
+    int rc = fetch_hist(e, cyc, di);
+    if (rc) return rc;
+    derive_q_rg(e->p.n_rg, e->p.max_read_len, cyc.data(), q, rg);
+    e->dq = train_model(e->p.n_rg, e->p.max_read_len, rg.data(), q.data(), cyc.data(), di.data());
+    return upload_dq(e);
+}
+
+int kbbq_dq_get(kbbq_engine *e, kbbq_dq *out) {
+    if (!e || !out) return fail(KBBQ_EINVAL, "null argument");
+    if (!e->dq_set) return fail(KBBQ_ESTATE, "no delta-Q tables yet");
+    const DqTables &d = e->dq;
+    out->n_rg = d.n_rg;
+    out->n_cycle = d.n_cycle;
+    if (out->meanq) memcpy(out->meanq, d.meanq.data(), d.meanq.size() * 4);
+    if (out->rgdq) memcpy(out->rgdq, d.rgdq.data(), d.rgdq.size() * 4);
+    if (out->qdq) memcpy(out->qdq, d.qdq.data(), d.qdq.size() * 4);
+    if (out->cycledq) memcpy(out->cycledq, d.cycledq.data(), d.cycledq.size() * 4);
+    if (out->dinucdq) memcpy(out->dinucdq, d.dinucdq.data(), d.dinucdq.size() * 4);
+    return KBBQ_OK;
+}
+
+int kbbq_set_dq(kbbq_engine *e, const kbbq_dq *in) {
+    if (!e || !in || !in->meanq || !in->rgdq || !in->qdq || !in->cycledq || !in->dinucdq) return fail(KBBQ_EINVAL, "null argument");
+    if (in->n_rg != (uint64_t)e->p.n_rg || in->n_cycle != (uint64_t)e->p.max_read_len)
+        return fail(KBBQ_EINVAL, "delta-Q tables must be [%d rg][%d cycles]", e->p.n_rg, e->p.max_read_len);
+    DqTables &d = e->dq;
+    d.n_rg = in->n_rg;
+    d.n_cycle = in->n_cycle;
+    d.meanq.assign(in->meanq, in->meanq + d.n_rg);
+    d.rgdq.assign(in->rgdq, in->rgdq + d.n_rg);
+    d.qdq.assign(in->qdq, in->qdq + d.n_rg * kNQ);
+    d.cycledq.assign(in->cycledq, in->cycledq + d.n_rg * kNQ * 2 * d.n_cycle);
+    d.dinucdq.assign(in->dinucdq, in->dinucdq + d.n_rg * kNQ * 16);
+    return upload_dq(e);
+}
+
+// ---- pass 4
+int kbbq_recalibrate_batch(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qual_out) {
+    if (!e || !qual_out) return fail(KBBQ_EINVAL, "null argument");
+    if (!e->dq_set) return fail(KBBQ_ESTATE, "no delta-Q tables yet");
+    ReadsDev R; int max_len;
+    int rc = device_view(e, reads, &R, &max_len);
+    if (rc) return rc;
+    uint8_t *d_out = qual_out;
+    if (!reads->on_device) {
+        if ((rc = ensure_scratch(e, 2, R.n_bases + 16))) return rc;
+        d_out = (uint8_t *)e->scratch[2];
+    }
+    DqDev D;
+    D.base = e->d_dq_base; D.cycle = e->d_dq_cycle; D.dinuc = e->d_dq_dinuc;
+    D.n_rg = e->p.n_rg; D.n_cycle = e->p.max_read_len;
+    {
+        Timed t(e, "k_recalibrate");
+        const uint64_t lanes = (R.n_bases + 15) / 16;
+        const int vec_ok = (((uintptr_t)R.qual | (uintptr_t)d_out) & 15) == 0;
+        hipLaunchKernelGGL(k_recalibrate, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, e->stream, R, D, d_out, 6, vec_ok);
+        HIP_TRY(hipGetLastError());
+    }
+    if (!reads->on_device) {
+        HIP_TRY(hipMemcpyAsync(qual_out, d_out, R.n_bases, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    return KBBQ_OK;
+}
+
+// ---- synthetic data
+int kbbq_synth_tables(const kbbq_synth_params *sp, uint32_t *qcum /* [read_len][4] */, uint32_t *errthr /* [94] */) {
+    if (!sp || !qcum || !errthr) return fail(KBBQ_EINVAL, "null argument");
+    // Quality profile: a few discrete values whose low-quality share grows
+    // quadratically along the read; substitution probability 10^(-q/10).
+    const uint32_t L = sp->read_len;
+    for (uint32_t c = 0; c < L; ++c) {
+        const double f = L > 1 ? (double)c / (double)(L - 1) : 0.0;
+        const double w2 = 0.002 + 0.010 * f * f, w12 = 0.010 + 0.080 * f * f, w22 = 0.030 + 0.120 * f * f,
+                     w32 = 0.100 + 0.100 * f;
+        const double cum[4] = {w2, w2 + w12, w2 + w12 + w22, w2 + w12 + w22 + w32};
+        for (int j = 0; j < 4; ++j) qcum[4 * c + j] = (uint32_t)(cum[j] * 4294967296.0);
+    }
+    for (int q = 0; q < 94; ++q) {
+        const double p = pow(10.0, -q / 10.0);
+        errthr[q] = p >= 1.0 ? 0xFFFFFFFFu : (uint32_t)(p * 4294967296.0);
+    }
+    return KBBQ_OK;
+}
+
+int kbbq_synth_reads(kbbq_engine *e, const kbbq_synth_params *sp, uint64_t first_read, uint64_t n, kbbq_reads *dev) {
+    if (!e || !sp || !dev || n == 0) return fail(KBBQ_EINVAL, "bad argument");
+    if (sp->read_len == 0 || sp->genome_len < sp->read_len || sp->n_rg == 0) return fail(KBBQ_EINVAL, "bad synthetic parameters");
+    if (e->qcum_len != sp->read_len) {
+        std::vector<uint32_t> qc(4 * (size_t)sp->read_len), et(94);
+        kbbq_synth_tables(sp, qc.data(), et.data());
+        hipFree(e->d_qcum); hipFree(e->d_errthr);
+        e->d_qcum = e->d_errthr = nullptr;
+        HIP_TRY(hipMalloc(&e->d_qcum, qc.size() * 4));
+        HIP_TRY(hipMalloc(&e->d_errthr, 94 * 4));
+        HIP_TRY(hipMemcpy(e->d_qcum, qc.data(), qc.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->d_errthr, et.data(), 94 * 4, hipMemcpyHostToDevice));
+        e->qcum_len = sp->read_len;
+    }
+    const uint64_t nb = n * sp->read_len;
+    memset(dev, 0, sizeof *dev);
+    dev->n_reads = n; dev->n_bases = nb; dev->read_len = sp->read_len; dev->on_device = 1;
+    void *b = nullptr, *m = nullptr, *q = nullptr, *f = nullptr, *g = nullptr;
+    HIP_TRY(hipMalloc(&b, (nb / 32 + 2) * 8));
+    HIP_TRY(hipMalloc(&m, (nb / 64 + 2) * 8));
+    HIP_TRY(hipMalloc(&q, nb + 16));
+    HIP_TRY(hipMalloc(&f, n));
+    HIP_TRY(hipMalloc(&g, n * 2));
+    HIP_TRY(hipMemsetAsync(b, 0, (nb / 32 + 2) * 8, e->stream));
+    HIP_TRY(hipMemsetAsync(m, 0, (nb / 64 + 2) * 8, e->stream));
+    HIP_TRY(hipMemsetAsync((char *)q + nb, 0, 16, e->stream));
+    dev->bases = (const uint64_t *)b; dev->nmask = (const uint64_t *)m; dev->qual = (const uint8_t *)q;
+    dev->flags = (const uint8_t *)f; dev->rg = (const uint16_t *)g;
+    SynthDev S;
+    S.seed = sp->seed; S.genome_len = sp->genome_len; S.first_read = first_read; S.n_reads = n;
+    S.read_len = sp->read_len; S.n_rg = sp->n_rg; S.paired = sp->paired;
+    S.n_thr = (uint32_t)(((uint64_t)sp->n_per_million << 20) / 1000000ULL);
+    S.qcum = e->d_qcum; S.errthr = e->d_errthr;
+    const uint64_t words = (nb + 31) / 32;
+    hipLaunchKernelGGL(k_synth, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, e->stream, S, (uint64_t *)b,
+                       (uint64_t *)m, (uint8_t *)q, (uint8_t *)f, (uint16_t *)g);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return KBBQ_OK;
+}
+
+// ---- measurement
+int kbbq_profile_get(kbbq_engine *e, kbbq_profile_entry *out, int32_t max_entries, int32_t *n_out) {
+    if (!e || !n_out) return fail(KBBQ_EINVAL, "null argument");
+    int rc = sync_engine(e);
+    if (rc) return rc;
+    int n = 0;
+    for (size_t i = 0; i < e->prof.size() && n < max_entries; ++i, ++n) {
+        if (!out) continue;
+        snprintf(out[n].name, sizeof out[n].name, "%s", e->prof[i].name.c_str());
+        out[n].launches = e->prof[i].launches;
+        out[n].total_ms = e->prof[i].ms;
+    }
+    *n_out = (int)e->prof.size();
+    return KBBQ_OK;
+}
+
+int kbbq_profile_reset(kbbq_engine *e) {
+    if (!e) return fail(KBBQ_EINVAL, "null engine");
+    int rc = sync_engine(e);
+    if (rc) return rc;
+    for (size_t i = 0; i < e->prof.size(); ++i) { e->prof[i].launches = 0; e->prof[i].ms = 0; }
+    return KBBQ_OK;
+}
+
+int kbbq_stats_get(kbbq_engine *e, uint64_t *out, int32_t n) {
+    if (!e || !out) return fail(KBBQ_EINVAL, "null argument");
+    for (int i = 0; i < n && i < 4; ++i) out[i] = e->stats[i];
+    return KBBQ_OK;
+}
+
+int kbbq_rng_state_at(uint32_t seed, uint64_t ordinal, uint64_t state_out[4]) {
+    if (!state_out) return fail(KBBQ_EINVAL, "null argument");
+    xoshiro_state_at(seed, ordinal, state_out);
+    return KBBQ_OK;
+}
+
+}  // extern "C"

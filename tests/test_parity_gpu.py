@@ -1,0 +1,158 @@
+"""GPU parity: the HIP engine (through the C ABI) against the oracle, bit for bit,
+on seeded inputs small enough for the oracle to finish in seconds.
+
+Run on the GPU box with `pytest -m gpu`.  There is no CPU fallback: without the
+HIP library or without a GPU these tests fail.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import common
+from kbbq_amd import _lib, synth
+from kbbq_amd.engine import Engine, device_tensor
+from kbbq_amd.reads import ReadBatch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_library_loaded_and_gpu_present():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU: the engine has no CPU path"
+    assert _lib.lib() is not None
+
+
+def test_uniform_150bp_single_rg():
+    d = common.make_dataset(seed=12345, genome_len=30000, coverage=20)
+    ora = common.run_oracle(d)
+    eng = common.run_engine(d, uniform=True)
+    common.assert_same_run(eng, ora)
+    assert eng["stats"]["corrected_reads"] > 0
+
+
+def test_ragged_short_reads_two_rg_paired_three_batches():
+    d = common.make_dataset(seed=99, genome_len=25000, coverage=24, n_rg=2, paired=True, n_per_million=3000,
+                            ragged=True, short_reads=40)
+    ora = common.run_oracle(d, n_rg=2)
+    eng = common.run_engine(d, n_rg=2, uniform=False, n_batches=3)
+    common.assert_same_run(eng, ora)
+
+
+def test_batching_does_not_change_results():
+    d = common.make_dataset(seed=5, genome_len=15000, coverage=20)
+    one = common.run_engine(d, uniform=True, n_batches=1)
+    many = common.run_engine(d, uniform=False, n_batches=7)
+    for key in ("sampled_table", "trusted_table", "errors", "recal", "infer_errors"):
+        assert np.array_equal(one[key], many[key]), key
+    assert one["sampled_inserted"] == many["sampled_inserted"]
+
+
+def test_k21_low_alpha():
+    d = common.make_dataset(seed=777, genome_len=20000, coverage=40, read_len=100)
+    ora = common.run_oracle(d, k=21, alpha=0.05)
+    eng = common.run_engine(d, k=21, alpha=0.05, uniform=True)
+    common.assert_same_run(eng, ora)
+
+
+def test_250bp_reads():
+    d = common.make_dataset(seed=31, genome_len=20000, coverage=20, read_len=250, n_per_million=1000)
+    ora = common.run_oracle(d)
+    eng = common.run_engine(d, uniform=True)
+    common.assert_same_run(eng, ora)
+
+
+def test_noisy_low_coverage_exercises_correct_one():
+    # low coverage leaves many reads without any trusted k-mer -> correct_one, bad prefix/suffix recursion
+    d = common.make_dataset(seed=4242, genome_len=40000, coverage=8, n_per_million=5000)
+    ora = common.run_oracle(d)
+    eng = common.run_engine(d, uniform=True)
+    common.assert_same_run(eng, ora)
+
+
+def test_device_synth_matches_host_twin():
+    sp = synth.synth_params(2024, 50000, 3000, 150, n_rg=3, paired=True, n_per_million=2000)
+    host = synth.generate(sp, first_read=100, n=1000)
+    e = Engine(32, 0.35, 777, 100000, n_rg=3, max_read_len=150)
+    dev = e.synth_reads(sp, 100, 1000)
+    got = e.download(dev)
+    ref = ReadBatch(host["seq"], host["qual"], host["off"], host["rg"], host["second"], uniform=True)
+    nb = ref.n_bases
+    assert np.array_equal(got["qual"][:nb], ref.qual[:nb])
+    assert np.array_equal(got["bases"][:nb // 32], ref.bases[:nb // 32])
+    assert np.array_equal(got["nmask"][:nb // 64], ref.nmask[:nb // 64])
+    assert np.array_equal(got["rg"], ref.rg)
+    assert np.array_equal(got["flags"], ref.flags)
+    dev.free()
+    e.close()
+
+
+def test_device_resident_batches_match_host_batches():
+    d = common.make_dataset(seed=8, genome_len=12000, coverage=20)
+    host_run = common.run_engine(d, uniform=True)
+    alpha_ld, cov, approx = common.plan_parameters(d["genome_len"], d["coverage"], None)
+    e = Engine(32, alpha_ld, 777, approx, n_rg=1, max_read_len=150)
+    hb = ReadBatch(d["seq"], d["qual"], d["off"], d["rg"], d["second"], uniform=True)
+    db = e.upload(hb)
+    e.subsample_kmers(db, 0)
+    assert e.sample_finish() == host_run["sampled_inserted"]
+    e.compute_thresholds()
+    e.find_trusted_kmers(db)
+    assert e.trusted_finish() == host_run["trusted_inserted"]
+    e.get_covariatedata(db)
+    cov_d = e.covariates()
+    assert np.array_equal(cov_d["cycle"], host_run["cov"]["cycle"])
+    e.get_dqs()
+    import torch
+    out = torch.zeros(hb.n_bases + 16, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()   # the engine runs on its own stream
+    e.recalibrate(db, out.data_ptr())
+    e.sync()
+    assert np.array_equal(out.cpu().numpy()[:hb.n_bases], host_run["recal"])
+    # filters are visible to torch without a copy (what the multi-GPU exchange relies on)
+    info = e.filter_info(1)
+    t = device_tensor(e.L.kbbq_filter_device_table(e.h, 1), info["n_blocks"] * 64, torch.int64)
+    assert np.array_equal(t.cpu().numpy().view(np.uint64), host_run["trusted_table"])
+    db.free()
+    e.close()
+
+
+def test_fixed_mode_tally_matches_oracle():
+    # --fixed (kbbq.cc:367-378): caller-supplied error flags feed the tally directly
+    d = common.make_dataset(seed=77, genome_len=8000, coverage=15, n_rg=2, paired=True)
+    rng = np.random.RandomState(1)
+    err = (rng.rand(len(d["seq"])) < 0.01).astype(np.uint8)
+    from oracle import pyoracle
+    o = pyoracle.Oracle(32, 0.35, 1, 10000)
+    o.tally(d["seq"], d["qual"], d["off"], np.ascontiguousarray(d["rg"], np.int32), d["second"], err)
+    oc = o.covariates()
+    from kbbq_amd.reads import pack_bits
+    e = Engine(32, 0.35, 1, 10000, n_rg=2, max_read_len=150)
+    b = ReadBatch(d["seq"], d["qual"], d["off"], d["rg"], d["second"], uniform=True)
+    e.tally(b, pack_bits(err))
+    ec = e.covariates()
+    for key in ("rg", "q", "cycle", "dinuc"):
+        assert np.array_equal(ec[key], oc[key]), key
+    e.close()
+
+
+def test_error_codes():
+    L = _lib.lib()
+    p = _lib.Params()
+    p.k, p.alpha, p.seed, p.n_rg, p.approx_kmers = 33, 0.3, 1, 1, 1000
+    p.fpr_sampled, p.fpr_trusted, p.bloom_seed, p.max_read_len = 0.01, 0.0005, _lib.DEFAULT_BLOOM_SEED, 150
+    h = _lib.c_vp()
+    assert L.kbbq_engine_create(ctypes.byref(p), ctypes.byref(h)) == -34   # k > 32 (kbbq.cc:102)
+    p.k = 32
+    p.bloom_seed = 0
+    assert L.kbbq_engine_create(ctypes.byref(p), ctypes.byref(h)) == -22   # invalid bloom parameters (bloom.cc:18-21)
+    assert b"Invalid bloom filter parameters" in L.kbbq_last_error()
+    e = Engine(32, 0.35, 1, 10000)
+    d = common.make_dataset(seed=3, genome_len=2000, coverage=5)
+    b = ReadBatch(d["seq"], d["qual"], d["off"], uniform=True)
+    with pytest.raises(_lib.KbbqError) as ei:
+        e.find_trusted_kmers(b)       # thresholds not set yet
+    assert ei.value.code == -1
+    with pytest.raises(_lib.KbbqError):
+        e.recalibrate(b)              # no delta-Q tables yet
+    e.close()
