@@ -940,11 +940,13 @@ Read make_read(const Batch &b, uint64_t r) {
 // ===========================================================================
 extern "C" {
 
-void *ko_new(int k, double alpha, uint32_t seed, uint64_t approx_kmers, double fpr_sampled, double fpr_trusted,
-             uint64_t bloom_seed) {
+// alpha_text: the reference keeps alpha in long double (kbbq.cc:83,251); it is
+// narrowed to double only for the sampler (htsiter.hh:143)
+void *ko_new(int k, const char *alpha_text, uint32_t seed, uint64_t approx_kmers, double fpr_sampled,
+             double fpr_trusted, uint64_t bloom_seed) {
     Ctx *c = new Ctx;
     c->k = k;
-    c->alpha = alpha;
+    c->alpha = strtold(alpha_text, nullptr);
     c->seed = seed;
     c->sampled.build(approx_kmers, fpr_sampled, bloom_seed, true);
     c->trusted.build(approx_kmers, fpr_trusted, bloom_seed, true);

@@ -36,7 +36,7 @@ def lib():
     if _LIB is None:
         L = ctypes.CDLL(build())
         L.ko_new.restype = ctypes.c_void_p
-        L.ko_new.argtypes = [ctypes.c_int, c_dbl, c_u32, c_u64, c_dbl, c_dbl, c_u64]
+        L.ko_new.argtypes = [ctypes.c_int, ctypes.c_char_p, c_u32, c_u64, c_dbl, c_dbl, c_u64]
         L.ko_free.argtypes = [ctypes.c_void_p]
         for name in ("ko_filter_bits", "ko_filter_bits_unblocked", "ko_filter_random_seed", "ko_filter_inserted"):
             getattr(L, name).restype = c_u64
@@ -141,7 +141,9 @@ class Oracle:
                  fpr_trusted=float(np.longdouble("0.0005")), bloom_seed=DEFAULT_BLOOM_SEED):
         self.L = lib()
         self.k = k
-        self.h = ctypes.c_void_p(self.L.ko_new(k, alpha, seed, approx_kmers, fpr_sampled, fpr_trusted, bloom_seed))
+        # alpha may be a numpy longdouble: it crosses as decimal text with full precision
+        alpha_text = np.format_float_scientific(np.longdouble(alpha), precision=25, unique=False).encode()
+        self.h = ctypes.c_void_p(self.L.ko_new(k, alpha_text, seed, approx_kmers, fpr_sampled, fpr_trusted, bloom_seed))
 
     def __del__(self):
         if getattr(self, "h", None):

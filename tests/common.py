@@ -17,19 +17,30 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def make_dataset(seed=12345, genome_len=20000, coverage=20, read_len=150, n_rg=1, paired=False, n_per_million=200,
-                 ragged=False, short_reads=0):
+                 ragged=False, short_reads=0, mid_reads=0, extra_errors=0):
     """Seeded synthetic reads; optionally trimmed to ragged lengths and with a few reads shorter than k."""
     n_reads = genome_len * coverage // read_len
     sp = synth.synth_params(seed, genome_len, n_reads, read_len, n_rg=n_rg, paired=paired, n_per_million=n_per_million)
     d = synth.generate(sp)
-    if ragged or short_reads:
-        rng = np.random.RandomState(seed & 0xFFFF)
+    rng = np.random.RandomState(seed & 0xFFFF)
+    if extra_errors:
+        # substitutions at quality 37, spaced closer than k in some reads: leaves reads without any trusted
+        # k-mer (correct_one) and ties / unfixable stretches (bad prefix / suffix recursion)
+        seq = d["seq"].reshape(n_reads, read_len)
+        for r in rng.choice(n_reads, size=extra_errors, replace=False):
+            step = rng.randint(8, 60)
+            for p in range(rng.randint(0, step), read_len, step):
+                seq[r, p] = ord("ACGT"[("ACGT".find(chr(seq[r, p])) + 1 + rng.randint(0, 3)) % 4]) if chr(seq[r, p]) in "ACGT" else seq[r, p]
+    if ragged or short_reads or mid_reads:
         lens = np.full(n_reads, read_len, dtype=np.int64)
         if ragged:
             lens = rng.randint(read_len * 2 // 3, read_len + 1, size=n_reads)
         if short_reads:
             idx = rng.choice(n_reads, size=short_reads, replace=False)
             lens[idx] = rng.randint(1, 31, size=short_reads)
+        if mid_reads:
+            idx = rng.choice(n_reads, size=mid_reads, replace=False)
+            lens[idx] = rng.randint(32, 64, size=mid_reads)
         keep = (np.arange(read_len)[None, :] < lens[:, None]).reshape(-1)
         d["seq"] = np.ascontiguousarray(d["seq"][keep])
         d["qual"] = np.ascontiguousarray(d["qual"][keep])
@@ -43,7 +54,7 @@ def make_dataset(seed=12345, genome_len=20000, coverage=20, read_len=150, n_rg=1
 
 def run_oracle(d, k=32, seed=777, alpha=None, n_rg=1):
     alpha_ld, cov, approx = plan_parameters(d["genome_len"], d["coverage"], alpha)
-    o = pyoracle.Oracle(k, float(alpha_ld), seed, approx)
+    o = pyoracle.Oracle(k, alpha_ld, seed, approx)
     rg = np.ascontiguousarray(d["rg"], dtype=np.int32)
     second = np.ascontiguousarray(d["second"], dtype=np.uint8)
     out = o.run_all(d["seq"], d["qual"], d["off"], rg, second)

@@ -33,7 +33,7 @@ def test_uniform_150bp_single_rg():
 
 def test_ragged_short_reads_two_rg_paired_three_batches():
     d = common.make_dataset(seed=99, genome_len=25000, coverage=24, n_rg=2, paired=True, n_per_million=3000,
-                            ragged=True, short_reads=40)
+                            ragged=True, short_reads=40, mid_reads=300, extra_errors=200)
     ora = common.run_oracle(d, n_rg=2)
     eng = common.run_engine(d, n_rg=2, uniform=False, n_batches=3)
     common.assert_same_run(eng, ora)
@@ -62,11 +62,13 @@ def test_250bp_reads():
     common.assert_same_run(eng, ora)
 
 
-def test_noisy_low_coverage_exercises_correct_one():
-    # low coverage leaves many reads without any trusted k-mer -> correct_one, bad prefix/suffix recursion
-    d = common.make_dataset(seed=4242, genome_len=40000, coverage=8, n_per_million=5000)
+def test_noisy_reads_exercise_correct_one_and_recursion():
+    # reads of 32..63 bases with an error have no trusted k-mer at all -> correct_one and its early
+    # return; densely mutated reads -> ties, unfixable stretches, bad prefix/suffix recursion
+    d = common.make_dataset(seed=4242, genome_len=30000, coverage=25, n_per_million=5000, mid_reads=800,
+                            extra_errors=600)
     ora = common.run_oracle(d)
-    eng = common.run_engine(d, uniform=True)
+    eng = common.run_engine(d, uniform=False)
     common.assert_same_run(eng, ora)
 
 
