@@ -124,6 +124,9 @@ int kbbq_filter_patterns_download(kbbq_engine *e, int which, uint64_t *host_word
 /* dst |= src over the whole bit array of a filter; src is a device buffer of the
  * same size (the OR step of the multi-GPU all-reduce; RCCL has no bitwise OR). */
 int kbbq_filter_or_from(kbbq_engine *e, int which, const void *src_device, uint64_t word_offset, uint64_t n_words);
+/* dst |= src for two arbitrary 16-byte-aligned device buffers of n_words u64
+ * (reducing the pieces received in the OR all-reduce). */
+int kbbq_device_or(kbbq_engine *e, void *dst_device, const void *src_device, uint64_t n_words);
 int kbbq_filter_set_inserted(kbbq_engine *e, int which, uint64_t inserted);
 
 /* ---- read staging ------------------------------------------------------ */

@@ -1007,6 +1007,17 @@ int kbbq_filter_or_from(kbbq_engine *e, int which, const void *src_device, uint6
     return KBBQ_OK;
 }
 
+int kbbq_device_or(kbbq_engine *e, void *dst_device, const void *src_device, uint64_t n_words) {
+    if (!e || !dst_device || !src_device) return fail(KBBQ_EINVAL, "bad argument");
+    if (((uintptr_t)dst_device | (uintptr_t)src_device) & 15) return fail(KBBQ_EINVAL, "buffers must be 16-byte aligned");
+    if (!n_words) return KBBQ_OK;
+    Timed t(e, "k_or_words");
+    hipLaunchKernelGGL(k_or_words, dim3((unsigned)((n_words / 2 + 256) / 256)), dim3(256), 0, e->stream,
+                       (uint64_t *)dst_device, (const uint64_t *)src_device, n_words);
+    HIP_TRY(hipGetLastError());
+    return KBBQ_OK;
+}
+
 int kbbq_filter_set_inserted(kbbq_engine *e, int which, uint64_t inserted) {
     if (!e || which < 0 || which > 1) return fail(KBBQ_EINVAL, "bad argument");
     HIP_TRY(hipMemcpyAsync(e->filt[which].d_inserted, &inserted, 8, hipMemcpyHostToDevice, e->stream));
