@@ -112,14 +112,17 @@ __device__ __forceinline__ bool bloom_coop(const FiltDev &f, bool active, uint32
     const int sub = lane & 7, grp = lane >> 3;
     uint64_t tv[8], pv[8];
     uint32_t bb[8];
+    const unsigned long long live = __ballot(active);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
+        tv[j] = 0;
+        pv[j] = 0;
+        bb[j] = 0;
+        if (((live >> (8 * j)) & 0xFFull) == 0) continue;   // wave-uniform: nobody owns a k-mer in this round
         const int src = j * 8 + grp;
         const int a = __shfl((int)active, src);
         bb[j] = __shfl(blk, src);
         const uint32_t p = __shfl(pat, src);
-        tv[j] = 0;
-        pv[j] = 0;
         if (a) {
             pv[j] = f.patterns[(uint64_t)p * 8 + sub];
             tv[j] = f.table[(uint64_t)bb[j] * 8 + sub];

@@ -24,6 +24,7 @@
 
 #include "../../include/kbbq_engine.h"
 #include "correct.h"
+#include "correct_wave.h"
 #include "device_common.h"
 #include "host_model.h"
 
@@ -372,6 +373,88 @@ __global__ void __launch_bounds__(BLOCK) k_correct(ReadsDev R, KParams K, FiltDe
     // per-wave reduction of the query counter
     for (int o = 32; o > 0; o >>= 1) q_total += __shfl_down(q_total, o);
     if ((threadIdx.x & 63) == 0 && q_total) atomicAdd(&stats[1], q_total);
+}
+
+
+// ---- pass 3b (default): the correction walk, one read per WAVEFRONT (correct_wave.h) ----
+template <int NB, int NN>
+__global__ void __launch_bounds__(256) k_correct_wave(ReadsDev R, KParams K, FiltDev T, const uint32_t *list,
+                                                       const unsigned long long *n_list, const uint64_t *tmask,
+                                                       int tmask_words, uint32_t *err_bits, uint32_t *patch,
+                                                       unsigned long long *stats) {
+    typedef WaveCorrector<NB, NN> C;
+    __shared__ uint64_t lds_words[4 * C::WORDS];
+    const int lane = threadIdx.x & 63;
+    // wave-uniform by construction: lets the compiler keep the read's words and the walk in SGPRs
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t n = *n_list;
+    unsigned long long q_total = 0;
+    for (uint64_t slot = wave; slot < n; slot += n_waves) {
+        const uint64_t r = C::uni((uint64_t)list[slot]);
+        uint64_t off; uint32_t len32;
+        read_span(R, r, off, len32);
+        off = C::uni(off);
+        const int len = C::uni((int)len32);
+        C cx;
+        cx.S = lds_words + (threadIdx.x >> 6) * C::WORDS;
+        cx.f = T;
+        cx.K = K;
+        cx.qual = R.qual + off;
+        cx.lane = lane;
+        cx.queries = 0;
+        // stage the read into the wavefront's LDS slice (lane w writes word w)
+        for (int slot_w = lane; slot_w < C::WORDS; slot_w += 64) {
+            uint64_t v = 0;
+            if (slot_w < NB) {
+                const int w = slot_w;
+                if (w * 32 < len) v = window64(R.bases, 2 * (off + (uint64_t)w * 32));
+                const int rem = len - w * 32;
+                if (rem < 32) v &= rem > 0 ? ((1ULL << (2 * rem)) - 1) : 0ULL;
+            } else if (slot_w >= C::NM && slot_w < C::NM + NN) {
+                const int c = slot_w - C::NM;
+                if (c * 64 < len) v = window64(R.nmask, off + (uint64_t)c * 64);
+                const int rem = len - c * 64;
+                if (rem < 64) v &= rem > 0 ? ((1ULL << rem) - 1) : 0ULL;
+            } else if (slot_w >= C::Tc && slot_w < C::Tc + NN) {
+                const int c = slot_w - C::Tc;
+                if (c < tmask_words) v = tmask[r * tmask_words + c];
+            }
+            cx.S[slot_w] = v;
+        }
+        const int k = K.k;
+        // activation 0 is the read; 1 and 2 are the one-level recursion on a long unfixed prefix /
+        // suffix (readutils.cc:547-563).  One call site keeps a single inlined copy of the walk.
+        int pre_n = 0, suf_lo = 0, suf_n = 0;
+#pragma unroll 1
+        for (int act = 0; act < 3; ++act) {
+            int lo = 0, nn = len;
+            if (act == 1) { if (!pre_n) continue; nn = pre_n; }
+            if (act == 2) { if (!suf_n) continue; lo = suf_lo; nn = suf_n; }
+            const typename C::CallOut out = cx.run_call(lo, nn, 6);
+            if (act == 0) {
+                if (out.patch_pos >= 0 && lane == 0)
+                    patch[r] = 0x80000000u | ((uint32_t)out.patch_pos << 8) | (uint32_t)out.patch_base;
+                if (out.bad_prefix > 0 && (out.bad_prefix >= len / 2 || out.bad_prefix >= 2 * k)) pre_n = out.bad_prefix + 1;
+                if (out.bad_suffix >= 0 && out.bad_suffix < len &&
+                    (len - out.bad_suffix > len / 2 || len - out.bad_suffix > 2 * k)) {
+                    suf_lo = out.bad_suffix;
+                    suf_n = len - out.bad_suffix;
+                }
+            }
+        }
+        // publish the flags: lane l owns the 32-bit piece l of the read's flag words
+        if (lane < 2 * NN && lane * 32 < len) {
+            const uint32_t v = (uint32_t)(cx.ldw(C::E, lane >> 1) >> (32 * (lane & 1)));
+            if (v) {
+                const uint64_t g = off + (uint64_t)lane * 32;
+                atomicOr(&err_bits[g >> 5], v << (g & 31));
+                if (g & 31) atomicOr(&err_bits[(g >> 5) + 1], v >> (32 - (g & 31)));
+            }
+        }
+        q_total += cx.queries;
+    }
+    if (lane == 0 && q_total) atomicAdd(&stats[1], q_total);
 }
 
 // ---- pass 3c: covariate tally ---------------------------------------------------
@@ -1263,6 +1346,20 @@ static int launch_correct(kbbq_engine *e, ReadsDev R, const uint32_t *list, cons
 
 extern "C" {
 
+
+}  // extern "C"
+template <int NB, int NN>
+static int launch_correct_wave(kbbq_engine *e, ReadsDev R, const uint32_t *list, const uint64_t *tmask, int tw,
+                               uint32_t *err_bits, uint32_t *patch) {
+    Timed t(e, "k_correct_wave");
+    const int blocks = (int)std::min<uint64_t>((R.n_reads + 3) / 4, 256 * 16);
+    hipLaunchKernelGGL((k_correct_wave<NB, NN>), dim3(blocks), dim3(256), 0, e->stream, R, e->K, e->filt[1].dev(), list,
+                       (const unsigned long long *)&e->d_counters[0], tmask, tw, err_bits, patch, e->d_counters);
+    HIP_TRY(hipGetLastError());
+    return KBBQ_OK;
+}
+extern "C" {
+
 static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits, const uint32_t *patch, int max_len) {
     HistDev H;
     H.cycle = e->d_hist;
@@ -1315,9 +1412,18 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
         hipLaunchKernelGGL(k_compact, dim3((unsigned)((R.n_reads + 255) / 256)), dim3(256), 0, e->stream, dirty, R.n_reads, list, &e->d_counters[0]);
         HIP_TRY(hipGetLastError());
     }
-    if (max_len <= 160) rc = launch_correct<160, 256>(e, R, list, tmask, NW, d_err, patch);
-    else if (max_len <= 320) rc = launch_correct<320, 128>(e, R, list, tmask, NW, d_err, patch);
-    else rc = launch_correct<512, 64>(e, R, list, tmask, NW, d_err, patch);
+    // one read per wavefront (correct_wave.h); the one-read-per-lane form (correct.h) serves k < 3
+    // and KBBQ_CORRECT=lane (A/B checks)
+    static const bool lane_form = getenv("KBBQ_CORRECT") && !strcmp(getenv("KBBQ_CORRECT"), "lane");
+    if (lane_form || e->p.k < 3) {
+        if (max_len <= 160) rc = launch_correct<160, 256>(e, R, list, tmask, NW, d_err, patch);
+        else if (max_len <= 320) rc = launch_correct<320, 128>(e, R, list, tmask, NW, d_err, patch);
+        else rc = launch_correct<512, 64>(e, R, list, tmask, NW, d_err, patch);
+    } else {
+        if (max_len <= 160) rc = launch_correct_wave<5, 3>(e, R, list, tmask, NW, d_err, patch);
+        else if (max_len <= 320) rc = launch_correct_wave<10, 5>(e, R, list, tmask, NW, d_err, patch);
+        else rc = launch_correct_wave<16, 8>(e, R, list, tmask, NW, d_err, patch);
+    }
     if (rc) return rc;
     if ((rc = run_tally(e, R, d_err, patch, max_len))) return rc;
     {
