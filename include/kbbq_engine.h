@@ -240,6 +240,21 @@ int kbbq_profile_reset(kbbq_engine *e);
  * queries issued there. */
 int kbbq_stats_get(kbbq_engine *e, uint64_t *out, int32_t n);
 
+/* ---- host-only entry points (no GPU touched) --------------------------------
+ * The scalar parts of the path, for integrators that keep their own device code
+ * and for the CPU test-suite.  Same arithmetic as the engine uses internally. */
+/* Filter sizing, salts and pattern table (bloom_filter.hpp:108-160,467-549; bloom.hh:36-56,189-231). */
+int kbbq_host_filter_spec(uint64_t approx_kmers, double fpr, uint64_t bloom_seed, kbbq_filter_info *info,
+                          uint64_t *patterns_out /* 65536*8 words or NULL */);
+/* kbbq.cc:304-313 from the sampled filter's size and insert count; returns 1 when fpr > .15. */
+int kbbq_host_thresholds(int32_t k, uint64_t filter_bits, uint64_t inserted, uint32_t n_salt, const char *alpha_text,
+                         int32_t *thresholds_out, double *fpr_out, char *p_text_out, size_t p_text_len);
+/* CCovariateData::get_dqs (covariateutils.cc:204-230) on dense histograms; cov->rg and cov->q are
+ * ignored (they are sums of cov->cycle). */
+int kbbq_host_train(const kbbq_covariates *cov, kbbq_dq *out);
+/* Largest T with: std::bernoulli_distribution(p) accepts a 64-bit draw u  <=>  u < T. */
+uint64_t kbbq_host_bernoulli_threshold(double p, int32_t *always);
+
 /* Test hook: xoshiro256** state after `ordinal` draws of a sampler seeded with
  * `seed` (jump-ahead used by pass 1). */
 int kbbq_rng_state_at(uint32_t seed, uint64_t ordinal, uint64_t state_out[4]);

@@ -102,6 +102,11 @@ SYMBOLS = {
     "kbbq_profile_get": (ctypes.c_int, [c_vp, ctypes.POINTER(ProfileEntry), ctypes.c_int32, c_i32p]),
     "kbbq_profile_reset": (ctypes.c_int, [c_vp]),
     "kbbq_stats_get": (ctypes.c_int, [c_vp, c_u64p, ctypes.c_int32]),
+    "kbbq_host_filter_spec": (ctypes.c_int, [c_u64, ctypes.c_double, c_u64, ctypes.POINTER(FilterInfo), c_u64p]),
+    "kbbq_host_thresholds": (ctypes.c_int, [ctypes.c_int32, c_u64, c_u64, ctypes.c_uint32, ctypes.c_char_p, c_i32p,
+                                            ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_size_t]),
+    "kbbq_host_train": (ctypes.c_int, [ctypes.POINTER(Covariates), ctypes.POINTER(Dq)]),
+    "kbbq_host_bernoulli_threshold": (c_u64, [ctypes.c_double, c_i32p]),
     "kbbq_rng_state_at": (ctypes.c_int, [ctypes.c_uint32, c_u64, c_u64p]),
 }
 

@@ -1645,6 +1645,56 @@ int kbbq_stats_get(kbbq_engine *e, uint64_t *out, int32_t n) {
     return KBBQ_OK;
 }
 
+// ---- host-only entry points (no GPU touched): the scalar parts of the path ----------
+int kbbq_host_filter_spec(uint64_t approx_kmers, double fpr, uint64_t bloom_seed, kbbq_filter_info *info,
+                          uint64_t *patterns_out) {
+    if (!info) return fail(KBBQ_EINVAL, "null argument");
+    FilterSpec s;
+    if (!make_filter_spec(approx_kmers, fpr, bloom_seed, s))
+        return fail(KBBQ_EINVAL, "Error: Invalid bloom filter parameters. Adjust parameters and try again.");
+    memset(info, 0, sizeof *info);
+    info->bits = s.bits; info->bits_unblocked = s.bits_unblocked; info->n_blocks = s.n_blocks;
+    info->random_seed = s.random_seed; info->n_hash = s.n_hash; info->n_salt = s.n_salt;
+    for (uint32_t i = 0; i < s.n_salt; ++i) info->salt[i] = s.salt[i];
+    if (patterns_out) memcpy(patterns_out, s.patterns.data(), kNumPatterns * 64);
+    return KBBQ_OK;
+}
+
+int kbbq_host_thresholds(int32_t k, uint64_t filter_bits, uint64_t inserted, uint32_t n_salt, const char *alpha_text,
+                         int32_t *thresholds_out, double *fpr_out, char *p_text_out, size_t p_text_len) {
+    if (!alpha_text || !thresholds_out) return fail(KBBQ_EINVAL, "null argument");
+    if (k < 1 || k > KBBQ_MAX_KMER) return fail(KBBQ_ERANGE, "k must be <= %d and > 0", KBBQ_MAX_KMER);
+    if (inserted == 0) return fail(KBBQ_ESTATE, "no k-mers were sampled");
+    double fpr = 0;
+    std::string p_text;
+    std::vector<int32_t> t = thresholds_from_counts(k, filter_bits, inserted, n_salt, alpha_text, &fpr, &p_text);
+    memcpy(thresholds_out, t.data(), (k + 1) * 4);
+    if (fpr_out) *fpr_out = fpr;
+    if (p_text_out && p_text_len) snprintf(p_text_out, p_text_len, "%s", p_text.c_str());
+    return fpr > .15 ? 1 : 0;
+}
+
+int kbbq_host_train(const kbbq_covariates *cov, kbbq_dq *out) {
+    if (!cov || !out || !cov->cycle || !cov->dinuc) return fail(KBBQ_EINVAL, "null argument");
+    std::vector<uint64_t> q, rg;
+    derive_q_rg(cov->n_rg, cov->n_cycle, cov->cycle, q, rg);
+    DqTables d = train_model(cov->n_rg, cov->n_cycle, rg.data(), q.data(), cov->cycle, cov->dinuc);
+    out->n_rg = d.n_rg; out->n_cycle = d.n_cycle;
+    if (out->meanq) memcpy(out->meanq, d.meanq.data(), d.meanq.size() * 4);
+    if (out->rgdq) memcpy(out->rgdq, d.rgdq.data(), d.rgdq.size() * 4);
+    if (out->qdq) memcpy(out->qdq, d.qdq.data(), d.qdq.size() * 4);
+    if (out->cycledq) memcpy(out->cycledq, d.cycledq.data(), d.cycledq.size() * 4);
+    if (out->dinucdq) memcpy(out->dinucdq, d.dinucdq.data(), d.dinucdq.size() * 4);
+    return KBBQ_OK;
+}
+
+uint64_t kbbq_host_bernoulli_threshold(double p, int32_t *always) {
+    bool a = false;
+    const uint64_t t = bernoulli_threshold(p, &a);
+    if (always) *always = a ? 1 : 0;
+    return t;
+}
+
 int kbbq_rng_state_at(uint32_t seed, uint64_t ordinal, uint64_t state_out[4]) {
     if (!state_out) return fail(KBBQ_EINVAL, "null argument");
     xoshiro_state_at(seed, ordinal, state_out);

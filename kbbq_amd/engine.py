@@ -26,7 +26,8 @@ def default_fprs():
 
 
 def plan_parameters(genomelen, coverage=0, alpha=None, seqlen=None):
-    """kbbq.cc:227-264: coverage, alpha (long double) and approx_kmers from the CLI inputs."""
+    """kbbq.cc:227-264: coverage, alpha (long double) and approx_kmers from the CLI inputs.
+    alpha may be given as text, which is parsed straight to long double like std::stold (kbbq.cc:122)."""
     if alpha is None or alpha == 0:
         if coverage == 0:
             coverage = int(seqlen // genomelen)

@@ -39,6 +39,21 @@
 
 namespace {
 
+// Branch counters: tests use them to prove that the seeded inputs of the parity suite reach the
+// rare paths of get_errors (they do not influence any result).
+enum {
+    C_GET_ERRORS, C_NO_ANCHOR, C_CORRECT_ONE_FIXED, C_EARLY_PATCH_RETURN, C_ADJUST, C_ADJUST_FIRST_TRY,
+    C_ADJUST_MOVED, C_ADJUST_STAYED, C_FIX_CALLS, C_EXTENSION_STEPS, C_TIE_STOP, C_TIE_CONTINUE, C_UNFIXABLE,
+    C_PREFIX_RECURSION, C_SUFFIX_RECURSION, C_VETO, C_OVERCORRECTED, C_UNFLAG_BACKJUMP, C_FIX_ON_N, C_LEFT_FIX,
+    C_RIGHT_FIX, C_COUNT
+};
+uint64_t g_count[C_COUNT];
+const char *const g_count_names[C_COUNT] = {
+    "get_errors", "no_anchor", "correct_one_fixed", "early_patch_return", "adjust", "adjust_first_try",
+    "adjust_moved", "adjust_stayed", "fix_calls", "extension_steps", "tie_stop", "tie_continue", "unfixable",
+    "prefix_recursion", "suffix_recursion", "veto", "overcorrected", "unflag_backjump", "fix_on_n", "left_fix",
+    "right_fix"};
+
 constexpr size_t NPOS = static_cast<size_t>(-1);
 constexpr int MAXQ = 93;            // covariateutils.hh:3  KBBQ_MAXQ
 constexpr int NQ = MAXQ + 1;
@@ -486,6 +501,7 @@ void longest_trusted_seq(const Codes &seq, const Filter &t, int k, size_t &a_sta
 struct Fix { std::vector<uint8_t> best; size_t stop; bool multiple; };
 Fix longest_fix(Codes sub, const Filter &t, int k, bool reverse_order) {
     Kmer km(k);
+    ++g_count[C_FIX_CALLS];
     Fix out; out.stop = 0; out.multiple = false;
     bool single = false;
     const uint8_t unfixed = sub[k - 1];
@@ -502,6 +518,7 @@ Fix longest_fix(Codes sub, const Filter &t, int k, bool reverse_order) {
             else {
                 n = next_trusted_code(km, t, reverse_order);
                 if (n < 0) break;
+                ++g_count[C_EXTENSION_STEPS];
             }
             km.push((uint8_t)n);
             if (i + 1 >= (size_t)k) {
@@ -522,6 +539,7 @@ Fix longest_fix(Codes sub, const Filter &t, int k, bool reverse_order) {
 // bloom.cc:208-277
 std::pair<size_t, bool> adjust_right_anchor(size_t anchor, const Codes &seq, const Filter &t, int k) {
     Kmer km(k);
+    ++g_count[C_ADJUST];
     bool multiple = false;
     size_t mod = anchor + 1;
     for (size_t i = mod - k + 1; i < mod; ++i) km.push(seq[i]);
@@ -531,7 +549,7 @@ std::pair<size_t, bool> adjust_right_anchor(size_t anchor, const Codes &seq, con
         nk.push(c);
         for (size_t i = 0; i <= (size_t)k; ++i) {
             if (!t.query(nk)) break;
-            if (mod + i == seq.size() - 1 || i == (size_t)k) return std::make_pair(anchor, multiple);
+            if (mod + i == seq.size() - 1 || i == (size_t)k) { ++g_count[C_ADJUST_FIRST_TRY]; return std::make_pair(anchor, multiple); }
             nk.push(seq[mod + i + 1]);
         }
     }
@@ -547,11 +565,12 @@ std::pair<size_t, bool> adjust_right_anchor(size_t anchor, const Codes &seq, con
                 multiple = true;
                 for (size_t j = 0; nk.valid() && t.query(nk) && mod + 1 + j < seq.size() && j <= (size_t)(k / 2); ++j) {
                     nk.push(seq[mod + 1 + j]);
-                    if (j == (size_t)(k / 2) && nk.valid() && t.query(nk)) return std::make_pair(mod - 1, multiple);
+                    if (j == (size_t)(k / 2) && nk.valid() && t.query(nk)) { ++g_count[C_ADJUST_MOVED]; return std::make_pair(mod - 1, multiple); }
                 }
             }
         }
     }
+    ++g_count[C_ADJUST_STAYED];
     return std::make_pair(anchor, multiple);
 }
 
@@ -617,15 +636,20 @@ void get_errors(Read &rd, const Filter &t, int k, int minqual, bool first_call) 
     size_t bad_suffix = NPOS;
     bool multiple = false;
     size_t anchor[2];
+    ++g_count[C_GET_ERRORS];
     longest_trusted_seq(rd.seq, t, k, anchor[0], anchor[1]);
+    bool patched = false;
     if (anchor[0] == NPOS) {
         multiple = true;
+        ++g_count[C_NO_ANCHOR];
         const size_t idx = correct_one(rd, t, k);
         if (idx == NPOS) return;
+        ++g_count[C_CORRECT_ONE_FIXED];
+        patched = true;
         longest_trusted_seq(rd.seq, t, k, anchor[0], anchor[1]);
         rd.err[idx] = 1;
     }
-    if (anchor[0] == 0 && anchor[1] == NPOS) return;
+    if (anchor[0] == 0 && anchor[1] == NPOS) { if (patched) ++g_count[C_EARLY_PATCH_RETURN]; return; }
     const size_t anchor_len = std::min(anchor[1], len - 1) + 1 - anchor[0];
     bool corrected = false;
     // right side, :271-346
@@ -646,9 +670,13 @@ void get_errors(Read &rd, const Filter &t, int k, int minqual, bool first_call) 
                     const size_t largest = std::min(i + k - 1, len - 1);
                     if (next_untrusted <= largest || largest - i + 1 < (size_t)k) {
                         bad_suffix = i;
+                        ++g_count[C_TIE_STOP];
                         break;
                     }
+                    ++g_count[C_TIE_CONTINUE];
                 } else {
+                    if (rd.seq[i] > 3) ++g_count[C_FIX_ON_N];
+                    ++g_count[C_RIGHT_FIX];
                     rd.seq[i] = fx.best[0];
                     rd.err[i] = 1;
                 }
@@ -656,6 +684,7 @@ void get_errors(Read &rd, const Filter &t, int k, int minqual, bool first_call) 
                 i += fx.stop - k + 1;
             } else {
                 bad_suffix = i;
+                ++g_count[C_UNFIXABLE];
                 break;
             }
         }
@@ -684,9 +713,12 @@ void get_errors(Read &rd, const Filter &t, int k, int minqual, bool first_call) 
                     const size_t largest = std::min((size_t)j + (size_t)k - 1, len - 1);
                     if (next_untrusted <= largest || largest - j + 1 < (size_t)k) {
                         bad_prefix = (size_t)i;
+                        ++g_count[C_TIE_STOP];
                         break;
                     }
+                    ++g_count[C_TIE_CONTINUE];
                 } else {
+                    ++g_count[C_LEFT_FIX];
                     rc[j] = fx.best[0];
                     rd.err[i] = 1;
                 }
@@ -694,6 +726,7 @@ void get_errors(Read &rd, const Filter &t, int k, int minqual, bool first_call) 
                 i -= (int)(next_untrusted - j);
             } else {
                 bad_prefix = (size_t)i;
+                ++g_count[C_UNFIXABLE];
                 break;
             }
         }
@@ -711,7 +744,7 @@ void get_errors(Read &rd, const Filter &t, int k, int minqual, bool first_call) 
             } else {
                 if (i > t_end) {
                     for (size_t j = t_start; j <= t_end; ++j) {
-                        if (rd.err[j]) { adjust = false; break; }
+                        if (rd.err[j]) { adjust = false; ++g_count[C_VETO]; break; }
                     }
                     t_start = NPOS;
                     t_end = NPOS;
@@ -732,7 +765,7 @@ void get_errors(Read &rd, const Filter &t, int k, int minqual, bool first_call) 
                 if (rd.qual[i - ocwindow] <= minqual) occount -= 0.5; else --occount;
             }
             threshold = (adjust && i >= ocwindow && (size_t)(i + ocwindow - 1) < len) ? base_threshold + 1 : base_threshold;
-            if (occount > threshold && rd.err[i]) over.push_back(i);
+            if (occount > threshold && rd.err[i]) { over.push_back(i); ++g_count[C_OVERCORRECTED]; }
         }
         for (size_t oi = 0; oi < over.size(); ++oi) {
             const int oc = over[oi];
@@ -746,6 +779,7 @@ void get_errors(Read &rd, const Filter &t, int k, int minqual, bool first_call) 
                         rd.err[i] = 0;
                         if (i + k > end) end = (size_t)(i + k) < len ? i + k : (int)len;
                         if (i - k < start) {
+                            ++g_count[C_UNFLAG_BACKJUMP];
                             i = i - k + 1 >= 0 ? i - k : -1;
                             start = i;
                         }
@@ -757,12 +791,14 @@ void get_errors(Read &rd, const Filter &t, int k, int minqual, bool first_call) 
     // one level of recursion on a long untouched prefix / suffix, :547-563
     if (first_call && bad_prefix > 0 && (bad_prefix >= len / 2 || bad_prefix >= (size_t)(2 * k))) {
         Read sub = rd.sub(0, bad_prefix + 1);
+        ++g_count[C_PREFIX_RECURSION];
         get_errors(sub, t, k, minqual, false);
         std::copy(sub.err.begin(), sub.err.end(), rd.err.begin());
     }
     if (first_call && bad_suffix < NPOS && bad_suffix < len &&
         (len - bad_suffix > len / 2 || len - bad_suffix > (size_t)(2 * k))) {
         Read sub = rd.sub(bad_suffix, NPOS);
+        ++g_count[C_SUFFIX_RECURSION];
         get_errors(sub, t, k, minqual, false);
         std::copy(sub.err.begin(), sub.err.end(), rd.err.begin() + bad_suffix);
     }
@@ -1085,6 +1121,28 @@ void ko_recalibrate(void *h, uint64_t n_reads, const uint8_t *seq, const uint8_t
         Read rd = make_read(b, r);
         recalibrate(rd, c->dq, 6, qual_out + off[r]);
     }
+}
+
+// branch counters
+int ko_counter_count(void) { return C_COUNT; }
+const char *ko_counter_name(int i) { return i >= 0 && i < C_COUNT ? g_count_names[i] : ""; }
+uint64_t ko_counter_value(int i) { return i >= 0 && i < C_COUNT ? g_count[i] : 0; }
+void ko_counters_reset(void) { memset(g_count, 0, sizeof g_count); }
+
+// hooks for the sharded (multi-process) protocol test: install exchanged state
+void ko_filter_set_inserted(void *h, int which, uint64_t n) { filt(h, which).inserted = n; }
+uint64_t *ko_filter_table_mut(void *h, int which) { return filt(h, which).table.data(); }
+void ko_skip_draws(void *h, uint64_t n) {
+    Ctx *c = (Ctx *)h;
+    for (uint64_t i = 0; i < n; ++i) c->draw_rng.next();
+    c->draws += n;
+}
+void ko_dq_set(void *h, uint64_t R, uint64_t C, const int32_t *meanq, const int32_t *rgdq, const int32_t *qdq,
+               const int32_t *cydq, const int32_t *didq) {
+    Dq &d = ((Ctx *)h)->dq;
+    d.R = R; d.C = C;
+    d.meanq.assign(meanq, meanq + R); d.rgdq.assign(rgdq, rgdq + R); d.qdq.assign(qdq, qdq + R * NQ);
+    d.cydq.assign(cydq, cydq + R * NQ * 2 * C); d.didq.assign(didq, didq + R * NQ * 16);
 }
 
 // ------------------------------------------------------------- unit probes

@@ -17,7 +17,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def make_dataset(seed=12345, genome_len=20000, coverage=20, read_len=150, n_rg=1, paired=False, n_per_million=200,
-                 ragged=False, short_reads=0, mid_reads=0, extra_errors=0):
+                 ragged=False, short_reads=0, mid_reads=0, extra_errors=0, clusters=0):
     """Seeded synthetic reads; optionally trimmed to ragged lengths and with a few reads shorter than k."""
     n_reads = genome_len * coverage // read_len
     sp = synth.synth_params(seed, genome_len, n_reads, read_len, n_rg=n_rg, paired=paired, n_per_million=n_per_million)
@@ -31,6 +31,16 @@ def make_dataset(seed=12345, genome_len=20000, coverage=20, read_len=150, n_rg=1
             step = rng.randint(8, 60)
             for p in range(rng.randint(0, step), read_len, step):
                 seq[r, p] = ord("ACGT"[("ACGT".find(chr(seq[r, p])) + 1 + rng.randint(0, 3)) % 4]) if chr(seq[r, p]) in "ACGT" else seq[r, p]
+    if clusters:
+        # 6-9 substitutions 2-4 bases apart: each is fixable in turn, so the over-correction window
+        # (more than 4 fixes in 20 bases, readutils.cc:479-546) fires
+        seq = d["seq"].reshape(n_reads, read_len)
+        for r in rng.choice(n_reads, size=clusters, replace=False):
+            p = rng.randint(35, read_len - 60)
+            for _ in range(rng.randint(6, 10)):
+                if chr(seq[r, p]) in "ACGT":
+                    seq[r, p] = ord("ACGT"[("ACGT".find(chr(seq[r, p])) + 1 + rng.randint(0, 3)) % 4])
+                p += rng.randint(2, 5)
     if ragged or short_reads or mid_reads:
         lens = np.full(n_reads, read_len, dtype=np.int64)
         if ragged:
@@ -50,6 +60,72 @@ def make_dataset(seed=12345, genome_len=20000, coverage=20, read_len=150, n_rg=1
     d["genome_len"] = genome_len
     d["coverage"] = coverage
     return d
+
+
+def make_repeat_dataset(seed=77, genome_len=12000, coverage=30, read_len=100, n_variants=12):
+    """A genome with a duplicated 400-base segment whose copies differ at a few single bases, and reads
+    that carry a sequencing error exactly at such a base: two alternative bases are then equally good
+    (both copies are in the filter) -- the tie of find_longest_fix that runs a full window
+    (readutils.cc:293-322 without the early stop)."""
+    rng = np.random.RandomState(seed)
+    g = rng.randint(0, 4, size=genome_len)
+    src, dst, seg = 1000, 7000, 400
+    g[dst:dst + seg] = g[src:src + seg]
+    var = np.sort(rng.choice(np.arange(60, seg - 60), size=n_variants, replace=False))
+    var = var[np.concatenate(([True], np.diff(var) > 40))]
+    g[dst + var] = (g[src + var] + 1 + rng.randint(0, 2, size=len(var))) % 4
+    n_reads = genome_len * coverage // read_len
+    starts = rng.randint(0, genome_len - read_len + 1, size=n_reads)
+    # make sure both copies are well covered
+    extra = np.concatenate([rng.randint(src - 50, src + seg - 50, size=200), rng.randint(dst - 50, dst + seg - 50, size=200)])
+    starts = np.concatenate([starts, extra])
+    n_reads = len(starts)
+    codes = g[starts[:, None] + np.arange(read_len)[None, :]]
+    qual = np.full((n_reads, read_len), 37, dtype=np.uint8)
+    # ordinary errors
+    err = rng.rand(n_reads, read_len) < 0.002
+    codes = np.where(err, (codes + 1 + rng.randint(0, 3, size=codes.shape)) % 4, codes)
+    # errors on the variant bases: a third base, neither copy's
+    third = 0
+    for r in range(n_reads):
+        for base, v in ((src, var), (dst, var)):
+            for x in v:
+                p = base + x - starts[r]
+                if 35 <= p < read_len - 35 and rng.rand() < 0.5:
+                    a, b = g[src + x], g[dst + x]
+                    c = [y for y in range(4) if y != a and y != b][rng.randint(0, 2)]
+                    codes[r, p] = c
+                    third += 1
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
+    off = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len)
+    return dict(seq=np.ascontiguousarray(seq.reshape(-1)), qual=np.ascontiguousarray(qual.reshape(-1)), off=off,
+                rg=np.zeros(n_reads, dtype=np.int32), second=np.zeros(n_reads, dtype=np.uint8), genome_len=genome_len,
+                coverage=coverage)
+
+
+# The seeded inputs of the GPU parity suite: name -> (dataset builder, dataset kwargs, run kwargs, engine kwargs).
+# tests/test_coverage_cpu.py proves on the CPU that together they reach every branch of get_errors.
+PARITY_CASES = {
+    "uniform_150": (make_dataset, dict(seed=12345, genome_len=30000, coverage=20), dict(), dict(uniform=True)),
+    "ragged_2rg_paired": (make_dataset, dict(seed=99, genome_len=25000, coverage=24, n_rg=2, paired=True, n_per_million=3000,
+                                             ragged=True, short_reads=40, mid_reads=300, extra_errors=200),
+                          dict(n_rg=2), dict(uniform=False, n_batches=3)),
+    "k21_low_alpha": (make_dataset, dict(seed=777, genome_len=20000, coverage=40, read_len=100), dict(k=21, alpha=0.05),
+                      dict(uniform=True)),
+    "reads_250": (make_dataset, dict(seed=31, genome_len=20000, coverage=20, read_len=250, n_per_million=1000), dict(),
+                  dict(uniform=True)),
+    "noisy": (make_dataset, dict(seed=4242, genome_len=30000, coverage=25, n_per_million=5000, mid_reads=800,
+                                 extra_errors=600), dict(), dict(uniform=False)),
+    "clusters": (make_dataset, dict(seed=606, genome_len=30000, coverage=25, clusters=400, extra_errors=100), dict(),
+                 dict(uniform=True, n_batches=2)),
+    "k9": (make_dataset, dict(seed=9, genome_len=3000, coverage=30, read_len=100, extra_errors=100), dict(k=9),
+           dict(uniform=True)),
+    "k12_clusters": (make_dataset, dict(seed=12, genome_len=6000, coverage=30, read_len=100, clusters=50), dict(k=12),
+                     dict(uniform=True)),
+    "repeat_ties": (make_repeat_dataset, dict(), dict(k=21), dict(uniform=True)),
+    "reads_400": (make_dataset, dict(seed=400, genome_len=20000, coverage=20, read_len=400, n_per_million=500,
+                                     extra_errors=60), dict(), dict(uniform=True)),
+}
 
 
 def run_oracle(d, k=32, seed=777, alpha=None, n_rg=1):

@@ -23,20 +23,35 @@ def test_library_loaded_and_gpu_present():
     assert _lib.lib() is not None
 
 
-def test_uniform_150bp_single_rg():
-    d = common.make_dataset(seed=12345, genome_len=30000, coverage=20)
-    ora = common.run_oracle(d)
-    eng = common.run_engine(d, uniform=True)
+@pytest.mark.parametrize("name", list(common.PARITY_CASES))
+def test_four_passes_bit_exact(name):
+    """Every intermediate of the four passes, bit for bit: filters' parameters and bit arrays, insert
+    counters, thresholds, infer_read_errors flags, get_errors flags, all four histograms, the delta-Q
+    tables and the recalibrated qualities.  tests/test_coverage_cpu.py shows these inputs together reach
+    every branch of get_errors (correct_one, anchor adjustment, ties, recursion, over-correction...)."""
+    build, dkw, rkw, ekw = common.PARITY_CASES[name]
+    d = build(**dkw)
+    ora = common.run_oracle(d, **rkw)
+    eng = common.run_engine(d, **rkw, **ekw)
     common.assert_same_run(eng, ora)
     assert eng["stats"]["corrected_reads"] > 0
 
 
-def test_ragged_short_reads_two_rg_paired_three_batches():
-    d = common.make_dataset(seed=99, genome_len=25000, coverage=24, n_rg=2, paired=True, n_per_million=3000,
-                            ragged=True, short_reads=40, mid_reads=300, extra_errors=200)
-    ora = common.run_oracle(d, n_rg=2)
-    eng = common.run_engine(d, n_rg=2, uniform=False, n_batches=3)
-    common.assert_same_run(eng, ora)
+def test_one_read_per_lane_form_agrees():
+    """The k < 3 / diagnostic form of the correction walk (correct.h) against the oracle; a second process
+    because the choice is read once from the environment."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, 'tests'); import common\n"
+            "for name in ('ragged_2rg_paired', 'clusters', 'k9', 'repeat_ties'):\n"
+            "    build, dkw, rkw, ekw = common.PARITY_CASES[name]\n"
+            "    d = build(**dkw)\n"
+            "    common.assert_same_run(common.run_engine(d, **rkw, **ekw), common.run_oracle(d, **rkw))\n"
+            "print('lane form ok')\n")
+    env = dict(os.environ, KBBQ_CORRECT="lane")
+    out = subprocess.run([sys.executable, "-c", code], cwd=common.ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "lane form ok" in out.stdout, out.stdout + out.stderr
 
 
 def test_batching_does_not_change_results():
@@ -48,27 +63,23 @@ def test_batching_does_not_change_results():
     assert one["sampled_inserted"] == many["sampled_inserted"]
 
 
-def test_k21_low_alpha():
-    d = common.make_dataset(seed=777, genome_len=20000, coverage=40, read_len=100)
-    ora = common.run_oracle(d, k=21, alpha=0.05)
-    eng = common.run_engine(d, k=21, alpha=0.05, uniform=True)
-    common.assert_same_run(eng, ora)
-
-
-def test_250bp_reads():
-    d = common.make_dataset(seed=31, genome_len=20000, coverage=20, read_len=250, n_per_million=1000)
+def test_empty_and_degenerate_reads():
+    """Zero-length reads, reads shorter than k and an all-N read in one ragged batch."""
+    d = common.make_dataset(seed=17, genome_len=6000, coverage=20, ragged=True, short_reads=60)
+    lens = np.diff(d["off"].astype(np.int64))
+    # empty the first, a middle and the last read
+    keep = np.ones(len(d["seq"]), dtype=bool)
+    off = d["off"].astype(np.int64)
+    for r in (0, len(lens) // 2, len(lens) - 1):
+        keep[off[r]:off[r + 1]] = False
+        lens[r] = 0
+    d["seq"], d["qual"] = np.ascontiguousarray(d["seq"][keep]), np.ascontiguousarray(d["qual"][keep])
+    d["off"] = np.concatenate(([0], np.cumsum(lens))).astype(np.uint64)
+    o2 = d["off"].astype(np.int64)
+    r = 5
+    d["seq"][o2[r]:o2[r + 1]] = ord("N")
     ora = common.run_oracle(d)
-    eng = common.run_engine(d, uniform=True)
-    common.assert_same_run(eng, ora)
-
-
-def test_noisy_reads_exercise_correct_one_and_recursion():
-    # reads of 32..63 bases with an error have no trusted k-mer at all -> correct_one and its early
-    # return; densely mutated reads -> ties, unfixable stretches, bad prefix/suffix recursion
-    d = common.make_dataset(seed=4242, genome_len=30000, coverage=25, n_per_million=5000, mid_reads=800,
-                            extra_errors=600)
-    ora = common.run_oracle(d)
-    eng = common.run_engine(d, uniform=False)
+    eng = common.run_engine(d, uniform=False, n_batches=2, max_read_len=150)
     common.assert_same_run(eng, ora)
 
 
