@@ -46,9 +46,11 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def run_step(e, xch, batches, ordinals, out_buf):
+def run_step(e, xch, batches, ordinals, out_buf, hints):
     """One complete pass of the hot path over this rank's shard."""
     e.reset()
+    hints.zero_()
+    torch.cuda.synchronize()
     for b, o in zip(batches, ordinals):
         e.subsample_kmers(b, o)
     e.sample_finish()
@@ -140,6 +142,10 @@ def main():
     t0 = time.perf_counter()
     shard = e.synth_reads(sp, a, n_local)
     log("[rank %d] generated %.3g bases on the device in %.1f s" % (rank, n_local * READ_LEN, time.perf_counter() - t0))
+    # hint bit arrays (include/kbbq_engine.h: kbbq_reads.hint_*): 2 x 1 bit per base, zeroed every step
+    hint_bytes = (n_local * READ_LEN // 64 + 2) * 8
+    hints = torch.zeros(2 * hint_bytes, dtype=torch.uint8, device="cuda")
+    shard.set_hints(hints.data_ptr(), hints.data_ptr() + hint_bytes)
     batches, ordinals = [], []
     for s in range(0, n_local, BATCH_READS):
         n = min(BATCH_READS, n_local - s)
@@ -157,12 +163,12 @@ def main():
 
     info = None
     for _ in range(args.warmup):
-        info = run_step(e, xch, batches, ordinals, out_buf)
+        info = run_step(e, xch, batches, ordinals, out_buf, hints)
     e.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        info = run_step(e, xch, batches, ordinals, out_buf)
+        info = run_step(e, xch, batches, ordinals, out_buf, hints)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:

@@ -74,6 +74,7 @@ typedef struct kbbq_params {
  *   flags   per read: bit 0 = second-in-pair (readutils.cc:59,89-97); NULL = 0.
  *   rg      per read dense read-group index (order of first appearance,
  *           readutils.cc:54-58,100-103); NULL = 0.
+ *   hint_*  see below (optional).
  * bases and nmask must be allocated with at least one extra zero u64 word past
  * the last used one (the kernels read unaligned 64-bit windows). */
 typedef struct kbbq_reads {
@@ -87,6 +88,13 @@ typedef struct kbbq_reads {
     const uint16_t *rg;
     uint32_t read_len;
     int32_t on_device;
+    /* Optional, device batches only (NULL = off): two caller-owned, caller-zeroed bit arrays, 1 bit per
+     * base of the batch (layout of nmask, n_bases/64+2 words), that live as long as the batch is
+     * re-submitted across passes.  Pass 1 marks the k-mer starts this read inserted into the sampled
+     * filter, pass 2 skips those lookups (an inserted k-mer is contained) and marks the starts it
+     * inserted into the trusted filter, pass 3 skips those.  Results are unchanged. */
+    uint64_t *hint_sampled;
+    uint64_t *hint_trusted;
 } kbbq_reads;
 
 typedef struct kbbq_filter_info {

@@ -35,7 +35,7 @@ class Params(ctypes.Structure):
 class Reads(ctypes.Structure):
     _fields_ = [("n_reads", c_u64), ("n_bases", c_u64), ("bases", c_vp), ("nmask", c_vp), ("qual", c_vp),
                 ("offsets", c_vp), ("flags", c_vp), ("rg", c_vp), ("read_len", ctypes.c_uint32),
-                ("on_device", ctypes.c_int32)]
+                ("on_device", ctypes.c_int32), ("hint_sampled", c_vp), ("hint_trusted", c_vp)]
 
 
 class FilterInfo(ctypes.Structure):

@@ -17,6 +17,8 @@ struct ReadsDev {
     const uint64_t *offsets;   // null => uniform
     const uint8_t *flags;      // null => 0
     const uint16_t *rg;        // null => 0
+    uint32_t *hint_sampled;    // optional: 1 bit per base, set where this read itself inserted the k-mer starting there
+    uint32_t *hint_trusted;    //           into the sampled (pass 1) / trusted (pass 2) filter
     uint64_t n_reads;
     uint64_t n_bases;
     uint32_t read_len;
@@ -151,6 +153,18 @@ __device__ __forceinline__ bool bloom_query1(const FiltDev &f, uint64_t key) {
     const uint64_t miss = (p0.x & ~t0.x) | (p0.y & ~t0.y) | (p1.x & ~t1.x) | (p1.y & ~t1.y) | (p2.x & ~t2.x) |
                           (p2.y & ~t2.y) | (p3.x & ~t3.x) | (p3.y & ~t3.y);
     return miss == 0;
+}
+
+// OR the 64 flags of one chunk (bit l = position `first` + l of the batch) into a shared bit array
+__device__ __forceinline__ void or_bits64(uint32_t *bits, uint64_t first, uint64_t word, int lane) {
+    if (lane < 2) {
+        const uint32_t v = (uint32_t)(word >> (32 * lane));
+        const uint64_t g = first + 32 * lane;
+        if (v) {
+            atomicOr(&bits[g >> 5], v << (g & 31));
+            if (g & 31) atomicOr(&bits[(g >> 5) + 1], v >> (32 - (g & 31)));
+        }
+    }
 }
 
 // select W[idx] from a small wave-uniform array without dynamic indexing

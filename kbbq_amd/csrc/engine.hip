@@ -144,7 +144,9 @@ __device__ __forceinline__ uint64_t kmer_base(const uint64_t *kofs, uint64_t r, 
 template <int NW>
 __global__ void __launch_bounds__(256) k_sample_insert(ReadsDev R, KParams K, FiltDev F, const uint64_t *mask,
                                                         const uint64_t *kofs, unsigned long long *inserted) {
+    __shared__ uint2 pack[4][64];
     const int lane = threadIdx.x & 63;
+    uint2 *slots = pack[threadIdx.x >> 6];
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     unsigned long long mine = 0;
@@ -154,6 +156,11 @@ __global__ void __launch_bounds__(256) k_sample_insert(ReadsDev R, KParams K, Fi
         if (len < (uint32_t)K.k) continue;
         const int nk = (int)len - K.k + 1;
         const uint64_t kb = kmer_base(kofs, r, R.read_len, K.k);
+        // Only ~alpha of the positions are sampled: the sampled k-mers of the read are first packed into
+        // the low lanes (through a per-wave LDS row), so the cooperative insert runs ceil(count/8) rounds
+        // instead of 8 per 64-position chunk.
+        uint32_t q_blk = 0, q_pat = 0;
+        int filled = 0;
 #pragma unroll 1
         for (int c = 0; c * 64 < nk; ++c) {
             const int s = c * 64 + lane;
@@ -168,9 +175,22 @@ __global__ void __launch_bounds__(256) k_sample_insert(ReadsDev R, KParams K, Fi
                 blk = block_of(F, key);
                 pat = pattern_of(F, key);
             }
-            bloom_coop<true>(F, take, blk, pat);
-            mine += __popcll(__ballot(take));
+            const unsigned long long bal = __ballot(take);
+            const int cnt = __popcll(bal);
+            if (R.hint_sampled) or_bits64(R.hint_sampled, off + (uint64_t)c * 64, bal, lane);
+            if (filled + cnt > 64) {
+                bloom_coop<true>(F, lane < filled, q_blk, q_pat);
+                filled = 0;
+            }
+            const int slot = filled + __popcll(bal & ((1ULL << lane) - 1));
+            if (take) slots[slot] = make_uint2(blk, pat);
+            __builtin_amdgcn_wave_barrier();
+            if (lane >= filled && lane < filled + cnt) { const uint2 v = slots[lane]; q_blk = v.x; q_pat = v.y; }
+            __builtin_amdgcn_wave_barrier();
+            filled += cnt;
+            mine += cnt;
         }
+        if (filled) bloom_coop<true>(F, lane < filled, q_blk, q_pat);
     }
     if (lane == 0 && mine) atomicAdd(inserted, mine);
 }
@@ -204,12 +224,18 @@ __global__ void __launch_bounds__(256) k_trusted(ReadsDev R, KParams K, FiltDev 
                 const int s = c * 64 + lane;
                 bool valid = false;
                 uint32_t blk = 0, pat = 0;
+                bool known = false;   // this read put the k-mer into the sampled filter itself (pass 1)
                 if (s < nk) {
                     key[c] = kmer_at(R, K, off + s, valid);
                     blk = block_of(S, key[c]);
                     pat = pattern_of(S, key[c]);
+                    if (R.hint_sampled) {
+                        const uint64_t g = off + s;
+                        known = (R.hint_sampled[g >> 5] >> (g & 31)) & 1;
+                    }
                 }
-                const bool present = bloom_coop<false>(S, valid, blk, pat) && valid;
+                const bool looked = bloom_coop<false>(S, valid && !known, blk, pat);   // every lane must take part
+                const bool present = known || (looked && valid);
                 P[c] = __ballot(present);
                 V[c] = __ballot(valid);
             }
@@ -229,18 +255,9 @@ __global__ void __launch_bounds__(256) k_trusted(ReadsDev R, KParams K, FiltDev 
             }
         }
         if (err_out) {
-            // flat bit array shared with neighbouring reads: OR in 32-bit pieces
 #pragma unroll
-            for (int c = 0; c < NW; ++c) {
-                if (c * 64 < L && lane < 2) {
-                    const uint32_t v = (uint32_t)(E[c] >> (32 * lane));
-                    const uint64_t g = off + (uint64_t)c * 64 + 32 * lane;
-                    if (v) {
-                        atomicOr(&err_out[g >> 5], v << (g & 31));
-                        if (g & 31) atomicOr(&err_out[(g >> 5) + 1], v >> (32 - (g & 31)));
-                    }
-                }
-            }
+            for (int c = 0; c < NW; ++c)
+                if (c * 64 < L) or_bits64(err_out, off + (uint64_t)c * 64, E[c], lane);
         }
 #pragma unroll
         for (int c = 0; c < NW; ++c) {
@@ -255,7 +272,9 @@ __global__ void __launch_bounds__(256) k_trusted(ReadsDev R, KParams K, FiltDev 
                     pat = pattern_of(T, key[c]);
                 }
                 bloom_coop<true>(T, take, blk, pat);
-                mine += __popcll(__ballot(take));
+                const unsigned long long bal = __ballot(take);
+                if (R.hint_trusted) or_bits64(R.hint_trusted, off + (uint64_t)c * 64, bal, lane);
+                mine += __popcll(bal);
             }
         }
     }
@@ -287,12 +306,18 @@ __global__ void __launch_bounds__(256) k_scan_trusted(ReadsDev R, KParams K, Fil
                 const int s = c * 64 + lane;
                 bool valid = false;
                 uint32_t blk = 0, pat = 0;
+                bool known = false;   // this read put the k-mer into the trusted filter itself (pass 2)
                 if (s < nk) {
                     const uint64_t key = kmer_at(R, K, off + s, valid);
                     blk = block_of(T, key);
                     pat = pattern_of(T, key);
+                    if (R.hint_trusted) {
+                        const uint64_t g = off + s;
+                        known = (R.hint_trusted[g >> 5] >> (g & 31)) & 1;
+                    }
                 }
-                const bool ok = bloom_coop<false>(T, valid, blk, pat) && valid;
+                const bool looked = bloom_coop<false>(T, valid && !known, blk, pat);   // every lane must take part
+                const bool ok = known || (looked && valid);
                 M[c] = __ballot(ok);
                 trusted += __popcll(M[c]);
             }
@@ -475,7 +500,7 @@ __device__ __forceinline__ uint64_t cyc_index(const HistDev &H, int rg, int q, i
     return ((((uint64_t)rg * KBBQ_NQ + q) * 2 + s) * H.n_cycle + c) * 2;
 }
 
-__global__ void __launch_bounds__(256) k_tally(ReadsDev R, HistDev H, const uint32_t *err_bits, const uint32_t *patch,
+__global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uint32_t *err_bits, const uint32_t *patch,
                                                 int ccap, int minscore) {
     extern __shared__ uint32_t lds[];
     // layout: cycle totals [2][ccap][94] u16 (packed), then dinuc totals [94][16] u32
@@ -861,9 +886,13 @@ int device_view(kbbq_engine *e, const kbbq_reads *in, ReadsDev *out, int *max_le
     R.n_reads = in->n_reads;
     R.n_bases = in->n_bases;
     R.read_len = in->read_len;
+    R.hint_sampled = nullptr;
+    R.hint_trusted = nullptr;
     if (in->on_device) {
         R.bases = in->bases; R.nmask = in->nmask; R.qual = in->qual;
         R.offsets = in->offsets; R.flags = in->flags; R.rg = in->rg;
+        R.hint_sampled = (uint32_t *)in->hint_sampled;
+        R.hint_trusted = (uint32_t *)in->hint_trusted;
     } else {
         int rc;
         if ((rc = stage_array(e, in->bases, in->n_bases / 32 + 1, 1, &R.bases))) return rc;
@@ -1131,6 +1160,8 @@ int kbbq_reads_upload(kbbq_engine *e, const kbbq_reads *host, kbbq_reads *dev) {
     if (host->on_device) return fail(KBBQ_EINVAL, "batch is already on the device");
     *dev = *host;
     dev->on_device = 1;
+    dev->hint_sampled = nullptr;
+    dev->hint_trusted = nullptr;
     dev->bases = nullptr; dev->nmask = nullptr; dev->qual = nullptr; dev->offsets = nullptr; dev->flags = nullptr; dev->rg = nullptr;
 #define UP(field, type, count, pad)                                                               \
     if (host->field) {                                                                            \
@@ -1374,8 +1405,9 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
         attr_lds = lds;
     }
     Timed t(e, "k_tally");
-    const int blocks = (int)std::min<uint64_t>((R.n_reads + 3) / 4, 256 * 2);
-    hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(256), lds, e->stream, R, H, err_bits, patch, ccap, 6);
+    // 16 wavefronts share one LDS table: two blocks (32 waves) per CU at 150-base reads
+    const int blocks = (int)std::min<uint64_t>((R.n_reads + 15) / 16, 256 * 2);
+    hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(1024), lds, e->stream, R, H, err_bits, patch, ccap, 6);
     HIP_TRY(hipGetLastError());
     return KBBQ_OK;
 }

@@ -50,6 +50,11 @@ class DeviceReads:
         self.n_bases = int(creads.n_bases)
         self.max_len = max_len
 
+    def set_hints(self, sampled_ptr, trusted_ptr):
+        """Attach the two caller-owned, zeroed hint bit arrays (n_bases/64+2 u64 words each)."""
+        self.c.hint_sampled = sampled_ptr
+        self.c.hint_trusted = trusted_ptr
+
     def free(self):
         if self.c is not None and self.engine.h:
             _lib.check(self.engine.L.kbbq_reads_free(self.engine.h, ctypes.byref(self.c)))
@@ -72,6 +77,8 @@ class DeviceReads:
         v.rg = (self.c.rg + 2 * first_read) if self.c.rg else None
         v.read_len = rl
         v.on_device = 1
+        v.hint_sampled = (self.c.hint_sampled + b0 // 8) if self.c.hint_sampled else None
+        v.hint_trusted = (self.c.hint_trusted + b0 // 8) if self.c.hint_trusted else None
         d = DeviceReads(self.engine, v, self.max_len)
         d.free = lambda: None
         return d

@@ -130,6 +130,42 @@ def test_device_resident_batches_match_host_batches():
     e.close()
 
 
+def test_hint_arrays_do_not_change_results():
+    """kbbq_reads.hint_sampled / hint_trusted only skip lookups whose answer is known."""
+    import torch
+    d = common.make_dataset(seed=88, genome_len=15000, coverage=24, n_per_million=2000, extra_errors=100)
+    ref = common.run_engine(d, uniform=True)
+    alpha_ld, cov, approx = common.plan_parameters(d["genome_len"], d["coverage"], None)
+    e = Engine(32, alpha_ld, 777, approx, n_rg=1, max_read_len=150)
+    hb = ReadBatch(d["seq"], d["qual"], d["off"], d["rg"], d["second"], uniform=True)
+    db = e.upload(hb)
+    nbytes = (hb.n_bases // 64 + 2) * 8
+    hints = torch.zeros(2 * nbytes, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    db.set_hints(hints.data_ptr(), hints.data_ptr() + nbytes)
+    # two sub-batches through views, like bench.py
+    n = db.n_reads
+    cut = (n // 2) // 32 * 32
+    parts = [db.view(0, cut), db.view(cut, n - cut)]
+    for v, o in zip(parts, (0, cut * (150 - 32 + 1))):
+        e.subsample_kmers(v, o)
+    assert e.sample_finish() == ref["sampled_inserted"]
+    assert np.array_equal(e.filter_table(0), ref["sampled_table"])
+    e.compute_thresholds()
+    for v in parts:
+        e.find_trusted_kmers(v)
+    assert e.trusted_finish() == ref["trusted_inserted"]
+    assert np.array_equal(e.filter_table(1), ref["trusted_table"])
+    for v in parts:
+        e.get_covariatedata(v)
+    c = e.covariates()
+    assert np.array_equal(c["cycle"], ref["cov"]["cycle"]) and np.array_equal(c["dinuc"], ref["cov"]["dinuc"])
+    hs = hints.cpu().numpy()
+    assert hs[:nbytes].any() and hs[nbytes:].any()       # the hints were actually written
+    db.free()
+    e.close()
+
+
 def test_fixed_mode_tally_matches_oracle():
     # --fixed (kbbq.cc:367-378): caller-supplied error flags feed the tally directly
     d = common.make_dataset(seed=77, genome_len=8000, coverage=15, n_rg=2, paired=True)
