@@ -75,8 +75,9 @@ def kernel_model(name, bases, nk, alpha, f_t):
     (packed bases 0.25 B, quals 1 B, Bloom query 64 B, insert 64 B + 64 B)."""
     return {
         "k_draw_mask": nk / 8.0,
-        "k_sample_insert": bases * 0.25 + nk / 8.0 + nk * alpha * 128.0,
-        "k_trusted": bases * 1.25 + nk * (64.0 + f_t * 128.0),
+        "k_insert_sampled": bases * 0.25 + nk / 8.0 + nk * alpha * 128.0,
+        "k_infer": bases * 1.25 + nk * 64.0,
+        "k_insert_trusted": bases * 0.25 + nk * f_t * 128.0,
         "k_scan_trusted": bases * 0.25 + nk * 64.0,
         "k_tally": bases * 1.25 + bases / 8.0,
         "k_recalibrate": bases * 2.25,

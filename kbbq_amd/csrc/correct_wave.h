@@ -153,7 +153,7 @@ struct WaveCorrector {
         const bool go = active && p.valid;
         const uint64_t key = p.fw < p.rc ? p.fw : p.rc;
         queries += __popcll(__ballot(go));
-        return bloom_coop<false>(f, go, block_of(f, key), pattern_of(f, key)) && go;
+        return bloom_coop<false, 4>(f, go, block_of(f, key), pattern_of(f, key)) && go;
     }
 
     // trusted mask of the working sequence for k-mer starts in [lo, lo+n-k]
@@ -540,8 +540,16 @@ struct WaveCorrector {
             }
             if (bad >= 0) { if (dir > 0) res.bad_suffix = bad; else res.bad_prefix = bad; }
         }
-        // over-correction control, readutils.cc:429-546
+        // over-correction control, readutils.cc:429-546.  A base is un-flagged only where the weighted
+        // count of flags in a 20-base window exceeds the threshold (4 or 5, flags weigh 1/2 or 1): with
+        // four flags or fewer in the whole range nothing can exceed it, and the trusted-region check
+        // (which only selects between 4 and 5) need not run either.
+        int n_flags = 0;
         if (corrected) {
+            for (int c = 0; c < NN; ++c) n_flags += __popcll(ldw(E, c));
+            n_flags = uni(n_flags);
+        }
+        if (corrected && n_flags > 4) {
             const int last = lo + n - k;   // last k-mer start
             // trusted regions of the entry sequence that end before the last k-mer must hold no flag
             const int tail_start = find_prev(Te, last, lo, false) + 1;   // first start of the final trusted run

@@ -100,45 +100,81 @@ __device__ __forceinline__ uint32_t pattern_of(const FiltDev &f, uint64_t key) {
     return hash_ap8(key, f.salt1) & 0xFFFFu;
 }
 
-// Eight lanes per k-mer: in round j the lanes 8g..8g+7 fetch the eight words of
-// the block and of the pattern owned by lane 8j+g, so every 64-byte block costs
-// exactly one fully used 64-byte request.  Returns, in the OWNING lane, whether
-// the filter contained the pattern before this call (pattern_blocked_bf::contains,
-// bloom.hh:276-292).  With INSERT the missing bits are OR-ed in with one 64-byte
-// atomic request per k-mer (pattern_blocked_bf::insert, bloom.hh:255-267); a
-// block that already holds the pattern is not written at all, which is legal
-// because bits are only ever set.  All 64 lanes must call this together.
-template <bool INSERT>
+// The cooperative Bloom access.  A wavefront holds one k-mer per lane (active, blk, pat); the 64-byte
+// block and the 64-byte pattern of every active k-mer are fetched by a GROUP of lanes so that each
+// block is exactly one fully used 64-byte request (tools/probe_hbm: only such shapes reach the chip's
+// random-64-byte ceiling):
+//   LANES = 8: eight lanes x 8 bytes, 8 rounds of 8 k-mers.  One atomic request per inserted block:
+//              used by the kernels that insert.
+//   LANES = 4: four lanes x 16 bytes, 4 rounds of 16 k-mers: half the shuffles and ballots, shorter
+//              dependent chain: used by the latency-bound correction walk.
+// Returns, in the OWNING lane, whether the filter contained the pattern before this call
+// (pattern_blocked_bf::contains, bloom.hh:276-292).  With INSERT the missing bits are OR-ed in
+// atomically (pattern_blocked_bf::insert, bloom.hh:255-267); a block that already holds the pattern is
+// not written at all, which is legal because bits are only ever set.
+// ALL 64 LANES MUST CALL THIS TOGETHER (never behind a short-circuit || or &&).
+template <bool INSERT, int LANES = 8>
 __device__ __forceinline__ bool bloom_coop(const FiltDev &f, bool active, uint32_t blk, uint32_t pat) {
     const int lane = threadIdx.x & 63;
-    const int sub = lane & 7, grp = lane >> 3;
-    uint64_t tv[8], pv[8];
-    uint32_t bb[8];
     const unsigned long long live = __ballot(active);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        tv[j] = 0;
-        pv[j] = 0;
-        bb[j] = 0;
-        if (((live >> (8 * j)) & 0xFFull) == 0) continue;   // wave-uniform: nobody owns a k-mer in this round
-        const int src = j * 8 + grp;
-        const int a = __shfl((int)active, src);
-        bb[j] = __shfl(blk, src);
-        const uint32_t p = __shfl(pat, src);
-        if (a) {
-            pv[j] = f.patterns[(uint64_t)p * 8 + sub];
-            tv[j] = f.table[(uint64_t)bb[j] * 8 + sub];
-        }
-    }
     bool contained = false;
+    if constexpr (LANES == 8) {
+        const int sub = lane & 7, grp = lane >> 3;
+        uint64_t tv[8], pv[8];
+        uint32_t bb[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const uint64_t miss = pv[j] & ~tv[j];
-        if (INSERT) {
-            if (miss) atomicOr((unsigned long long *)&f.table[(uint64_t)bb[j] * 8 + sub], (unsigned long long)miss);
+        for (int j = 0; j < 8; ++j) {
+            tv[j] = 0;
+            pv[j] = 0;
+            bb[j] = 0;
+            if (((live >> (8 * j)) & 0xFFull) == 0) continue;   // wave-uniform: nobody owns a k-mer in this round
+            const int src = j * 8 + grp;
+            const int a = __shfl((int)active, src);
+            bb[j] = __shfl(blk, src);
+            const uint32_t p = __shfl(pat, src);
+            if (a) {
+                pv[j] = f.patterns[(uint64_t)p * 8 + sub];
+                tv[j] = f.table[(uint64_t)bb[j] * 8 + sub];
+            }
         }
-        const unsigned long long bal = __ballot(miss != 0);
-        if (grp == j) contained = ((bal >> (8 * sub)) & 0xFFull) == 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint64_t miss = pv[j] & ~tv[j];
+            if (INSERT) {
+                if (miss) atomicOr((unsigned long long *)&f.table[(uint64_t)bb[j] * 8 + sub], (unsigned long long)miss);
+            }
+            const unsigned long long bal = __ballot(miss != 0);
+            if (grp == j) contained = ((bal >> (8 * sub)) & 0xFFull) == 0;
+        }
+    } else {
+        const int sub = lane & 3, grp = lane >> 2;
+        ulonglong2 tv[4], pv[4];
+        uint32_t bb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tv[j] = make_ulonglong2(0, 0);
+            pv[j] = make_ulonglong2(0, 0);
+            bb[j] = 0;
+            if (((live >> (16 * j)) & 0xFFFFull) == 0) continue;
+            const int src = j * 16 + grp;
+            const int a = __shfl((int)active, src);
+            bb[j] = __shfl(blk, src);
+            const uint32_t p = __shfl(pat, src);
+            if (a) {
+                pv[j] = *reinterpret_cast<const ulonglong2 *>(f.patterns + (uint64_t)p * 8 + sub * 2);
+                tv[j] = *reinterpret_cast<const ulonglong2 *>(f.table + (uint64_t)bb[j] * 8 + sub * 2);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t mx = pv[j].x & ~tv[j].x, my = pv[j].y & ~tv[j].y;
+            if (INSERT) {
+                if (mx) atomicOr((unsigned long long *)&f.table[(uint64_t)bb[j] * 8 + sub * 2], (unsigned long long)mx);
+                if (my) atomicOr((unsigned long long *)&f.table[(uint64_t)bb[j] * 8 + sub * 2 + 1], (unsigned long long)my);
+            }
+            const unsigned long long bal = __ballot((mx | my) != 0);
+            if ((lane >> 4) == j) contained = ((bal >> (4 * (lane & 15))) & 0xFull) == 0;
+        }
     }
     return contained;
 }

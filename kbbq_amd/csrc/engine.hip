@@ -2,8 +2,9 @@
 //
 // Pass structure (one kernel or kernel group per reference loop):
 //   pass 1  k_draw_mask        one xoshiro256** draw per k-mer position (htsiter.cc:113-129)
-//           k_sample_insert    sampled & valid k-mers -> sampled filter   (recalibrateutils.cc:7-13)
-//   pass 2  k_trusted          infer_read_errors + trusted inserts        (recalibrateutils.cc:15-40)
+//           k_insert_marked    sampled & valid k-mers -> sampled filter   (recalibrateutils.cc:7-13)
+//   pass 2  k_infer            infer_read_errors, which k-mers are trusted (recalibrateutils.cc:15-40)
+//           k_insert_marked    those k-mers -> trusted filter
 //   pass 3  k_scan_trusted     trusted mask of every k-mer; clean reads finish here
 //           k_compact          work list of reads that need the correction walk
 //           k_correct          get_errors, one read per lane             (readutils.cc:238-570)
@@ -139,10 +140,13 @@ __device__ __forceinline__ uint64_t kmer_base(const uint64_t *kofs, uint64_t r, 
     return r * (uint64_t)(read_len >= (uint32_t)k ? read_len - k + 1 : 0);
 }
 
-// ---- pass 1b: insert the sampled k-mers -------------------------------------
-// One wavefront per read, one lane per k-mer start.
-template <int NW>
-__global__ void __launch_bounds__(256) k_sample_insert(ReadsDev R, KParams K, FiltDev F, const uint64_t *mask,
+// ---- passes 1b and 2b: insert the marked k-mers of every read into a filter --------------
+// One wavefront per read, one lane per k-mer start.  BY_BASE = false: `mask` is the sampler's draw
+// mask, one bit per k-mer position in file order (pass 1: insert where drawn and valid, and record
+// that in hint_sampled).  BY_BASE = true: `mask` has one bit per base of the batch and already
+// means "insert the k-mer starting here" (pass 2: the decisions of k_infer).
+template <int NW, bool BY_BASE>
+__global__ void __launch_bounds__(256) k_insert_marked(ReadsDev R, KParams K, FiltDev F, const uint64_t *mask,
                                                         const uint64_t *kofs, unsigned long long *inserted) {
     __shared__ uint2 pack[4][64];
     const int lane = threadIdx.x & 63;
@@ -155,7 +159,7 @@ __global__ void __launch_bounds__(256) k_sample_insert(ReadsDev R, KParams K, Fi
         read_span(R, r, off, len);
         if (len < (uint32_t)K.k) continue;
         const int nk = (int)len - K.k + 1;
-        const uint64_t kb = kmer_base(kofs, r, R.read_len, K.k);
+        const uint64_t kb = BY_BASE ? off : kmer_base(kofs, r, R.read_len, K.k);
         // Only ~alpha of the positions are sampled: the sampled k-mers of the read are first packed into
         // the low lanes (through a per-wave LDS row), so the cooperative insert runs ceil(count/8) rounds
         // instead of 8 per 64-position chunk.
@@ -171,13 +175,13 @@ __global__ void __launch_bounds__(256) k_sample_insert(ReadsDev R, KParams K, Fi
                 const bool drawn = (mask[o >> 6] >> (o & 63)) & 1;
                 bool valid;
                 const uint64_t key = kmer_at(R, K, off + s, valid);
-                take = drawn && valid;
+                take = drawn && (BY_BASE || valid);
                 blk = block_of(F, key);
                 pat = pattern_of(F, key);
             }
             const unsigned long long bal = __ballot(take);
             const int cnt = __popcll(bal);
-            if (R.hint_sampled) or_bits64(R.hint_sampled, off + (uint64_t)c * 64, bal, lane);
+            if (!BY_BASE && R.hint_sampled) or_bits64(R.hint_sampled, off + (uint64_t)c * 64, bal, lane);
             if (filled + cnt > 64) {
                 bloom_coop<true>(F, lane < filled, q_blk, q_pat);
                 filled = 0;
@@ -192,7 +196,7 @@ __global__ void __launch_bounds__(256) k_sample_insert(ReadsDev R, KParams K, Fi
         }
         if (filled) bloom_coop<true>(F, lane < filled, q_blk, q_pat);
     }
-    if (lane == 0 && mine) atomicAdd(inserted, mine);
+    if (inserted && lane == 0 && mine) atomicAdd(inserted, mine);
 }
 
 // ---- pass 2 ------------------------------------------------------------------
@@ -204,8 +208,8 @@ __global__ void __launch_bounds__(256) k_sample_insert(ReadsDev R, KParams K, Fi
 struct Thresholds { int v[KBBQ_MAX_KMER + 1]; };
 
 template <int NW>
-__global__ void __launch_bounds__(256) k_trusted(ReadsDev R, KParams K, FiltDev S, FiltDev T, Thresholds thr,
-                                                  unsigned long long *inserted, uint32_t *err_out) {
+__global__ void __launch_bounds__(256) k_infer(ReadsDev R, KParams K, FiltDev S, Thresholds thr, uint32_t *take_bits,
+                                                unsigned long long *inserted, uint32_t *err_out) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -216,19 +220,19 @@ __global__ void __launch_bounds__(256) k_trusted(ReadsDev R, KParams K, FiltDev 
         read_span(R, r, off, len);
         if (len < (uint32_t)k) continue;   // engine-defined: the reference underflows size_t here
         const int L = (int)len, nk = L - k + 1;
-        uint64_t P[NW], E[NW], V[NW], key[NW];
+        uint64_t P[NW], E[NW], V[NW];
 #pragma unroll
         for (int c = 0; c < NW; ++c) {
-            P[c] = 0; E[c] = 0; V[c] = 0; key[c] = 0;
+            P[c] = 0; E[c] = 0; V[c] = 0;
             if (c * 64 < nk) {
                 const int s = c * 64 + lane;
                 bool valid = false;
                 uint32_t blk = 0, pat = 0;
                 bool known = false;   // this read put the k-mer into the sampled filter itself (pass 1)
                 if (s < nk) {
-                    key[c] = kmer_at(R, K, off + s, valid);
-                    blk = block_of(S, key[c]);
-                    pat = pattern_of(S, key[c]);
+                    const uint64_t key = kmer_at(R, K, off + s, valid);
+                    blk = block_of(S, key);
+                    pat = pattern_of(S, key);
                     if (R.hint_sampled) {
                         const uint64_t g = off + s;
                         known = (R.hint_sampled[g >> 5] >> (g & 31)) & 1;
@@ -259,21 +263,15 @@ __global__ void __launch_bounds__(256) k_trusted(ReadsDev R, KParams K, FiltDev 
             for (int c = 0; c < NW; ++c)
                 if (c * 64 < L) or_bits64(err_out, off + (uint64_t)c * 64, E[c], lane);
         }
+        // the k-mer ending at i goes into the trusted filter iff it is valid and its k bases are all
+        // unflagged (recalibrateutils.cc:26-38); the inserts themselves are k_insert_marked's
 #pragma unroll
         for (int c = 0; c < NW; ++c) {
             if (c * 64 < nk) {
                 const int s = c * 64 + lane;
-                bool take = false;
-                uint32_t blk = 0, pat = 0;
-                if (s < nk) {
-                    const bool valid = (V[c] >> lane) & 1;
-                    take = valid && range_popc<NW>(E, s, s + k - 1) == 0;
-                    blk = block_of(T, key[c]);
-                    pat = pattern_of(T, key[c]);
-                }
-                bloom_coop<true>(T, take, blk, pat);
+                const bool take = s < nk && ((V[c] >> lane) & 1) && range_popc<NW>(E, s, s + k - 1) == 0;
                 const unsigned long long bal = __ballot(take);
-                if (R.hint_trusted) or_bits64(R.hint_trusted, off + (uint64_t)c * 64, bal, lane);
+                or_bits64(take_bits, off + (uint64_t)c * 64, bal, lane);
                 mine += __popcll(bal);
             }
         }
@@ -328,16 +326,24 @@ __global__ void __launch_bounds__(256) k_scan_trusted(ReadsDev R, KParams K, Fil
     }
 }
 
-__global__ void __launch_bounds__(256) k_compact(const uint8_t *dirty, uint64_t n, uint32_t *list,
-                                                  unsigned long long *count) {
+__global__ void __launch_bounds__(1024) k_compact(const uint8_t *dirty, uint64_t n, uint32_t *list,
+                                                   unsigned long long *count) {
+    // one global atomic per 1024-lane block: wave counts -> LDS scan -> block base
+    __shared__ unsigned int wave_cnt[16];
+    __shared__ unsigned long long block_base;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool d = i < n && dirty[i];
     const unsigned long long bal = __ballot(d);
-    const int lane = threadIdx.x & 63;
-    unsigned long long base = 0;
-    if (lane == 0 && bal) base = atomicAdd(count, (unsigned long long)__popcll(bal));
-    base = __shfl(base, 0);
-    if (d) list[base + __popcll(bal & ((1ULL << lane) - 1))] = (uint32_t)i;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[w] = (unsigned int)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int tot = 0;
+        for (int k = 0; k < 16; ++k) { const unsigned int c = wave_cnt[k]; wave_cnt[k] = tot; tot += c; }
+        block_base = tot ? atomicAdd(count, (unsigned long long)tot) : 0ULL;
+    }
+    __syncthreads();
+    if (d) list[block_base + wave_cnt[w] + __popcll(bal & ((1ULL << lane) - 1))] = (uint32_t)i;
 }
 
 // ---- pass 3b: the correction walk, one read per lane ---------------------------
@@ -403,7 +409,7 @@ __global__ void __launch_bounds__(BLOCK) k_correct(ReadsDev R, KParams K, FiltDe
 
 // ---- pass 3b (default): the correction walk, one read per WAVEFRONT (correct_wave.h) ----
 template <int NB, int NN>
-__global__ void __launch_bounds__(256) k_correct_wave(ReadsDev R, KParams K, FiltDev T, const uint32_t *list,
+__global__ void __launch_bounds__(256, 4) k_correct_wave(ReadsDev R, KParams K, FiltDev T, const uint32_t *list,
                                                        const unsigned long long *n_list, const uint64_t *tmask,
                                                        int tmask_words, uint32_t *err_bits, uint32_t *patch,
                                                        unsigned long long *stats) {
@@ -500,94 +506,155 @@ __device__ __forceinline__ uint64_t cyc_index(const HistDev &H, int rg, int q, i
     return ((((uint64_t)rg * KBBQ_NQ + q) * 2 + s) * H.n_cycle + c) * 2;
 }
 
+// One lane per 16 consecutive bases of the batch (16-byte quality load, 4-byte base load), a block of
+// 1024 lanes per 16 Ki bases; the block's LDS table is flushed before any 16-bit counter could wrap
+// (a read adds at most 1 to a counter, so the block counts the reads it has touched).
 __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uint32_t *err_bits, const uint32_t *patch,
-                                                int ccap, int minscore) {
+                                                 int ccap, int minscore, int vec_ok) {
     extern __shared__ uint32_t lds[];
-    // layout: cycle totals [2][ccap][94] u16 (packed), then dinuc totals [94][16] u32
+    // layout: cycle totals [2][94][ccap] u16 (packed, cycle slots permuted), dinuc totals [94][16] u32,
+    // dinuc errors [94][16] u32 (few, hot addresses: global atomics on them serialise at the memory side),
+    // reads-touched counter
     const int cyc_words = (2 * ccap * KBBQ_NQ + 1) / 2;
     uint32_t *l_cyc = lds;
-    uint32_t *l_di = lds + cyc_words;
-    const int lds_words = cyc_words + KBBQ_NQ * 16;
+    uint32_t *l_cye = lds + cyc_words;          // cycle error counts, same layout as the totals
+    uint32_t *l_di = l_cye + cyc_words;
+    uint32_t *l_die = l_di + KBBQ_NQ * 16;
+    uint32_t *l_reads = l_die + KBBQ_NQ * 16;
+    const int lds_words = 2 * cyc_words + 2 * KBBQ_NQ * 16 + 1;
     for (int i = threadIdx.x; i < lds_words; i += blockDim.x) lds[i] = 0;
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    const int waves_per_block = blockDim.x >> 6;
     const int lds_rg = R.rg ? (int)R.rg[0] : 0;
-    int since_flush = 0;
-    // every wave of a block runs the same number of iterations so that the
-    // flush barriers below are reached by all of them
-    const uint64_t iters = (R.n_reads + n_waves - 1) / n_waves;
+    const uint64_t n_groups = (R.n_bases + 15) / 16;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t iters = (n_groups + stride - 1) / stride;
     for (uint64_t it = 0; it < iters; ++it) {
-        const uint64_t r = wave + it * n_waves;
-        if (r < R.n_reads) {
-            uint64_t off; uint32_t len;
-            read_span(R, r, off, len);
-            const int rg = R.rg ? (int)R.rg[r] : 0;
-            const int second = R.flags ? (R.flags[r] & 1) : 0;
-            const uint32_t pt = patch ? patch[r] : 0u;
-            const int p_pos = (pt >> 31) ? (int)((pt >> 8) & 0xFFFF) : -1;
-            const int p_base = (int)(pt & 3);
-            if (rg < H.n_rg) {
-                for (int c0 = 0; c0 < (int)len; c0 += 64) {
-                    const int i = c0 + lane;
-                    if (i < (int)len && i < H.n_cycle) {
-                        const uint64_t g = off + i;
-                        const int q = R.qual[g];
-                        if (q < KBBQ_NQ) {
-                            const int e = (err_bits[g >> 5] >> (g & 31)) & 1;
-                            if (rg == lds_rg && i < ccap) {
-                                const int idx = (second * ccap + i) * KBBQ_NQ + q;
-                                atomicAdd(&l_cyc[idx >> 1], 1u << (16 * (idx & 1)));
+        const uint64_t grp = it * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const uint64_t g0 = grp * 16;
+        int starts = 0;
+        if (g0 < R.n_bases) {
+            uint64_t r, start, end;
+            if (R.offsets) {
+                uint64_t lo = 0, hi = R.n_reads;   // last r with offsets[r] <= g0
+                while (hi - lo > 1) {
+                    const uint64_t mid = (lo + hi) >> 1;
+                    if (R.offsets[mid] <= g0) lo = mid; else hi = mid;
+                }
+                r = lo;
+                start = R.offsets[r];
+                end = R.offsets[r + 1];
+                while (end <= g0) { ++r; start = end; end = R.offsets[r + 1]; }
+            } else {
+                r = g0 / R.read_len;
+                start = r * R.read_len;
+                end = start + R.read_len;
+            }
+            const int n = (int)min((uint64_t)16, R.n_bases - g0);
+            uint8_t qv[16];
+            if (n == 16 && vec_ok) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(R.qual + g0);
+                memcpy(qv, &v, 16);
+            } else {
+                for (int i = 0; i < 16; ++i) qv[i] = i < n ? R.qual[g0 + i] : 0;
+            }
+            const uint32_t bw = (uint32_t)(R.bases[g0 >> 5] >> ((g0 & 31) * 2));
+            const uint32_t nw = (uint32_t)(R.nmask[g0 >> 6] >> (g0 & 63)) & 0xFFFFu;
+            const uint32_t ew = (err_bits[g0 >> 5] >> (g0 & 31)) & 0xFFFFu;
+            int prev_b = 0, prev_n = 1;
+            if (g0 > 0) {
+                const uint64_t gp = g0 - 1;
+                prev_b = (int)((R.bases[gp >> 5] >> ((gp & 31) * 2)) & 3);
+                prev_n = (int)((R.nmask[gp >> 6] >> (gp & 63)) & 1);
+            }
+            int rg = R.rg ? (int)R.rg[r] : 0;
+            int second = R.flags ? (R.flags[r] & 1) : 0;
+            uint32_t pt = patch ? patch[r] : 0u;
+            starts = g0 == start ? 1 : 0;
+            // the read this group starts in may carry a patch on the base just before the group
+            if ((pt >> 31) && g0 > start && (int)((pt >> 8) & 0xFFFF) == (int)(g0 - 1 - start)) { prev_b = (int)(pt & 3); prev_n = 0; }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint64_t g = g0 + i;
+                if (i < n) {
+                    while (g >= end) {
+                        ++r; start = end;
+                        end = R.offsets ? R.offsets[r + 1] : end + R.read_len;
+                        rg = R.rg ? (int)R.rg[r] : 0;
+                        second = R.flags ? (R.flags[r] & 1) : 0;
+                        pt = patch ? patch[r] : 0u;
+                        if (end > start) ++starts;
+                    }
+                    const int cyc = (int)(g - start);
+                    int b = (int)((bw >> (2 * i)) & 3), nn = (int)((nw >> i) & 1);
+                    if ((pt >> 31) && (int)((pt >> 8) & 0xFFFF) == cyc) { b = (int)(pt & 3); nn = 0; }
+                    const int q = qv[i];
+                    const int er = (int)((ew >> i) & 1);
+                    if (rg < H.n_rg && cyc < H.n_cycle && q < KBBQ_NQ) {
+                        if (rg == lds_rg && cyc < ccap) {
+                            // lanes of one instruction are 16 cycles apart: store cycle c at slot
+                            // (c%16)*(ccap/16) + c/16 so that they land in neighbouring words, not in two banks
+                            const int slot = (cyc & 15) * (ccap >> 4) + (cyc >> 4);
+                            const int idx = (second * KBBQ_NQ + q) * ccap + slot;
+                            atomicAdd(&l_cyc[idx >> 1], 1u << (16 * (idx & 1)));
+                            if (er) atomicAdd(&l_cye[idx >> 1], 1u << (16 * (idx & 1)));
+                        } else {
+                            atomicAdd(&H.cycle[cyc_index(H, rg, q, second, cyc) + 1], 1ULL);
+                            if (er) atomicAdd(&H.cycle[cyc_index(H, rg, q, second, cyc)], 1ULL);
+                        }
+                        if (cyc >= 1 && q >= minscore && !nn && !prev_n) {
+                            const int d = (prev_b << 2) | b;
+                            if (rg == lds_rg) {
+                                atomicAdd(&l_di[q * 16 + d], 1u);
+                                if (er) atomicAdd(&l_die[q * 16 + d], 1u);
                             } else {
-                                atomicAdd(&H.cycle[cyc_index(H, rg, q, second, i) + 1], 1ULL);
-                            }
-                            if (e) atomicAdd(&H.cycle[cyc_index(H, rg, q, second, i)], 1ULL);
-                            if (i >= 1 && q >= minscore) {
-                                int b1 = (int)((R.bases[g >> 5] >> ((g & 31) * 2)) & 3);
-                                int n1 = (int)((R.nmask[g >> 6] >> (g & 63)) & 1);
-                                const uint64_t gp = g - 1;
-                                int b0 = (int)((R.bases[gp >> 5] >> ((gp & 31) * 2)) & 3);
-                                int n0 = (int)((R.nmask[gp >> 6] >> (gp & 63)) & 1);
-                                if (i == p_pos) { b1 = p_base; n1 = 0; }
-                                if (i - 1 == p_pos) { b0 = p_base; n0 = 0; }
-                                if (!n0 && !n1) {
-                                    const int d = (b0 << 2) | b1;
-                                    if (rg == lds_rg) atomicAdd(&l_di[q * 16 + d], 1u);
-                                    else atomicAdd(&H.dinuc[(((uint64_t)rg * KBBQ_NQ + q) * 16 + d) * 2 + 1], 1ULL);
-                                    if (e) atomicAdd(&H.dinuc[(((uint64_t)rg * KBBQ_NQ + q) * 16 + d) * 2], 1ULL);
-                                }
+                                atomicAdd(&H.dinuc[(((uint64_t)rg * KBBQ_NQ + q) * 16 + d) * 2 + 1], 1ULL);
+                                if (er) atomicAdd(&H.dinuc[(((uint64_t)rg * KBBQ_NQ + q) * 16 + d) * 2], 1ULL);
                             }
                         }
                     }
+                    prev_b = b;
+                    prev_n = nn;
                 }
             }
+            // a read that began before this group and continues into it also counts once for this block
+            starts += g0 != start ? 1 : 0;
         }
-        since_flush += waves_per_block;
-        if (since_flush >= 60000 || it + 1 == iters) {
+        {
+            // reads touched by this wavefront (a lane touches at most 17): bit-sliced ballot sum, one LDS add per wave
+            const int s = g0 < R.n_bases ? starts : 0;
+            unsigned int tot = 0;
+#pragma unroll
+            for (int b = 0; b < 5; ++b) tot += (unsigned int)__popcll(__ballot((s >> b) & 1)) << b;
+            if ((threadIdx.x & 63) == 0 && tot) atomicAdd(l_reads, tot);
+        }
+        __syncthreads();
+        if (*l_reads >= 40000u || it + 1 == iters) {
             __syncthreads();
             for (int w = threadIdx.x; w < cyc_words; w += blockDim.x) {
-                const uint32_t v = l_cyc[w];
-                if (!v) continue;
+                const uint32_t v = l_cyc[w], ve = l_cye[w];
+                if (!v) continue;      // no total, no error
                 l_cyc[w] = 0;
+                l_cye[w] = 0;
                 for (int h = 0; h < 2; ++h) {
-                    const uint32_t cnt = (v >> (16 * h)) & 0xFFFFu;
+                    const uint32_t cnt = (v >> (16 * h)) & 0xFFFFu, cne = (ve >> (16 * h)) & 0xFFFFu;
                     if (!cnt) continue;
                     const int idx = 2 * w + h;
-                    const int q = idx % KBBQ_NQ, rest = idx / KBBQ_NQ;
-                    const int c = rest % ccap, s = rest / ccap;
-                    atomicAdd(&H.cycle[cyc_index(H, lds_rg, q, s, c) + 1], (unsigned long long)cnt);
+                    const int slot = idx % ccap, rest = idx / ccap;
+                    const int q = rest % KBBQ_NQ, s = rest / KBBQ_NQ;
+                    const int c = (slot % (ccap >> 4)) * 16 + slot / (ccap >> 4);
+                    if (c < H.n_cycle) {
+                        atomicAdd(&H.cycle[cyc_index(H, lds_rg, q, s, c) + 1], (unsigned long long)cnt);
+                        if (cne) atomicAdd(&H.cycle[cyc_index(H, lds_rg, q, s, c)], (unsigned long long)cne);
+                    }
                 }
             }
             for (int w = threadIdx.x; w < KBBQ_NQ * 16; w += blockDim.x) {
-                const uint32_t v = l_di[w];
-                if (!v) continue;
-                l_di[w] = 0;
-                atomicAdd(&H.dinuc[((uint64_t)lds_rg * KBBQ_NQ * 16 + w) * 2 + 1], (unsigned long long)v);
+                const uint32_t v = l_di[w], ve = l_die[w];
+                if (v) { l_di[w] = 0; atomicAdd(&H.dinuc[((uint64_t)lds_rg * KBBQ_NQ * 16 + w) * 2 + 1], (unsigned long long)v); }
+                if (ve) { l_die[w] = 0; atomicAdd(&H.dinuc[((uint64_t)lds_rg * KBBQ_NQ * 16 + w) * 2], (unsigned long long)ve); }
             }
+            if (threadIdx.x == 0) *l_reads = 0;
             __syncthreads();
-            since_flush = 0;
         }
     }
 }
@@ -786,8 +853,8 @@ struct kbbq_engine {
     int8_t *d_dq_cycle = nullptr;
     int8_t *d_dq_dinuc = nullptr;
     // scratch
-    void *scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void *scratch[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long *d_counters = nullptr;   // [0] work-list length, [1] correction queries, [2] scan total
     std::vector<void *> staged;   // device copies of host batches, freed at the next sync
     uint64_t stats[4] = {0, 0, 0, 0};
@@ -1046,7 +1113,7 @@ void kbbq_engine_destroy(kbbq_engine *e) {
     hipFree(e->d_counters);
     hipFree(e->d_qcum);
     hipFree(e->d_errthr);
-    for (int i = 0; i < 8; ++i) hipFree(e->scratch[i]);
+    for (int i = 0; i < 10; ++i) hipFree(e->scratch[i]);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1216,8 +1283,8 @@ extern "C" {
 }  // extern "C"
 template <int NW> struct LaunchSample {
     static int go(kbbq_engine *e, ReadsDev R, const uint64_t *mask, const uint64_t *kofs) {
-        Timed t(e, "k_sample_insert");
-        hipLaunchKernelGGL(k_sample_insert<NW>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
+        Timed t(e, "k_insert_sampled");
+        hipLaunchKernelGGL((k_insert_marked<NW, false>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
                            e->filt[0].dev(), mask, kofs, e->filt[0].d_inserted);
         HIP_TRY(hipGetLastError());
         return KBBQ_OK;
@@ -1286,18 +1353,26 @@ int kbbq_set_thresholds(kbbq_engine *e, const int32_t *thresholds, int32_t n) {
 // ---- pass 2
 }  // extern "C"
 template <int NW> struct LaunchTrusted {
-    static int go(kbbq_engine *e, ReadsDev R, uint32_t *err_out) {
-        Timed t(e, "k_trusted");
+    static int go(kbbq_engine *e, ReadsDev R, uint32_t *take_bits, uint32_t *err_out) {
         Thresholds thr;
         memset(&thr, 0, sizeof thr);
         for (size_t i = 0; i < e->thresholds.size() && i <= KBBQ_MAX_KMER; ++i) thr.v[i] = e->thresholds[i];
-        hipLaunchKernelGGL(k_trusted<NW>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
-                           e->filt[0].dev(), e->filt[1].dev(), thr, e->filt[1].d_inserted, err_out);
-        HIP_TRY(hipGetLastError());
+        {
+            Timed t(e, "k_infer");
+            hipLaunchKernelGGL(k_infer<NW>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
+                               e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out);
+            HIP_TRY(hipGetLastError());
+        }
+        {
+            Timed t(e, "k_insert_trusted");
+            hipLaunchKernelGGL((k_insert_marked<NW, true>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
+                               e->filt[1].dev(), (const uint64_t *)take_bits, (const uint64_t *)nullptr,
+                               (unsigned long long *)nullptr);
+            HIP_TRY(hipGetLastError());
+        }
         return KBBQ_OK;
     }
 };
-
 extern "C" {
 
 static int bit_out_begin(kbbq_engine *e, const kbbq_reads *reads, uint64_t *user, int slot, uint32_t **dev) {
@@ -1329,7 +1404,15 @@ int kbbq_trusted_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *infer_
     if (rc) return rc;
     uint32_t *d_err;
     if ((rc = bit_out_begin(e, reads, infer_errors_out, 2, &d_err))) return rc;
-    if ((rc = dispatch_nw<LaunchTrusted>(max_len, e, R, d_err))) return rc;
+    // the insert decisions of k_infer: the caller's hint array when there is one (pass 3 then reuses
+    // them), a scratch bit array otherwise
+    uint32_t *take_bits = R.hint_trusted;
+    if (!take_bits) {
+        if ((rc = ensure_scratch(e, 8, (R.n_bases / 64 + 2) * 8))) return rc;
+        take_bits = (uint32_t *)e->scratch[8];
+        HIP_TRY(hipMemsetAsync(take_bits, 0, (R.n_bases / 64 + 2) * 8, e->stream));
+    }
+    if ((rc = dispatch_nw<LaunchTrusted>(max_len, e, R, take_bits, d_err))) return rc;
     return bit_out_end(e, reads, infer_errors_out, d_err);
 }
 
@@ -1397,8 +1480,8 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
     H.dinuc = e->d_hist + e->hist_cycle_words;
     H.n_rg = e->p.n_rg;
     H.n_cycle = e->p.max_read_len;
-    int ccap = std::min(((max_len + 31) / 32) * 32, 384);
-    const size_t lds = ((size_t)(2 * ccap * KBBQ_NQ + 1) / 2 + KBBQ_NQ * 16) * 4;
+    int ccap = std::min(((max_len + 31) / 32) * 32, 192);   // LDS: 2 tables x 2 x 94 x ccap x 2 B <= 141 KB
+    const size_t lds = (2 * ((size_t)(2 * ccap * KBBQ_NQ + 1) / 2) + 2 * KBBQ_NQ * 16 + 1) * 4;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         HIP_TRY(hipFuncSetAttribute((const void *)k_tally, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1406,8 +1489,10 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
     }
     Timed t(e, "k_tally");
     // 16 wavefronts share one LDS table: two blocks (32 waves) per CU at 150-base reads
-    const int blocks = (int)std::min<uint64_t>((R.n_reads + 15) / 16, 256 * 2);
-    hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(1024), lds, e->stream, R, H, err_bits, patch, ccap, 6);
+    const uint64_t groups = (R.n_bases + 15) / 16;
+    const int blocks = (int)std::min<uint64_t>((groups + 1023) / 1024, 256);
+    const int vec_ok = ((uintptr_t)R.qual & 15) == 0;
+    hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(1024), lds, e->stream, R, H, err_bits, patch, ccap, 6, vec_ok);
     HIP_TRY(hipGetLastError());
     return KBBQ_OK;
 }
@@ -1441,7 +1526,7 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
     if ((rc = dispatch_nw<LaunchScan>(max_len, e, R, tmask, dirty))) return rc;
     {
         Timed t(e, "k_compact");
-        hipLaunchKernelGGL(k_compact, dim3((unsigned)((R.n_reads + 255) / 256)), dim3(256), 0, e->stream, dirty, R.n_reads, list, &e->d_counters[0]);
+        hipLaunchKernelGGL(k_compact, dim3((unsigned)((R.n_reads + 1023) / 1024)), dim3(1024), 0, e->stream, dirty, R.n_reads, list, &e->d_counters[0]);
         HIP_TRY(hipGetLastError());
     }
     // one read per wavefront (correct_wave.h); the one-read-per-lane form (correct.h) serves k < 3
