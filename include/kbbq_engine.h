@@ -135,6 +135,9 @@ int kbbq_filter_or_from(kbbq_engine *e, int which, const void *src_device, uint6
 /* dst |= src for two arbitrary 16-byte-aligned device buffers of n_words u64
  * (reducing the pieces received in the OR all-reduce). */
 int kbbq_device_or(kbbq_engine *e, void *dst_device, const void *src_device, uint64_t n_words);
+/* dst |= OR over p != skip of src[p*piece_words .. (p+1)*piece_words): all received pieces in one launch. */
+int kbbq_device_or_pieces(kbbq_engine *e, void *dst_device, const void *src_device, uint64_t piece_words,
+                          int32_t n_pieces, int32_t skip);
 int kbbq_filter_set_inserted(kbbq_engine *e, int which, uint64_t inserted);
 
 /* ---- read staging ------------------------------------------------------ */

@@ -77,6 +77,7 @@ SYMBOLS = {
     "kbbq_filter_patterns_download": (ctypes.c_int, [c_vp, ctypes.c_int, c_u64p]),
     "kbbq_filter_or_from": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_u64, c_u64]),
     "kbbq_device_or": (ctypes.c_int, [c_vp, c_vp, c_vp, c_u64]),
+    "kbbq_device_or_pieces": (ctypes.c_int, [c_vp, c_vp, c_vp, c_u64, ctypes.c_int32, ctypes.c_int32]),
     "kbbq_filter_set_inserted": (ctypes.c_int, [c_vp, ctypes.c_int, c_u64]),
     "kbbq_pack_bases": (ctypes.c_int, [c_u8p, c_u64, c_u64p, c_u64p]),
     "kbbq_reads_upload": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads), ctypes.POINTER(Reads)]),

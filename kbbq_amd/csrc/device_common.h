@@ -117,6 +117,7 @@ template <bool INSERT, int LANES = 8>
 __device__ __forceinline__ bool bloom_coop(const FiltDev &f, bool active, uint32_t blk, uint32_t pat) {
     const int lane = threadIdx.x & 63;
     const unsigned long long live = __ballot(active);
+    const uint32_t pa = pat | ((uint32_t)active << 16);   // pattern index and the active flag travel in one shuffle
     bool contained = false;
     if constexpr (LANES == 8) {
         const int sub = lane & 7, grp = lane >> 3;
@@ -129,10 +130,10 @@ __device__ __forceinline__ bool bloom_coop(const FiltDev &f, bool active, uint32
             bb[j] = 0;
             if (((live >> (8 * j)) & 0xFFull) == 0) continue;   // wave-uniform: nobody owns a k-mer in this round
             const int src = j * 8 + grp;
-            const int a = __shfl((int)active, src);
             bb[j] = __shfl(blk, src);
-            const uint32_t p = __shfl(pat, src);
-            if (a) {
+            const uint32_t q = __shfl(pa, src);
+            const uint32_t p = q & 0xFFFFu;
+            if (q >> 16) {
                 pv[j] = f.patterns[(uint64_t)p * 8 + sub];
                 tv[j] = f.table[(uint64_t)bb[j] * 8 + sub];
             }
@@ -157,10 +158,10 @@ __device__ __forceinline__ bool bloom_coop(const FiltDev &f, bool active, uint32
             bb[j] = 0;
             if (((live >> (16 * j)) & 0xFFFFull) == 0) continue;
             const int src = j * 16 + grp;
-            const int a = __shfl((int)active, src);
             bb[j] = __shfl(blk, src);
-            const uint32_t p = __shfl(pat, src);
-            if (a) {
+            const uint32_t q = __shfl(pa, src);
+            const uint32_t p = q & 0xFFFFu;
+            if (q >> 16) {
                 pv[j] = *reinterpret_cast<const ulonglong2 *>(f.patterns + (uint64_t)p * 8 + sub * 2);
                 tv[j] = *reinterpret_cast<const ulonglong2 *>(f.table + (uint64_t)bb[j] * 8 + sub * 2);
             }

@@ -669,9 +669,24 @@ struct DqDev {
     int n_rg, n_cycle;
 };
 
-__global__ void __launch_bounds__(256) k_recalibrate(ReadsDev R, DqDev D, uint8_t *out, int minqual, int vec_ok) {
-    const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
-    if (g0 >= R.n_bases) return;
+__global__ void __launch_bounds__(256) k_recalibrate(ReadsDev R, DqDev D, uint8_t *out, int minqual, int vec_ok, int lds_rgs) {
+    // the delta-Q tables of the first `lds_rgs` read groups sit in LDS (a few tens of KB): 48 dependent
+    // table reads per lane then cost LDS, not L2, latency
+    extern __shared__ uint8_t l_tab[];
+    const int cyc_bytes = KBBQ_NQ * 2 * D.n_cycle, di_bytes = KBBQ_NQ * 16, base_bytes = KBBQ_NQ * 2;
+    const int per_rg = (cyc_bytes + di_bytes + base_bytes + 3) & ~3;
+    for (int i = threadIdx.x; i < lds_rgs * per_rg; i += blockDim.x) {
+        const int rg = i / per_rg, o = i % per_rg;
+        uint8_t v = 0;
+        if (o < cyc_bytes) v = (uint8_t)D.cycle[(size_t)rg * cyc_bytes + o];
+        else if (o < cyc_bytes + di_bytes) v = (uint8_t)D.dinuc[(size_t)rg * di_bytes + (o - cyc_bytes)];
+        else if (o < cyc_bytes + di_bytes + base_bytes) v = reinterpret_cast<const uint8_t *>(D.base)[(size_t)rg * base_bytes + (o - cyc_bytes - di_bytes)];
+        l_tab[i] = v;
+    }
+    __syncthreads();
+    // persistent blocks: the table load above is paid once per block, not once per 4 KB of qualities
+    for (uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; g0 < R.n_bases;
+         g0 += (uint64_t)gridDim.x * blockDim.x * 16) {
     // read containing g0
     uint64_t r, start, end;
     if (R.offsets) {
@@ -725,8 +740,15 @@ __global__ void __launch_bounds__(256) k_recalibrate(ReadsDev R, DqDev D, uint8_
         int v = q;
         if (i < n && q >= minqual && q < KBBQ_NQ && rg < D.n_rg && cyc < D.n_cycle) {
             const int cell = rg * KBBQ_NQ + q;
-            v = D.base[cell] + D.cycle[((uint64_t)cell * 2 + second) * D.n_cycle + cyc];
-            if (cyc > 0 && !nn && !prev_n) v += D.dinuc[cell * 16 + ((prev_b << 2) | b)];
+            const bool use_di = cyc > 0 && !nn && !prev_n;
+            if (rg < lds_rgs) {
+                const uint8_t *t = l_tab + rg * per_rg;
+                v = *reinterpret_cast<const int16_t *>(t + cyc_bytes + di_bytes + 2 * q) + (int8_t)t[(q * 2 + second) * D.n_cycle + cyc];
+                if (use_di) v += (int8_t)t[cyc_bytes + q * 16 + ((prev_b << 2) | b)];
+            } else {
+                v = D.base[cell] + D.cycle[((uint64_t)cell * 2 + second) * D.n_cycle + cyc];
+                if (use_di) v += D.dinuc[cell * 16 + ((prev_b << 2) | b)];
+            }
         }
         res[i] = (uint8_t)(v < 0 ? 0 : (v > KBBQ_MAXQ ? KBBQ_MAXQ : v));
         prev_b = b;
@@ -738,6 +760,7 @@ __global__ void __launch_bounds__(256) k_recalibrate(ReadsDev R, DqDev D, uint8_
         *reinterpret_cast<uint4 *>(out + g0) = v;
     } else {
         for (int i = 0; i < n; ++i) out[g0 + i] = res[i];
+    }
     }
 }
 
@@ -751,6 +774,27 @@ __global__ void k_or_words(uint64_t *dst, const uint64_t *src, uint64_t n) {
         *reinterpret_cast<ulonglong2 *>(dst + i) = a;
     } else if (i < n) {
         dst[i] |= src[i];
+    }
+}
+
+// dst |= OR of n_pieces consecutive pieces of `src` (each piece_words long), skipping piece `skip`:
+// the reduce step of the OR all-reduce in one launch
+__global__ void k_or_pieces(uint64_t *dst, const uint64_t *src, uint64_t piece_words, int n_pieces, int skip) {
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i >= piece_words) return;
+    if (i + 1 < piece_words) {
+        ulonglong2 a = *reinterpret_cast<ulonglong2 *>(dst + i);
+        for (int p = 0; p < n_pieces; ++p) {
+            if (p == skip) continue;
+            const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(src + (uint64_t)p * piece_words + i);
+            a.x |= b.x; a.y |= b.y;
+        }
+        *reinterpret_cast<ulonglong2 *>(dst + i) = a;
+    } else {
+        uint64_t a = dst[i];
+        for (int p = 0; p < n_pieces; ++p)
+            if (p != skip) a |= src[(uint64_t)p * piece_words + i];
+        dst[i] = a;
     }
 }
 
@@ -1193,6 +1237,19 @@ int kbbq_device_or(kbbq_engine *e, void *dst_device, const void *src_device, uin
     Timed t(e, "k_or_words");
     hipLaunchKernelGGL(k_or_words, dim3((unsigned)((n_words / 2 + 256) / 256)), dim3(256), 0, e->stream,
                        (uint64_t *)dst_device, (const uint64_t *)src_device, n_words);
+    HIP_TRY(hipGetLastError());
+    return KBBQ_OK;
+}
+
+int kbbq_device_or_pieces(kbbq_engine *e, void *dst_device, const void *src_device, uint64_t piece_words,
+                          int32_t n_pieces, int32_t skip) {
+    if (!e || !dst_device || !src_device || n_pieces < 1) return fail(KBBQ_EINVAL, "bad argument");
+    if ((((uintptr_t)dst_device | (uintptr_t)src_device) & 15) || (piece_words & 1))
+        return fail(KBBQ_EINVAL, "buffers must be 16-byte aligned and pieces an even number of words");
+    if (!piece_words) return KBBQ_OK;
+    Timed t(e, "k_or_pieces");
+    hipLaunchKernelGGL(k_or_pieces, dim3((unsigned)((piece_words / 2 + 255) / 256)), dim3(256), 0, e->stream,
+                       (uint64_t *)dst_device, (const uint64_t *)src_device, piece_words, n_pieces, skip);
     HIP_TRY(hipGetLastError());
     return KBBQ_OK;
 }
@@ -1661,7 +1718,11 @@ int kbbq_recalibrate_batch(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qua
         Timed t(e, "k_recalibrate");
         const uint64_t lanes = (R.n_bases + 15) / 16;
         const int vec_ok = (((uintptr_t)R.qual | (uintptr_t)d_out) & 15) == 0;
-        hipLaunchKernelGGL(k_recalibrate, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, e->stream, R, D, d_out, 6, vec_ok);
+        const int per_rg = (KBBQ_NQ * 2 * D.n_cycle + KBBQ_NQ * 16 + KBBQ_NQ * 2 + 3) & ~3;
+        const int lds_rgs = std::max(0, std::min(D.n_rg, (48 * 1024) / per_rg));   // keep >= 3 blocks per CU
+        const unsigned blocks = (unsigned)std::min<uint64_t>((lanes + 255) / 256, 256 * 4);
+        hipLaunchKernelGGL(k_recalibrate, dim3(blocks), dim3(256), (size_t)lds_rgs * per_rg, e->stream,
+                           R, D, d_out, 6, vec_ok, lds_rgs);
         HIP_TRY(hipGetLastError());
     }
     if (!reads->on_device) {

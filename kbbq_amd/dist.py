@@ -31,11 +31,12 @@ def world(group=None):
     return dist.get_rank(group), dist.get_world_size(group)
 
 
-def or_allreduce_(t, or_into, slab_words=1 << 27, group=None):
+def or_allreduce_(t, or_into, slab_words=1 << 27, group=None, or_pieces=None):
     """In-place bitwise-OR all-reduce of a 1-D int64 tensor.
 
     or_into(dst, src): dst |= src for two equally long int64 tensors (the HIP
-    kernel on a GPU, tensor.bitwise_or_ on the CPU).
+    kernel on a GPU, tensor.bitwise_or_ on the CPU).  or_pieces(dst, recv, piece, n, skip), when
+    given, ORs all n-1 foreign pieces of `recv` into dst in one launch.
     """
     rank, n = world(group)
     if n == 1:
@@ -60,9 +61,12 @@ def or_allreduce_(t, or_into, slab_words=1 << 27, group=None):
             view = pad
         dist.all_to_all_single(recv, view, group=group)
         mine.copy_(recv[rank * piece:(rank + 1) * piece])
-        for j in range(n):
-            if j != rank:
-                or_into(mine, recv[j * piece:(j + 1) * piece])
+        if or_pieces is not None:
+            or_pieces(mine, recv, piece, n, rank)
+        else:
+            for j in range(n):
+                if j != rank:
+                    or_into(mine, recv[j * piece:(j + 1) * piece])
         dist.all_gather_into_tensor(view, mine, group=group)
         if ln != slab:
             t[s:s + ln].copy_(pad[:ln])
@@ -107,7 +111,8 @@ class Exchange:
         if self.n == 1:
             return local
         self.peer.quiesce()
-        or_allreduce_(self.peer.table_tensor(which), self.peer.or_into, self.slab_words, self.group)
+        or_allreduce_(self.peer.table_tensor(which), self.peer.or_into, self.slab_words, self.group,
+                      getattr(self.peer, "or_pieces", None))
         cnt = torch.tensor([local], dtype=torch.int64, device=self.device)
         sum_allreduce_(cnt, self.group)
         total = int(cnt.item())
@@ -169,6 +174,12 @@ class EnginePeer:
         from . import _lib
         torch.cuda.synchronize()
         _lib.check(self.e.L.kbbq_device_or(self.e.h, dst.data_ptr(), src.data_ptr(), dst.numel()))
+        self.e.sync()
+
+    def or_pieces(self, dst, recv, piece, n, skip):
+        from . import _lib
+        torch.cuda.synchronize()
+        _lib.check(self.e.L.kbbq_device_or_pieces(self.e.h, dst.data_ptr(), recv.data_ptr(), piece, n, skip))
         self.e.sync()
 
     def get_inserted(self, which):

@@ -166,6 +166,49 @@ def test_hint_arrays_do_not_change_results():
     e.close()
 
 
+def test_or_kernels_of_the_exchange_step():
+    """kbbq_device_or / kbbq_device_or_pieces / kbbq_filter_or_from: the reduce step of the OR all-reduce."""
+    import torch
+    e = Engine(32, 0.35, 1, 100000)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    n, pieces = 4098, 5
+    recv = torch.randint(-2 ** 62, 2 ** 62, (pieces * n,), dtype=torch.int64, generator=g).cuda()
+    mine = recv[2 * n:3 * n].clone()
+    want = recv.view(pieces, n)[0].clone()
+    for p in range(1, pieces):
+        want |= recv.view(pieces, n)[p]
+    torch.cuda.synchronize()
+    _lib.check(e.L.kbbq_device_or_pieces(e.h, mine.data_ptr(), recv.data_ptr(), n, pieces, 2))
+    e.sync()
+    assert torch.equal(mine, want)
+    a = recv[:n].clone()
+    torch.cuda.synchronize()
+    _lib.check(e.L.kbbq_device_or(e.h, a.data_ptr(), recv[n:2 * n].data_ptr(), n))
+    e.sync()
+    assert torch.equal(a, recv[:n] | recv[n:2 * n])
+    # into the filter itself
+    info = e.filter_info(0)
+    words = info["n_blocks"] * 8
+    src = torch.randint(0, 2 ** 62, (words,), dtype=torch.int64, generator=g).cuda()
+    torch.cuda.synchronize()
+    _lib.check(e.L.kbbq_filter_or_from(e.h, 0, src.data_ptr(), 0, words))
+    assert np.array_equal(e.filter_table(0), src.cpu().numpy().view(np.uint64))
+    e.close()
+
+
+def test_single_rank_exchange_is_a_no_op():
+    from kbbq_amd.dist import EnginePeer, Exchange
+    d = common.make_dataset(seed=8, genome_len=6000, coverage=20)
+    alpha_ld, cov, approx = common.plan_parameters(d["genome_len"], d["coverage"], None)
+    e = Engine(32, alpha_ld, 777, approx, max_read_len=150)
+    b = ReadBatch(d["seq"], d["qual"], d["off"], uniform=True)
+    e.subsample_kmers(b, 0)
+    n = e.sample_finish()
+    x = Exchange(EnginePeer(e))
+    assert x.filter_done(0) == n
+    e.close()
+
+
 def test_fixed_mode_tally_matches_oracle():
     # --fixed (kbbq.cc:367-378): caller-supplied error flags feed the tally directly
     d = common.make_dataset(seed=77, genome_len=8000, coverage=15, n_rg=2, paired=True)
