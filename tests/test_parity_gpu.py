@@ -166,6 +166,15 @@ def test_hint_arrays_do_not_change_results():
     e.close()
 
 
+def test_device_pattern_tables_equal_the_oracle():
+    from oracle import pyoracle
+    e = Engine(32, 0.35, 1, 700000)
+    o = pyoracle.Oracle(32, 0.35, 1, 700000)
+    for which in (0, 1):
+        assert np.array_equal(e.filter_patterns(which), o.filter_patterns(which))
+    e.close()
+
+
 def test_or_kernels_of_the_exchange_step():
     """kbbq_device_or / kbbq_device_or_pieces / kbbq_filter_or_from: the reduce step of the OR all-reduce."""
     import torch
