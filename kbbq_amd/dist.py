@@ -31,7 +31,7 @@ def world(group=None):
     return dist.get_rank(group), dist.get_world_size(group)
 
 
-def or_allreduce_(t, or_into, slab_words=1 << 27, group=None, or_pieces=None):
+def or_allreduce_(t, or_into, slab_words=1 << 27, group=None, or_pieces=None, force=False):
     """In-place bitwise-OR all-reduce of a 1-D int64 tensor.
 
     or_into(dst, src): dst |= src for two equally long int64 tensors (the HIP
@@ -39,7 +39,7 @@ def or_allreduce_(t, or_into, slab_words=1 << 27, group=None, or_pieces=None):
     given, ORs all n-1 foreign pieces of `recv` into dst in one launch.
     """
     rank, n = world(group)
-    if n == 1:
+    if n == 1 and not force:      # force: run the collectives anyway (single-rank plumbing check)
         return t
     assert t.dim() == 1 and t.dtype == torch.int64 and t.is_contiguous()
     total = t.numel()
@@ -74,8 +74,7 @@ def or_allreduce_(t, or_into, slab_words=1 << 27, group=None, or_pieces=None):
 
 
 def sum_allreduce_(t, group=None):
-    _, n = world(group)
-    if n > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
@@ -98,21 +97,22 @@ class Exchange:
     aliasing the tallied histograms, train() -> dict of int32 arrays, set_dq(dict), quiesce().
     """
 
-    def __init__(self, peer, group=None, slab_words=1 << 27, device=None):
+    def __init__(self, peer, group=None, slab_words=1 << 27, device=None, force=False):
         self.peer = peer
         self.group = group
         self.slab_words = slab_words
         self.rank, self.n = world(group)
         self.device = device
+        self.force = force and dist.is_initialized()   # run the collectives even with one rank
 
     def filter_done(self, which):
         """After pass 1 (which=0) or pass 2 (which=1): make filter and counter global."""
         local = self.peer.get_inserted(which)
-        if self.n == 1:
+        if self.n == 1 and not self.force:
             return local
         self.peer.quiesce()
         or_allreduce_(self.peer.table_tensor(which), self.peer.or_into, self.slab_words, self.group,
-                      getattr(self.peer, "or_pieces", None))
+                      getattr(self.peer, "or_pieces", None), force=self.force)
         cnt = torch.tensor([local], dtype=torch.int64, device=self.device)
         sum_allreduce_(cnt, self.group)
         total = int(cnt.item())
@@ -121,7 +121,7 @@ class Exchange:
         return total
 
     def histograms_done(self):
-        if self.n == 1:
+        if self.n == 1 and not self.force:
             return
         self.peer.quiesce()
         sum_allreduce_(self.peer.hist_tensor(), self.group)
@@ -130,7 +130,7 @@ class Exchange:
     def train_and_share(self):
         """Rank 0 trains (host, long double), the int32 tables are broadcast and installed everywhere."""
         keys = ("meanq", "rg", "q", "cycle", "dinuc")
-        if self.n == 1:
+        if self.n == 1 and not self.force:
             return self.peer.train()
         if self.rank == 0:
             dq = self.peer.train()

@@ -205,6 +205,52 @@ def test_or_kernels_of_the_exchange_step():
     e.close()
 
 
+def test_exchange_steps_over_rccl_with_one_rank():
+    """The N > 1 plumbing on real RCCL, as far as one GPU allows: a one-rank `nccl` group with the
+    collectives forced on (all_to_all / all_gather / all_reduce / broadcast over the engine's own device
+    memory viewed as tensors) must leave every result unchanged.  Multi-rank equality is proven on the
+    CPU in tests/test_dist_cpu.py."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+sys.path.insert(0, "tests")
+import numpy as np, torch, torch.distributed as dist
+import common
+from kbbq_amd.dist import EnginePeer, Exchange
+from kbbq_amd.engine import Engine
+from kbbq_amd.reads import ReadBatch
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29733", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+d = common.make_dataset(seed=8, genome_len=12000, coverage=20, n_rg=2, paired=True, extra_errors=50)
+ref = common.run_engine(d, n_rg=2, uniform=True)
+alpha_ld, cov, approx = common.plan_parameters(d["genome_len"], d["coverage"], None)
+e = Engine(32, alpha_ld, 777, approx, n_rg=2, max_read_len=150)
+x = Exchange(EnginePeer(e), slab_words=1 << 14, device=torch.device("cuda", 0), force=True)
+b = e.upload(ReadBatch(d["seq"], d["qual"], d["off"], d["rg"], d["second"], uniform=True))
+e.subsample_kmers(b, 0); e.sample_finish()
+assert x.filter_done(0) == ref["sampled_inserted"]
+assert np.array_equal(e.filter_table(0), ref["sampled_table"])
+e.compute_thresholds()
+e.find_trusted_kmers(b); e.trusted_finish()
+assert x.filter_done(1) == ref["trusted_inserted"]
+assert np.array_equal(e.filter_table(1), ref["trusted_table"])
+e.get_covariatedata(b)
+x.histograms_done()
+dq = x.train_and_share()
+assert np.array_equal(dq["cycle"], ref["dq"]["cycle"]) and np.array_equal(dq["q"], ref["dq"]["q"])
+out = torch.zeros(b.n_bases + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+e.recalibrate(b, out.data_ptr()); e.sync()
+assert np.array_equal(out.cpu().numpy()[:b.n_bases], ref["recal"])
+dist.destroy_process_group()
+print("rccl one-rank exchange ok")
+'''
+    out = subprocess.run([sys.executable, "-c", code], cwd=common.ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "rccl one-rank exchange ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
 def test_single_rank_exchange_is_a_no_op():
     from kbbq_amd.dist import EnginePeer, Exchange
     d = common.make_dataset(seed=8, genome_len=6000, coverage=20)
