@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkbbq_engine.so")
+# KBBQ_LIB: load another build of the same library (A/B experiments with kernel variants)
+LIB_PATH = os.environ.get("KBBQ_LIB") or os.path.join(_HERE, "libkbbq_engine.so")
 
 c_u8p = ctypes.POINTER(ctypes.c_uint8)
 c_u16p = ctypes.POINTER(ctypes.c_uint16)
