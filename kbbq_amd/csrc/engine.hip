@@ -327,12 +327,12 @@ __global__ void __launch_bounds__(256) k_scan_trusted(ReadsDev R, KParams K, Fil
 }
 
 __global__ void __launch_bounds__(1024) k_compact(const uint8_t *dirty, uint64_t n, uint32_t *list,
-                                                   unsigned long long *count) {
+                                                   unsigned long long *count, int only_one) {
     // one global atomic per 1024-lane block: wave counts -> LDS scan -> block base
     __shared__ unsigned int wave_cnt[16];
     __shared__ unsigned long long block_base;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool d = i < n && dirty[i];
+    const bool d = i < n && (only_one ? dirty[i] == 1 : dirty[i] != 0);
     const unsigned long long bal = __ballot(d);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) wave_cnt[w] = (unsigned int)__popcll(bal);
@@ -344,6 +344,108 @@ __global__ void __launch_bounds__(1024) k_compact(const uint8_t *dirty, uint64_t
     }
     __syncthreads();
     if (d) list[block_base + wave_cnt[w] + __popcll(bal & ((1ULL << lane) - 1))] = (uint32_t)i;
+}
+
+// ---- pass 3a': the isolated-error fast path ------------------------------------------
+// More than half of the reads that need work carry ONE isolated error: their trusted mask has a
+// single run of untrusted k-mers, exactly the k-mers that cover one base p.  For such a read
+// get_errors (readutils.cc:238-570) reduces to: the anchor is the longer trusted side; if exactly
+// one alternative base at p makes every covering k-mer trusted, find_longest_fix returns it alone
+// with the longest walk, the walk then runs to the read end, one flag is set (so the over-correction
+// window cannot fire), nothing is left for the recursion -- errors = {p}.  This kernel decides that
+// with two small cooperative lookups per read and marks the read done (dirty = 2); every other
+// read (no or several full alternatives, any other mask shape) stays for k_correct_wave.
+template <int NW>
+__global__ void __launch_bounds__(256) k_fix_single(ReadsDev R, KParams K, FiltDev T, const uint32_t *list,
+                                                     const unsigned long long *n_list, const uint64_t *tmask,
+                                                     uint32_t *err_bits, uint8_t *dirty, unsigned long long *stats) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t n = *n_list;
+    const int k = K.k;
+    unsigned long long q_total = 0;
+    for (uint64_t slot = wave; slot < n; slot += n_waves) {
+        const uint64_t r = list[slot];
+        uint64_t off; uint32_t len32;
+        read_span(R, r, off, len32);
+        const int len = (int)len32, nk = len - k + 1;
+        // the run of untrusted k-mer starts
+        int zeros = 0, z0 = -1, z1 = -1;
+#pragma unroll
+        for (int c = 0; c < NW; ++c) {
+            if (c * 64 < nk) {
+                const int rem = nk - c * 64;
+                const uint64_t in = rem >= 64 ? ~0ULL : ((1ULL << rem) - 1);
+                const uint64_t z = ~tmask[r * NW + c] & in;
+                if (z) {
+                    if (z0 < 0) z0 = c * 64 + __ffsll((unsigned long long)z) - 1;
+                    z1 = c * 64 + 63 - __clzll((long long)z);
+                    zeros += __popcll(z);
+                }
+            }
+        }
+        bool eligible = zeros > 0 && zeros < nk && zeros == z1 - z0 + 1 && zeros <= k;
+        int p = 0;
+        if (eligible) {
+            p = z0 > 0 ? z0 + k - 1 : z1;
+            // the run must be exactly the in-range starts that cover p
+            eligible = z0 == max(0, p - k + 1) && z1 == min(p, nk - 1);
+        }
+        int full = 0, full_y = 0;
+        if (eligible) {
+            const uint64_t gp = off + p;
+            const int cur = ((R.nmask[gp >> 6] >> (gp & 63)) & 1) ? 4 : (int)((R.bases[gp >> 5] >> ((gp & 31) * 2)) & 3);
+            // k-mer starting at st with base p := y
+            auto key_of = [&](int st, int y, bool &valid) -> uint64_t {
+                uint64_t w = window64(R.bases, 2 * (off + st));
+                uint32_t nm = (uint32_t)window64(R.nmask, off + st) & K.nmask_bits;
+                const int j = p - st;
+                w = (w & ~(3ULL << (2 * j))) | ((uint64_t)y << (2 * j));
+                nm &= ~(1u << j);
+                valid = nm == 0;
+                const uint64_t rc = (~w) & K.mask, fw = rev2(w) >> (64 - 2 * k);
+                return fw < rc ? fw : rc;
+            };
+            // round 1: one covering k-mer per alternative
+            int alive;
+            {
+                const int y = lane & 3;
+                const bool act = lane < 4 && y != cur;
+                bool valid = false;
+                const uint64_t key = key_of(z0, y, valid);
+                const bool go = act && valid;
+                q_total += __popcll(__ballot(go));
+                const bool t = bloom_coop<false>(T, go, block_of(T, key), pattern_of(T, key)) && go;
+                alive = (int)(__ballot(t) & 0xF);
+            }
+            // round 2: every covering k-mer of the survivors, two alternatives per lookup
+            while (alive) {
+                const int ya = __ffs(alive) - 1;
+                alive &= alive - 1;
+                int yb = -1;
+                if (alive) { yb = __ffs(alive) - 1; alive &= alive - 1; }
+                const int y = (lane >> 5) ? yb : ya;
+                const int st = z0 + (lane & 31);
+                const bool act = y >= 0 && st <= z1;
+                bool valid = false;
+                const uint64_t key = key_of(act ? st : z0, y < 0 ? 0 : y, valid);
+                const bool go = act && valid;
+                q_total += __popcll(__ballot(go));
+                const bool t = bloom_coop<false>(T, go, block_of(T, key), pattern_of(T, key)) && go;
+                const unsigned long long bal = __ballot(t);
+                if (__popcll(bal & 0xFFFFFFFFULL) == zeros) { ++full; full_y = ya; }
+                if (yb >= 0 && __popcll(bal >> 32) == zeros) { ++full; full_y = yb; }
+            }
+        }
+        (void)full_y;
+        if (full == 1 && lane == 0) {
+            const uint64_t g = off + p;
+            atomicOr(&err_bits[g >> 5], 1u << (g & 31));
+            dirty[r] = 2;
+        }
+    }
+    if (lane == 0 && q_total) atomicAdd(&stats[1], q_total);
 }
 
 // ---- pass 3b: the correction walk, one read per lane ---------------------------
@@ -1483,6 +1585,15 @@ int kbbq_trusted_finish(kbbq_engine *e, uint64_t *inserted) {
 
 // ---- pass 3
 }  // extern "C"
+template <int NW> struct LaunchFixSingle {
+    static int go(kbbq_engine *e, ReadsDev R, const uint32_t *list, const uint64_t *tmask, uint32_t *err_bits, uint8_t *dirty) {
+        Timed t(e, "k_fix_single");
+        hipLaunchKernelGGL(k_fix_single<NW>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K, e->filt[1].dev(),
+                           list, (const unsigned long long *)&e->d_counters[0], tmask, err_bits, dirty, e->d_counters);
+        HIP_TRY(hipGetLastError());
+        return KBBQ_OK;
+    }
+};
 template <int NW> struct LaunchScan {
     static int go(kbbq_engine *e, ReadsDev R, uint64_t *tmask, uint8_t *dirty) {
         Timed t(e, "k_scan_trusted");
@@ -1583,7 +1694,16 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
     if ((rc = dispatch_nw<LaunchScan>(max_len, e, R, tmask, dirty))) return rc;
     {
         Timed t(e, "k_compact");
-        hipLaunchKernelGGL(k_compact, dim3((unsigned)((R.n_reads + 1023) / 1024)), dim3(1024), 0, e->stream, dirty, R.n_reads, list, &e->d_counters[0]);
+        hipLaunchKernelGGL(k_compact, dim3((unsigned)((R.n_reads + 1023) / 1024)), dim3(1024), 0, e->stream, dirty, R.n_reads, list, &e->d_counters[0], 0);
+        HIP_TRY(hipGetLastError());
+    }
+    // isolated single errors are settled by the fast path; the walk gets what is left
+    static const bool no_fast = getenv("KBBQ_NO_FASTPATH") != nullptr;
+    if (!no_fast && e->p.k >= 3) {
+        if ((rc = dispatch_nw<LaunchFixSingle>(max_len, e, R, (const uint32_t *)list, (const uint64_t *)tmask, d_err, dirty))) return rc;
+        HIP_TRY(hipMemsetAsync(&e->d_counters[0], 0, 8, e->stream));
+        Timed t(e, "k_compact");
+        hipLaunchKernelGGL(k_compact, dim3((unsigned)((R.n_reads + 1023) / 1024)), dim3(1024), 0, e->stream, dirty, R.n_reads, list, &e->d_counters[0], 1);
         HIP_TRY(hipGetLastError());
     }
     // one read per wavefront (correct_wave.h); the one-read-per-lane form (correct.h) serves k < 3
