@@ -347,18 +347,21 @@ __global__ void __launch_bounds__(1024) k_compact(const uint8_t *dirty, uint64_t
 }
 
 // ---- pass 3a': the isolated-error fast path ------------------------------------------
-// More than half of the reads that need work carry ONE isolated error: their trusted mask has a
-// single run of untrusted k-mers, exactly the k-mers that cover one base p.  For such a read
-// get_errors (readutils.cc:238-570) reduces to: the anchor is the longer trusted side; if exactly
-// one alternative base at p makes every covering k-mer trusted, find_longest_fix returns it alone
-// with the longest walk, the walk then runs to the read end, one flag is set (so the over-correction
-// window cannot fire), nothing is left for the recursion -- errors = {p}.  This kernel decides that
-// with two small cooperative lookups per read and marks the read done (dirty = 2); every other
-// read (no or several full alternatives, any other mask shape) stays for k_correct_wave.
+// Most reads that need work carry a few ISOLATED errors: their trusted mask has up to four separate
+// runs of untrusted k-mers, each run being exactly the k-mers that cover one base p.  For such a
+// read get_errors (readutils.cc:238-570) reduces to: the anchor is the longest trusted run; walking
+// away from it, find_longest_fix meets the errors one at a time; if exactly one alternative base at
+// p makes every k-mer covering p trusted, that alternative alone has the longest walk, it is
+// applied, and the walk continues through the trusted k-mers to the next run (or the read end).  At
+// most four flags are set, so the over-correction window cannot fire and nothing is left for the
+// recursion: errors = {p1..pm}.  This kernel decides that with two small cooperative lookups per
+// read and marks the read done (dirty = 2); if any run has no or several full alternatives, or the
+// mask has any other shape, the read stays untouched for k_correct_wave.
 template <int NW>
 __global__ void __launch_bounds__(256) k_fix_single(ReadsDev R, KParams K, FiltDev T, const uint32_t *list,
                                                      const unsigned long long *n_list, const uint64_t *tmask,
                                                      uint32_t *err_bits, uint8_t *dirty, unsigned long long *stats) {
+    constexpr int MAXRUN = 4;
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -370,34 +373,51 @@ __global__ void __launch_bounds__(256) k_fix_single(ReadsDev R, KParams K, FiltD
         uint64_t off; uint32_t len32;
         read_span(R, r, off, len32);
         const int len = (int)len32, nk = len - k + 1;
-        // the run of untrusted k-mer starts
-        int zeros = 0, z0 = -1, z1 = -1;
+        // runs of untrusted k-mer starts: z = complement of the trusted mask inside [0, nk)
+        uint64_t Z[NW];
+        int zeros = 0;
 #pragma unroll
         for (int c = 0; c < NW; ++c) {
+            Z[c] = 0;
             if (c * 64 < nk) {
                 const int rem = nk - c * 64;
-                const uint64_t in = rem >= 64 ? ~0ULL : ((1ULL << rem) - 1);
-                const uint64_t z = ~tmask[r * NW + c] & in;
-                if (z) {
-                    if (z0 < 0) z0 = c * 64 + __ffsll((unsigned long long)z) - 1;
-                    z1 = c * 64 + 63 - __clzll((long long)z);
-                    zeros += __popcll(z);
-                }
+                Z[c] = ~tmask[r * NW + c] & (rem >= 64 ? ~0ULL : ((1ULL << rem) - 1));
+                zeros += __popcll(Z[c]);
             }
         }
-        bool eligible = zeros > 0 && zeros < nk && zeros == z1 - z0 + 1 && zeros <= k;
-        int p = 0;
-        if (eligible) {
-            p = z0 > 0 ? z0 + k - 1 : z1;
+        auto next_bit = [&](int from, bool one) -> int {      // first index >= from with Z bit == one, nk if none
+            while (from < nk) {
+                uint64_t x = sel_word<NW>(Z, from >> 6);
+                if (!one) x = ~x;
+                x >>= (from & 63);
+                if (x) { const int q = from + __ffsll((unsigned long long)x) - 1; return q < nk ? q : nk; }
+                from = ((from >> 6) + 1) << 6;
+            }
+            return nk;
+        };
+        int m = 0, z0s[MAXRUN], z1s[MAXRUN], ps[MAXRUN];
+        bool eligible = zeros > 0 && zeros < nk;
+        for (int pos = next_bit(0, true); eligible && pos < nk;) {
+            const int z0 = pos, z1 = next_bit(pos, false) - 1;
+            if (m == MAXRUN || z1 - z0 + 1 > k) { eligible = false; break; }
+            const int p = z0 > 0 ? z0 + k - 1 : z1;
             // the run must be exactly the in-range starts that cover p
-            eligible = z0 == max(0, p - k + 1) && z1 == min(p, nk - 1);
+            if (!(z0 == max(0, p - k + 1) && z1 == min(p, nk - 1))) { eligible = false; break; }
+#pragma unroll
+            for (int q = 0; q < MAXRUN; ++q) if (q == m) { z0s[q] = z0; z1s[q] = z1; ps[q] = p; }
+            ++m;
+            pos = next_bit(z1 + 1, true);
         }
-        int full = 0, full_y = 0;
+        int singles = 0;   // runs with exactly one full alternative
         if (eligible) {
-            const uint64_t gp = off + p;
-            const int cur = ((R.nmask[gp >> 6] >> (gp & 63)) & 1) ? 4 : (int)((R.bases[gp >> 5] >> ((gp & 31) * 2)) & 3);
+            auto pick = [&](const int (&a)[MAXRUN], int idx) -> int {
+                int v = a[0];
+#pragma unroll
+                for (int q = 1; q < MAXRUN; ++q) v = (idx == q) ? a[q] : v;
+                return v;
+            };
             // k-mer starting at st with base p := y
-            auto key_of = [&](int st, int y, bool &valid) -> uint64_t {
+            auto key_of = [&](int st, int p, int y, bool &valid) -> uint64_t {
                 uint64_t w = window64(R.bases, 2 * (off + st));
                 uint32_t nm = (uint32_t)window64(R.nmask, off + st) & K.nmask_bits;
                 const int j = p - st;
@@ -407,42 +427,57 @@ __global__ void __launch_bounds__(256) k_fix_single(ReadsDev R, KParams K, FiltD
                 const uint64_t rc = (~w) & K.mask, fw = rev2(w) >> (64 - 2 * k);
                 return fw < rc ? fw : rc;
             };
-            // round 1: one covering k-mer per alternative
+            // round 1: one covering k-mer per (run, alternative): lane 4*run + y
             int alive;
             {
-                const int y = lane & 3;
-                const bool act = lane < 4 && y != cur;
+                const int run = lane >> 2, y = lane & 3;
+                bool act = lane < 4 * m;
+                int p = 0, st = 0;
+                if (act) {
+                    p = pick(ps, run);
+                    st = pick(z0s, run);
+                    const uint64_t gp = off + p;
+                    const int cur = ((R.nmask[gp >> 6] >> (gp & 63)) & 1) ? 4 : (int)((R.bases[gp >> 5] >> ((gp & 31) * 2)) & 3);
+                    act = y != cur;
+                }
                 bool valid = false;
-                const uint64_t key = key_of(z0, y, valid);
+                const uint64_t key = key_of(st, p, y, valid);
                 const bool go = act && valid;
                 q_total += __popcll(__ballot(go));
                 const bool t = bloom_coop<false>(T, go, block_of(T, key), pattern_of(T, key)) && go;
-                alive = (int)(__ballot(t) & 0xF);
+                alive = (int)(__ballot(t) & 0xFFFF);
             }
-            // round 2: every covering k-mer of the survivors, two alternatives per lookup
+            // round 2: every covering k-mer of the survivors, two (run, alternative) pairs per lookup
+            int full = 0;   // 3 bits per run: number of alternatives whose covering k-mers are all trusted
             while (alive) {
-                const int ya = __ffs(alive) - 1;
+                const int a = __ffs(alive) - 1;
                 alive &= alive - 1;
-                int yb = -1;
-                if (alive) { yb = __ffs(alive) - 1; alive &= alive - 1; }
-                const int y = (lane >> 5) ? yb : ya;
+                int b = -1;
+                if (alive) { b = __ffs(alive) - 1; alive &= alive - 1; }
+                const int mine = (lane >> 5) ? b : a;
+                const int run = mine >= 0 ? mine >> 2 : 0, y = mine >= 0 ? (mine & 3) : 0;
+                const int z0 = pick(z0s, run), z1 = pick(z1s, run), p = pick(ps, run);
                 const int st = z0 + (lane & 31);
-                const bool act = y >= 0 && st <= z1;
+                const bool act = mine >= 0 && st <= z1;
                 bool valid = false;
-                const uint64_t key = key_of(act ? st : z0, y < 0 ? 0 : y, valid);
+                const uint64_t key = key_of(act ? st : z0, p, y, valid);
                 const bool go = act && valid;
                 q_total += __popcll(__ballot(go));
                 const bool t = bloom_coop<false>(T, go, block_of(T, key), pattern_of(T, key)) && go;
                 const unsigned long long bal = __ballot(t);
-                if (__popcll(bal & 0xFFFFFFFFULL) == zeros) { ++full; full_y = ya; }
-                if (yb >= 0 && __popcll(bal >> 32) == zeros) { ++full; full_y = yb; }
+                const int ra = a >> 2;
+                if (__popcll(bal & 0xFFFFFFFFULL) == pick(z1s, ra) - pick(z0s, ra) + 1) full += 1 << (3 * ra);
+                if (b >= 0) {
+                    const int rb = b >> 2;
+                    if (__popcll(bal >> 32) == pick(z1s, rb) - pick(z0s, rb) + 1) full += 1 << (3 * rb);
+                }
             }
+            for (int q = 0; q < m; ++q) singles += ((full >> (3 * q)) & 7) == 1 ? 1 : 0;
         }
-        (void)full_y;
-        if (full == 1 && lane == 0) {
-            const uint64_t g = off + p;
+        if (eligible && singles == m && lane < m) {
+            const uint64_t g = off + (lane == 0 ? ps[0] : lane == 1 ? ps[1] : lane == 2 ? ps[2] : ps[3]);
             atomicOr(&err_bits[g >> 5], 1u << (g & 31));
-            dirty[r] = 2;
+            if (lane == 0) dirty[r] = 2;
         }
     }
     if (lane == 0 && q_total) atomicAdd(&stats[1], q_total);
