@@ -1150,17 +1150,21 @@ int device_view(kbbq_engine *e, const kbbq_reads *in, ReadsDev *out, int *max_le
         if ((rc = stage_array(e, in->flags, in->flags ? in->n_reads : 0, 0, &R.flags))) return rc;
         if ((rc = stage_array(e, in->rg, in->rg ? in->n_reads : 0, 0, &R.rg))) return rc;
     }
+    uint64_t host_longest = 0;
     if (!in->on_device && in->offsets) {
         if (in->offsets[0] != 0 || in->offsets[in->n_reads] != in->n_bases) return fail(KBBQ_EINVAL, "offsets do not span n_bases");
         for (uint64_t r = 0; r < in->n_reads; ++r) {
             if (in->offsets[r + 1] < in->offsets[r]) return fail(KBBQ_EINVAL, "offsets are not monotone");
-            if (in->offsets[r + 1] - in->offsets[r] > (uint64_t)e->p.max_read_len)
+            const uint64_t l = in->offsets[r + 1] - in->offsets[r];
+            if (l > (uint64_t)e->p.max_read_len)
                 return fail(KBBQ_ERANGE, "read %llu is longer than params.max_read_len %d", (unsigned long long)r, e->p.max_read_len);
+            host_longest = std::max(host_longest, l);
         }
     }
     *out = R;
-    // longest read: uniform => read_len; ragged => the engine's declared maximum
-    *max_len = in->offsets ? e->p.max_read_len : (int)in->read_len;
+    // longest read (selects the kernel variants): uniform => read_len; ragged host batch => measured;
+    // ragged device batch => the engine's declared maximum
+    *max_len = !in->offsets ? (int)in->read_len : in->on_device ? e->p.max_read_len : std::max<int>(1, (int)host_longest);
     if (*max_len > KBBQ_MAX_READ_LEN) return fail(KBBQ_ERANGE, "read length %d > %d", *max_len, KBBQ_MAX_READ_LEN);
     if (*max_len > e->p.max_read_len) return fail(KBBQ_ERANGE, "read length %d > params.max_read_len %d", *max_len, e->p.max_read_len);
     return KBBQ_OK;

@@ -1,0 +1,89 @@
+// fastq_io.h -- host I/O of the FASTQ path, on plain zlib because
+// htslib is not part of this image:
+//   * FastqReader  : what kseq_read over bgzf_read delivers to FastqFile (htsiter.hh:101-126,
+//                    htsiter.cc:49-59): name (up to the first blank), comment (rest of the header
+//                    line), sequence, quality; plain, gzip and BGZF input alike (BGZF is multi-member gzip);
+//   * parse_read_name : the read-group / second-in-pair rules of CReadData's FASTQ constructor
+//                    (readutils.cc:64-104), quirks included;
+//   * BgzfWriter / write_fastq_record : FastqFile::write (htsiter.cc:75-86): "@name\nseq\n+comment\nqual\n"
+//                    through BGZF blocks (bgzf_open(.., "w"), htsiter.cc:67-72), ending with the BGZF EOF
+//                    block.  Parity is promised on the DECOMPRESSED bytes, not on the compressed ones.
+#pragma once
+#include <zlib.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace kbbq {
+
+struct FastqRecord {
+    std::string name, comment, seq, qual;
+};
+
+class FastqReader {
+public:
+    explicit FastqReader(const std::string &path);
+    ~FastqReader();
+    bool ok() const { return fh_ != nullptr; }
+    // >= 0: sequence length; -1: end of file; -2: truncated quality (kseq_read's return values)
+    int next(FastqRecord &rec);
+
+private:
+    int getc_();
+    bool getline_(std::string &out, bool append);   // without the line terminator; false at EOF with nothing read
+    gzFile fh_ = nullptr;
+    std::vector<unsigned char> buf_;
+    size_t pos_ = 0, end_ = 0;
+    int last_char_ = 0;
+    bool eof_ = false;
+};
+
+// The dense read-group index in order of first appearance (CReadData::rg_to_int, readutils.cc:10-11,100-103).
+class ReadGroups {
+public:
+    int index_of(const std::string &rg) {
+        auto it = map_.find(rg);
+        if (it != map_.end()) return it->second;
+        const int id = (int)map_.size();   // g++ evaluates size() before the insertion (SURVEY hazard H4)
+        map_.emplace(rg, id);
+        names_.push_back(rg);
+        return id;
+    }
+    size_t size() const { return names_.size(); }
+    const std::vector<std::string> &names() const { return names_; }
+
+private:
+    std::unordered_map<std::string, int> map_;
+    std::vector<std::string> names_;
+};
+
+// readutils.cc:74-97 with rg = "", second = 2 (infer), namedelimiter = "_".  Returns false where the
+// reference would throw (name shorter than two characters, readutils.cc:90).
+bool parse_read_name(const std::string &fullname, std::string &rg, bool &second, std::string &first_name);
+
+class BgzfWriter {
+public:
+    explicit BgzfWriter(FILE *out) : out_(out) { pending_.reserve(kBlock); }
+    ~BgzfWriter() { close(); }
+    bool write(const char *data, size_t n);
+    bool close();   // flushes and appends the 28-byte EOF block; idempotent
+
+private:
+    static constexpr size_t kBlock = 0xff00;   // BGZF_BLOCK_SIZE of htslib
+    bool flush_block();
+    FILE *out_;
+    std::vector<unsigned char> pending_;
+    bool closed_ = false;
+};
+
+inline bool write_fastq_record(BgzfWriter &w, const FastqRecord &r, const std::string &qual) {
+    std::string s;
+    s.reserve(r.name.size() + r.seq.size() + r.comment.size() + qual.size() + 8);
+    s += '@'; s += r.name; s += '\n'; s += r.seq; s += "\n+"; s += r.comment; s += '\n'; s += qual; s += '\n';
+    return w.write(s.data(), s.size());
+}
+
+}  // namespace kbbq

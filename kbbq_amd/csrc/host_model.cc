@@ -270,6 +270,9 @@ bool make_filter_spec(uint64_t projected, double fpr, uint64_t seed, FilterSpec 
 double sampled_fpr(uint64_t table_bits, uint64_t inserted, uint32_t n_salt) {
     // pattern_blocked_bf::effective_fpp, bloom.hh:318-330
     if (inserted == 0) return 0.0;   // the reference divides by zero here
+    // more elements than bits: c = 0 and lambda = inf below, and the reference's loop never ends; the
+    // filter is saturated, which the caller's 0.15 gate (kbbq.cc:306-310) turns into its usual error
+    if (inserted > table_bits) return 1.0;
     const size_t nsalt = n_salt;
     long double c = table_bits / inserted;
     long double lambda = kBlockBits / c;
@@ -290,6 +293,13 @@ long double binom_logpmf(unsigned long long k, unsigned long long n, long double
     return (long double)comb + (long double)k * std::log(p) + (long double)(n - k) * std::log1p(-p);
 }
 }  // namespace
+
+std::vector<long double> log_binom_cdf_values(unsigned long long k, long double p) {
+    std::vector<long double> ret(k + 1);
+    ret[0] = binom_logpmf(0, k, p);
+    for (unsigned long long i = 1; i <= k; ++i) ret[i] = std::log(std::exp(ret[i - 1]) + std::exp(binom_logpmf(i, k, p)));
+    return ret;
+}
 
 std::vector<int32_t> thresholds_from_counts(int k, uint64_t table_bits, uint64_t inserted, uint32_t n_salt,
                                             const char *alpha_text, double *fpr_out, std::string *p_text) {

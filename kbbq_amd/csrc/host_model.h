@@ -60,6 +60,9 @@ double sampled_fpr(uint64_t table_bits, uint64_t inserted, uint32_t n_salt);
 std::vector<int32_t> thresholds_from_counts(int k, uint64_t table_bits, uint64_t inserted, uint32_t n_salt,
                                             const char *alpha_text, double *fpr_out, std::string *p_text);
 
+// covariateutils::log_binom_cdf(k, p) (covariateutils.hh:61-68): the values main() logs (kbbq.cc:327-331)
+std::vector<long double> log_binom_cdf_values(unsigned long long k, long double p);
+
 struct DqTables {
     uint64_t n_rg = 0, n_cycle = 0;
     std::vector<int32_t> meanq, rgdq, qdq, cycledq, dinucdq;

@@ -329,6 +329,9 @@ struct Filter {
 
 // pattern_blocked_bf::effective_fpp, bloom.hh:318-330 (returns double).
 double effective_fpp(uint64_t table_bits, uint64_t element_count, size_t nsalt) {
+    // More elements than bits: the reference's integer division gives c = 0, lambda = inf and a loop that
+    // never ends (bloom.hh:320-323).  Both sides of the parity pair report a saturated filter instead.
+    if (element_count > table_bits) return 1.0;
     long double c = table_bits / element_count;                 // integer division
     long double lambda = BLOCK_BITS / c;
     long double fpp = 0;

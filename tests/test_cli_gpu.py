@@ -1,0 +1,136 @@
+"""The `kbbq` command line (kbbq_amd/csrc/kbbq_cli.cc) end to end on the GPU: FASTQ(.gz) in, recalibrated BGZF
+FASTQ on stdout, against the oracle run on the same records (kbbq.cc:205-457 for FASTQ input)."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import common
+from test_cli_io_cpu import CLI, ref_name_rules
+
+pytestmark = pytest.mark.gpu
+
+
+def write_fastq(path, d, names, comments=None):
+    off = d["off"].astype(np.int64)
+    seq, qual = d["seq"].tobytes(), (d["qual"] + 33).astype(np.uint8).tobytes()
+    opener = gzip.open if str(path).endswith(".gz") else open
+    with opener(path, "wb") as fh:
+        for r, name in enumerate(names):
+            head = name if not comments or not comments[r] else name + " " + comments[r]
+            fh.write(b"@" + head.encode() + b"\n" + seq[off[r]:off[r + 1]] + b"\n+\n" + qual[off[r]:off[r + 1]] + b"\n")
+
+
+def read_fastq_text(blob):
+    lines = blob.decode().split("\n")
+    assert lines[-1] == ""
+    return [tuple(lines[i:i + 4]) for i in range(0, len(lines) - 1, 4)]
+
+
+def named_dataset(**kw):
+    d = common.make_dataset(**kw)
+    n = len(d["off"]) - 1
+    groups = ["", "laneA", "laneB"]
+    names, rg_index, seen = [], [], {}
+    for r in range(n):
+        g = groups[(r * 7 // 3) % 3] if r > 4 else ""
+        name = "read%d%s" % (r // 2, "/2" if r & 1 else "/1")
+        if g:
+            name += "_x_RG:Z:%s" % g
+        rg, second, _ = ref_name_rules(name)
+        rg_index.append(seen.setdefault(rg, len(seen)))
+        assert second == bool(r & 1)
+        names.append(name)
+    d["rg"] = np.array(rg_index, dtype=np.int32)
+    d["second"] = (np.arange(n) & 1).astype(np.uint8)
+    return d, names, len(seen)
+
+
+def run_cli(args, env_extra=None):
+    env = dict(os.environ, **(env_extra or {}))
+    p = subprocess.run([CLI] + [str(a) for a in args], capture_output=True, env=env, timeout=600)
+    return p.returncode, p.stdout, p.stderr.decode()
+
+
+def test_cli_recalibrates_fastq_like_the_reference_pipeline(tmp_path):
+    d, names, n_rg = named_dataset(seed=2024, genome_len=25000, coverage=24, n_per_million=3000, ragged=True, mid_reads=100,
+                                   extra_errors=150)
+    comments = ["c%d extra" % r if r % 5 == 0 else "" for r in range(len(names))]
+    fq = tmp_path / "in.fq.gz"
+    write_fastq(fq, d, names, comments)
+    total = int(d["off"][-1])
+    coverage = total // d["genome_len"]          # what the CLI estimates (kbbq.cc:229-250)
+    rc, out, err = run_cli(["-g", d["genome_len"], fq], {"KBBQ_SEED": "777"})
+    assert rc == 0, err
+    for line in ("Estimating alpha.", "Estimating coverage.", "Total Sequence length: %d" % total, "Estimated coverage: %d" % coverage,
+                 "Seed: 777", "Sampled ", "Approximate false positive rate:", "log CDF: [", "Finding trusted kmers", "Finding errors",
+                 "Training model", "Recalibrating file"):
+        assert line in err, line
+    ora = common.run_oracle(dict(d, coverage=coverage), seed=777, n_rg=n_rg)
+    assert " Sampled %d valid kmers." % ora["sampled_inserted"] in err
+    recs = read_fastq_text(gzip.decompress(out))
+    assert len(recs) == len(names)
+    off = d["off"].astype(np.int64)
+    seq = d["seq"].tobytes().decode()
+    want_q = (ora["recal"] + 33).astype(np.uint8).tobytes().decode()
+    for r, (h, s, plus, q) in enumerate(recs):
+        assert h == "@" + names[r] and s == seq[off[r]:off[r + 1]] and plus == "+" + comments[r]   # htsiter.cc:75-86
+        assert q == want_q[off[r]:off[r + 1]], "read %d" % r
+    assert (ora["recal"] != d["qual"]).any()
+
+
+def test_cli_options_k_alpha_coverage_and_plain_input(tmp_path):
+    d, names, n_rg = named_dataset(seed=5, genome_len=15000, coverage=40, read_len=100)
+    fq = tmp_path / "in.fq"
+    write_fastq(fq, d, names)
+    rc, out, err = run_cli(["-k", 21, "-a", "0.05", "-c", 40, "--genomelen", d["genome_len"], "-t", 4, fq], {"KBBQ_SEED": "31337"})
+    assert rc == 0, err
+    assert "Estimating" not in err and "Sampling kmers at rate 0.05" in err
+    ora = common.run_oracle(dict(d, coverage=40), k=21, seed=31337, alpha="0.05", n_rg=n_rg)
+    recs = read_fastq_text(gzip.decompress(out))
+    got = "".join(q for _, _, _, q in recs)
+    assert got == (ora["recal"] + 33).astype(np.uint8).tobytes().decode()
+
+
+def test_cli_fixed_mode_uses_the_corrected_file_as_truth(tmp_path):
+    d, names, n_rg = named_dataset(seed=8, genome_len=12000, coverage=20, read_len=100)
+    truth = dict(d)
+    rng = np.random.RandomState(3)
+    seq = d["seq"].copy()
+    flip = rng.rand(len(seq)) < 0.01
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seq[flip] = acgt[rng.randint(0, 4, size=int(flip.sum()))]
+    truth["seq"] = seq
+    fq, fixed = tmp_path / "in.fq.gz", tmp_path / "fixed.fq"
+    write_fastq(fq, d, names)
+    write_fastq(fixed, truth, names)
+    rc, out, err = run_cli(["--fixed", fixed, fq])
+    assert rc == 0, err
+    assert "Using fixed file to find errors." in err
+    errors = (d["seq"] != seq).astype(np.uint8)
+    alpha_ld, cov, approx = common.plan_parameters(d["genome_len"], 20, None)
+    o = common.pyoracle.Oracle(32, alpha_ld, 1, approx)
+    o.tally(d["seq"], d["qual"], d["off"], d["rg"], d["second"], errors)       # consume_read, kbbq.cc:371-377
+    o.train()
+    want = o.recalibrate(d["seq"], d["qual"], d["off"], d["rg"], d["second"])
+    got = "".join(q for _, _, _, q in read_fastq_text(gzip.decompress(out)))
+    assert got == (want + 33).astype(np.uint8).tobytes().decode()
+
+
+def test_cli_error_paths(tmp_path):
+    d, names, _ = named_dataset(seed=5, genome_len=3000, coverage=10, read_len=100)
+    fq = tmp_path / "in.fq"
+    write_fastq(fq, d, names)
+    rc, out, err = run_cli([fq])
+    assert rc != 0 and "--genomelen must be specified" in err and out == b""
+    rc, out, err = run_cli(["-g", 10 ** 9, fq])
+    assert rc != 0 and "estimated coverage is 0" in err
+    rc, out, err = run_cli(["-k", 33, "-g", 3000, fq])
+    assert rc != 0 and "k must be <= 32" in err
+    rc, out, err = run_cli(["-g", 3000, tmp_path / "missing.fq"])
+    assert rc != 0 and "Error opening file" in err
+    # a genome length far too small for the data: the sampled filter overflows its false-positive gate (kbbq.cc:311-316)
+    rc, out, err = run_cli(["-g", 30, "-c", 10, fq], {"KBBQ_SEED": "1"})
+    assert rc != 0 and "false positive rate is too high" in err

@@ -146,7 +146,8 @@ def test_host_thresholds_equal_oracle():
     L, O = _lib.lib(), pyoracle.lib()
     cases = [(32, 67150848, 5553859, 7, np.longdouble("0.35")), (32, 67150848, 5553859, 7, np.longdouble(7) / np.longdouble(30)),
              (21, 10 ** 9, 31234567, 7, np.longdouble("0.05")), (32, 2 * 10 ** 11, 16607190899, 7, np.longdouble(7) / np.longdouble(30)),
-             (15, 5 * 10 ** 6, 4 * 10 ** 6, 7, np.longdouble("0.09"))]
+             (15, 5 * 10 ** 6, 4 * 10 ** 6, 7, np.longdouble("0.09")),
+             (32, 2048, 14413, 7, np.longdouble("0.7"))]      # saturated: more elements than bits, fpr reported as 1
     for k, bits, ins, nsalt, alpha in cases:
         thr = np.zeros(k + 1, dtype=np.int32)
         fpr = ctypes.c_double()
