@@ -1,0 +1,185 @@
+// bam_io.cc -- see bam_io.h.
+#include "bam_io.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace kbbq {
+
+// ------------------------------------------------------------------ record ----
+void BamRecord::sequence(std::string &out) const {
+    static const char letters[] = "=ACMGRSVTWYHKDBN";                      // seq_nt16_str
+    static const int8_t two_bit[16] = {4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4};   // seq_nt16_int
+    const uint32_t n = l_seq();
+    const uint8_t *s = data.data() + seq_at();
+    out.resize(n);
+    const bool rev = reverse();
+    for (uint32_t i = 0; i < n; ++i) {
+        const int code = (s[i >> 1] >> ((~i & 1) << 2)) & 15;              // bam_seqi
+        if (!rev) {
+            out[i] = letters[code];
+        } else {
+            const int b = two_bit[code];
+            out[n - 1 - i] = b < 4 ? "TGCA"[b] : 'N';                       // readutils.hh:35-36, then the reversal
+        }
+    }
+}
+
+// length of the value that starts with the type byte at s (skip_aux of htslib), or 0 if it does not fit
+static size_t aux_value_size(const uint8_t *s, const uint8_t *end) {
+    if (s >= end) return 0;
+    size_t fixed = 0;
+    switch (*s) {
+        case 'A': case 'c': case 'C': fixed = 1; break;
+        case 's': case 'S': fixed = 2; break;
+        case 'i': case 'I': case 'f': fixed = 4; break;
+        case 'd': fixed = 8; break;
+        case 'Z': case 'H': {
+            const void *nul = memchr(s + 1, 0, (size_t)(end - (s + 1)));
+            return nul ? (size_t)((const uint8_t *)nul - s) + 1 : 0;
+        }
+        case 'B': {
+            if (end - s < 6) return 0;
+            size_t each;
+            switch (s[1]) {
+                case 'c': case 'C': each = 1; break;
+                case 's': case 'S': each = 2; break;
+                case 'i': case 'I': case 'f': each = 4; break;
+                default: return 0;
+            }
+            const uint64_t count = (uint64_t)s[2] | (uint64_t)s[3] << 8 | (uint64_t)s[4] << 16 | (uint64_t)s[5] << 24;
+            const uint64_t total = 6 + each * count;
+            return total <= (uint64_t)(end - s) ? (size_t)total : 0;
+        }
+        default: return 0;
+    }
+    return 1 + fixed <= (size_t)(end - s) ? 1 + fixed : 0;
+}
+
+size_t BamRecord::aux_find(const char tag[2], int &status) const {
+    const uint8_t *base = data.data(), *end = base + data.size();
+    const uint8_t *s = base + aux_at();
+    while (end - s >= 3) {
+        const bool hit = s[0] == (uint8_t)tag[0] && s[1] == (uint8_t)tag[1];
+        s += 2;
+        const size_t sz = aux_value_size(s, end);
+        if (!sz) { status = BAM_AUX_CORRUPT; return 0; }
+        if (hit) { status = BAM_AUX_OK; return (size_t)(s - base); }
+        s += sz;
+    }
+    status = BAM_AUX_MISSING;
+    return 0;
+}
+
+bool BamRecord::aux_string(const char tag[2], std::string &out, int &status) const {
+    const size_t at = aux_find(tag, status);
+    if (!at) return false;
+    if (data[at] != 'Z' && data[at] != 'H') { status = BAM_AUX_CORRUPT; return false; }   // bam_aux2Z returns NULL, EINVAL
+    out.assign((const char *)data.data() + at + 1);
+    return true;
+}
+
+bool BamRecord::aux_update_string(const char tag[2], const std::string &text, int &status) {
+    const size_t at = aux_find(tag, status);
+    if (at) {
+        if (data[at] != 'Z') { status = BAM_AUX_CORRUPT; return false; }
+        const size_t old_len = strlen((const char *)data.data() + at + 1) + 1;
+        std::vector<uint8_t> value(text.begin(), text.end());
+        value.push_back(0);
+        data.erase(data.begin() + at + 1, data.begin() + at + 1 + old_len);
+        data.insert(data.begin() + at + 1, value.begin(), value.end());
+        return true;
+    }
+    if (status != BAM_AUX_MISSING) return false;
+    data.push_back((uint8_t)tag[0]);
+    data.push_back((uint8_t)tag[1]);
+    data.push_back('Z');
+    data.insert(data.end(), text.begin(), text.end());
+    data.push_back(0);
+    status = BAM_AUX_OK;
+    return true;
+}
+
+// ------------------------------------------------------------------ reader ----
+BamReader::BamReader(const std::string &path) {
+    fh_ = gzopen(path.c_str(), "rb");     // BGZF is a series of gzip members, which gzread concatenates
+    if (!fh_) return;
+    gzbuffer(fh_, 1 << 20);
+    unsigned char magic[4];
+    uint32_t l_text = 0, n_ref = 0;
+    if (!read_exact(magic, 4) || memcmp(magic, "BAM\1", 4) != 0) return;
+    if (!read_exact(&l_text, 4)) return;
+    header_.text.resize(l_text);
+    if (l_text && !read_exact(&header_.text[0], l_text)) return;
+    if (!read_exact(&n_ref, 4)) return;
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        uint32_t l_name = 0, l_ref = 0;
+        if (!read_exact(&l_name, 4) || l_name == 0 || l_name > (1u << 20)) return;
+        std::string name(l_name, '\0');
+        if (!read_exact(&name[0], l_name) || !read_exact(&l_ref, 4)) return;
+        name.resize(l_name - 1);
+        header_.refs.emplace_back(name, l_ref);
+    }
+    ok_ = true;
+}
+
+BamReader::~BamReader() {
+    if (fh_) gzclose(fh_);
+}
+
+bool BamReader::read_exact(void *dst, size_t n) {
+    unsigned char *p = (unsigned char *)dst;
+    while (n) {
+        const int got = gzread(fh_, p, (unsigned)std::min<size_t>(n, 1u << 30));
+        if (got <= 0) return false;
+        p += got;
+        n -= (size_t)got;
+    }
+    return true;
+}
+
+int BamReader::next(BamRecord &rec) {
+    if (!ok_) return -2;
+    unsigned char len[4];
+    const int got = gzread(fh_, len, 4);
+    if (got == 0) return -1;
+    if (got != 4) {
+        if (got > 0 && read_exact(len + got, 4 - (size_t)got)) { /* short read at a member boundary */ } else return -2;
+    }
+    const uint32_t block = (uint32_t)len[0] | (uint32_t)len[1] << 8 | (uint32_t)len[2] << 16 | (uint32_t)len[3] << 24;
+    if (block < 32 || block > (1u << 29)) return -2;
+    rec.data.resize(block);
+    if (!read_exact(rec.data.data(), block)) return -2;
+    if (!rec.well_formed()) return -2;
+    return (int)block;
+}
+
+// ------------------------------------------------------------------ writer ----
+static void put32(std::string &s, uint32_t v) {
+    for (int i = 0; i < 4; ++i) s.push_back((char)(v >> (8 * i)));
+}
+
+bool BamWriter::write_header(const BamHeader &h) {
+    std::string s("BAM\1", 4);
+    put32(s, (uint32_t)h.text.size());
+    s += h.text;
+    put32(s, (uint32_t)h.refs.size());
+    for (auto &r : h.refs) {
+        put32(s, (uint32_t)r.first.size() + 1);
+        s += r.first;
+        s.push_back('\0');
+        put32(s, r.second);
+    }
+    // htslib flushes the BGZF block after the header, so records start in a block of their own; the
+    // decompressed stream is the same either way
+    return out_.write(s.data(), s.size());
+}
+
+bool BamWriter::write(const BamRecord &rec) {
+    unsigned char len[4];
+    const uint32_t n = (uint32_t)rec.data.size();
+    for (int i = 0; i < 4; ++i) len[i] = (unsigned char)(n >> (8 * i));
+    return out_.write((const char *)len, 4) && out_.write((const char *)rec.data.data(), rec.data.size());
+}
+
+}  // namespace kbbq

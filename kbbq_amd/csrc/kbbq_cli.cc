@@ -7,17 +7,19 @@
 // also computes there (coverage, alpha, thresholds, the delta-Q model -- inside the library).
 //
 // Differences, all deliberate:
-//   * BAM/CRAM input is refused: it needs htslib, which this image does not have (SURVEY risk R1);
+//   * BAM goes through this tool's own codec (bam_io.*) because htslib is not in this image; CRAM and SAM
+//     text are refused (SURVEY risk R1);
 //   * one extra read-only scan of the input sizes the histograms (read groups, longest read) before
 //     the engine is created; the reference grows its tables on the fly;
 //   * the sampler seed can be fixed with KBBQ_SEED=<u32> (the reference always draws it from time+pid,
 //     kbbq.cc:268-270, so two of its own runs differ: SURVEY hazard H1);
 //   * --threads is accepted and ignored (it only sizes htslib's BGZF pool, kbbq.cc:159-168);
-//   * where the reference prints an error and then crashes (missing --genomelen on FASTQ, kbbq.cc:218)
-//     this exits 1.
+//   * where the reference prints an error and then crashes or throws (missing --genomelen on FASTQ,
+//     kbbq.cc:218; missing RG / OQ tags, readutils.cc:20-30,42-53) this prints the same text and exits 1.
 #include <getopt.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -30,6 +32,7 @@
 #include <vector>
 
 #include "../../include/kbbq_engine.h"
+#include "bam_io.h"
 #include "fastq_io.h"
 #include "host_model.h"
 
@@ -65,7 +68,7 @@ static uint32_t time_pid_seed() {
     return (uint32_t)(sum >> 32);
 }
 
-enum class Format { fastq, bam, unknown };
+enum class Format { fastq, bam, cram, unknown };
 static Format sniff(const std::string &path) {   // hts_detect_format, as far as this tool needs it
     gzFile f = path == "-" ? nullptr : gzopen(path.c_str(), "rb");
     if (!f) return Format::unknown;
@@ -73,38 +76,134 @@ static Format sniff(const std::string &path) {   // hts_detect_format, as far as
     const int n = gzread(f, b, 4);
     gzclose(f);
     if (n >= 4 && b[0] == 'B' && b[1] == 'A' && b[2] == 'M' && b[3] == 1) return Format::bam;
-    if (n >= 4 && b[0] == 'C' && b[1] == 'R' && b[2] == 'A' && b[3] == 'M') return Format::bam;
+    if (n >= 4 && b[0] == 'C' && b[1] == 'R' && b[2] == 'A' && b[3] == 'M') return Format::cram;
     if (n >= 1 && b[0] == '@') return Format::fastq;
     return Format::unknown;
 }
 
+// One read as the passes see it (what HTSFile::get() puts into CReadData), plus the record it came from.
+struct Item {
+    std::string seq;              // sequencing orientation
+    std::vector<uint8_t> qual;    // numeric, sequencing orientation
+    std::string rg;
+    bool second = false;
+    FastqRecord fq;
+    BamRecord bam;
+};
+
+enum { SRC_FATAL = -100 };        // an error the reference throws on; the message is already on stderr
+
+// The record source of the passes: htsiter::HTSFile (htsiter.hh:40-49) for this tool.
+class Source {
+public:
+    virtual ~Source() {}
+    virtual bool ok() const = 0;
+    virtual int next(Item &it) = 0;   // >= 0 ok, -1 end of file, < -1 error (the reference's loops just end), SRC_FATAL
+};
+
+class FastqSource : public Source {   // FastqFile + CReadData(kseq_t*), htsiter.cc:49-59, readutils.cc:64-104
+public:
+    explicit FastqSource(const std::string &path) : in_(path) {}
+    bool ok() const override { return in_.ok(); }
+    int next(Item &it) override {
+        const int rc = in_.next(it.fq);
+        if (rc < 0) return rc;
+        std::string first;
+        if (!parse_read_name(it.fq.name, it.rg, it.second, first)) {
+            std::cerr << put_now << " Error: read name '" << it.fq.name << "' is shorter than 2 characters before the first '_'." << std::endl;
+            return SRC_FATAL;   // std::out_of_range in the reference (readutils.cc:90)
+        }
+        it.seq = it.fq.seq;
+        it.qual.resize(it.fq.qual.size());
+        for (size_t i = 0; i < it.qual.size(); ++i) it.qual[i] = (uint8_t)(it.fq.qual[i] - 33);   // readutils.cc:70-71
+        return rc;
+    }
+
+private:
+    FastqReader in_;
+};
+
+class BamSource : public Source {     // BamFile + CReadData(bam1_t*, use_oq), htsiter.cc:5-9, readutils.cc:13-61
+public:
+    BamSource(const std::string &path, bool use_oq) : in_(path), use_oq_(use_oq) {}
+    bool ok() const override { return in_.ok(); }
+    const BamHeader &header() const { return in_.header(); }
+    int next(Item &it) override {
+        const int rc = in_.next(it.bam);
+        if (rc < 0) return rc;
+        const BamRecord &b = it.bam;
+        b.sequence(it.seq);
+        int status = 0;
+        if (use_oq_) {
+            std::string oq;
+            if (!b.aux_string("OQ", oq, status)) {
+                std::cerr << "Error: --use-oq was specified but unable to read OQ tag on read " << b.name() << std::endl;
+                if (status == BAM_AUX_MISSING) std::cerr << "OQ not found. Try again without the --use-oq option." << std::endl;
+                else std::cerr << "Tag data is corrupt. Repair the tags and try again." << std::endl;
+                return SRC_FATAL;
+            }
+            if (oq.size() != b.l_seq()) {   // the reference indexes past the shorter of the two
+                std::cerr << "Error: OQ tag of read " << b.name() << " has " << oq.size() << " values for " << b.l_seq() << " bases." << std::endl;
+                return SRC_FATAL;
+            }
+            it.qual.resize(oq.size());
+            for (size_t i = 0; i < oq.size(); ++i) it.qual[i] = (uint8_t)(oq[i] - 33);
+        } else {
+            it.qual.assign(b.qual(), b.qual() + b.l_seq());
+        }
+        if (b.reverse()) std::reverse(it.qual.begin(), it.qual.end());   // readutils.cc:36-39
+        if (!b.aux_string("RG", it.rg, status)) {
+            std::cerr << "Error: Unable to read RG tag on read " << b.name() << std::endl;
+            if (status == BAM_AUX_MISSING)
+                std::cerr << "RG not found. Every read in the BAM must have an RG tag; add tags with "
+                          << "samtools addreplacerg and try again." << std::endl;
+            else std::cerr << "Tag data is corrupt. Repair the tags and try again." << std::endl;
+            return SRC_FATAL;
+        }
+        it.second = b.second();
+        return rc;
+    }
+
+private:
+    BamReader in_;
+    bool use_oq_;
+};
+
+static std::unique_ptr<Source> open_source(const std::string &path, bool is_bam, bool use_oq) {   // open_file, kbbq.cc:55-64
+    if (is_bam) return std::unique_ptr<Source>(new BamSource(path, use_oq));
+    return std::unique_ptr<Source>(new FastqSource(path));
+}
+
 // One batch of reads in the engine's layout, plus the records themselves for the output pass.
 struct Batch {
-    std::vector<FastqRecord> recs;
+    std::vector<FastqRecord> fq_recs;
+    std::vector<BamRecord> bam_recs;
     std::vector<uint8_t> seq, qual, flags;
     std::vector<uint16_t> rg;
     std::vector<uint64_t> off, bases, nmask;
     kbbq_reads c;
     bool stop_at_empty = false;   // next_str() != "" loops end at the first empty read (kbbq.cc:234, htsiter.cc:95)
+    bool fatal = false;
+    Item it;
 
     // returns false when no read was collected
-    bool fill(FastqReader &in, ReadGroups &groups, size_t max_reads, bool keep_records, bool &bad_name) {
-        recs.clear(); seq.clear(); qual.clear(); flags.clear(); rg.clear();
+    bool fill(Source &in, ReadGroups &groups, size_t max_reads, bool keep_records, bool is_bam = false) {
+        fq_recs.clear(); bam_recs.clear(); seq.clear(); qual.clear(); flags.clear(); rg.clear();
         off.assign(1, 0);
-        FastqRecord r;
         while (rg.size() < max_reads) {
-            const int rc = in.next(r);
+            const int rc = in.next(it);
+            if (rc == SRC_FATAL) { fatal = true; return false; }
             if (rc < 0) break;                       // -1 end of file; < -1 error: the reference's loops also just end
-            if (stop_at_empty && r.seq.empty()) break;
-            std::string group, first;
-            bool second = false;
-            if (!parse_read_name(r.name, group, second, first)) { bad_name = true; return false; }
-            seq.insert(seq.end(), r.seq.begin(), r.seq.end());
-            for (char ch : r.qual) qual.push_back((uint8_t)(ch - 33));       // readutils.cc:70-71
+            if (stop_at_empty && it.seq.empty()) break;
+            seq.insert(seq.end(), it.seq.begin(), it.seq.end());
+            qual.insert(qual.end(), it.qual.begin(), it.qual.end());
+            qual.resize(seq.size(), 0);
             off.push_back(seq.size());
-            flags.push_back(second ? 1 : 0);
-            rg.push_back((uint16_t)groups.index_of(group));
-            if (keep_records) recs.push_back(r);
+            flags.push_back(it.second ? 1 : 0);
+            rg.push_back((uint16_t)groups.index_of(it.rg));
+            if (keep_records) {
+                if (is_bam) bam_recs.push_back(it.bam); else fq_recs.push_back(it.fq);
+            }
         }
         if (rg.empty()) return false;
         bases.assign(seq.size() / 32 + 2, 0);
@@ -148,6 +247,42 @@ static int io_test(int argc, char *argv[]) {
         }
         printf("#end %d\n", rc);
         return 0;
+    }
+    if (what == "bam" && argc > 3) {     // what the passes see of a BAM: --io-test bam FILE [use-oq]
+        BamSource in(argv[3], argc > 4 && std::string(argv[4]) == "use-oq");
+        if (!in.ok()) return 2;
+        printf("#text %zu genome %llu refs %zu\n", in.header().text.size(), (unsigned long long)in.header().genome_length(), in.header().refs.size());
+        Item it;
+        ReadGroups groups;
+        int rc;
+        while ((rc = in.next(it)) >= 0) {
+            std::string q(it.qual.size(), ' ');
+            for (size_t i = 0; i < q.size(); ++i) q[i] = (char)(it.qual[i] + 33);
+            printf("%s\t%d\t%s\t%d\t%d\t%s\t%s\n", it.bam.name().c_str(), (int)it.bam.flag(), it.rg.c_str(), groups.index_of(it.rg), (int)it.second,
+                   it.seq.c_str(), q.c_str());
+        }
+        printf("#end %d\n", rc);
+        return 0;
+    }
+    if (what == "bamcopy" && argc > 3) { // reader -> (OQ update) -> writer: --io-test bamcopy FILE [set-oq]
+        BamReader in(argv[3]);
+        if (!in.ok()) return 2;
+        const bool set_oq = argc > 4 && std::string(argv[4]) == "set-oq";
+        BgzfWriter out(stdout);
+        BamWriter w(out);
+        if (!w.write_header(in.header())) return 1;
+        BamRecord b;
+        std::string q;
+        while (in.next(b) >= 0) {
+            if (set_oq) {
+                q.assign(b.l_seq(), ' ');
+                for (size_t i = 0; i < q.size(); ++i) q[i] = (char)(b.qual()[i] + 33);
+                int status = 0;
+                if (!b.aux_update_string("OQ", q, status)) return 3;
+            }
+            if (!w.write(b)) return 1;
+        }
+        return out.close() ? 0 : 1;
     }
     if (what == "bgzf") {   // stdin -> BGZF on stdout
         BgzfWriter out(stdout);
@@ -196,7 +331,7 @@ int main(int argc, char *argv[]) {
                 return 1;
         }
     }
-    (void)set_oq; (void)use_oq; (void)nthreads;
+    (void)nthreads;
     std::string filename("-");
     if (optind < argc) {
         filename = std::string(argv[optind]);
@@ -209,31 +344,35 @@ int main(int argc, char *argv[]) {
         std::cerr << put_now << " Error opening file " << filename << std::endl;   // also: a pipe cannot be re-read by the passes
         return 1;
     }
-    if (fmt == Format::bam) {
-        std::cerr << put_now << " Error: BAM/CRAM input needs htslib, which this build does not have; only FASTQ is supported."
-                  << std::endl;
+    if (fmt == Format::cram) {
+        std::cerr << put_now << " Error: CRAM input needs htslib, which this build does not have; use BAM or FASTQ." << std::endl;
         return 1;
     }
+    const bool is_bam = fmt == Format::bam;
 
     // one read-only scan: total length (the reference's coverage pass, kbbq.cc:229-250), read groups, longest read
     ReadGroups groups;
     uint64_t seqlen = 0, n_reads = 0;
     size_t longest = 0;
+    BamHeader bam_header;
     {
-        FastqReader in(filename);
-        FastqRecord r;
-        std::string group, first;
-        bool second;
-        while (in.next(r) >= 0 && !r.seq.empty()) {
-            seqlen += r.seq.length();
-            longest = std::max(longest, r.seq.length());
-            ++n_reads;
-            if (!parse_read_name(r.name, group, second, first)) {
-                std::cerr << put_now << " Error: read name '" << r.name << "' is shorter than 2 characters before the first '_'." << std::endl;
-                return 1;   // std::out_of_range in the reference (readutils.cc:90)
-            }
-            groups.index_of(group);
+        std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
+        if (!in->ok()) {
+            std::cerr << put_now << " Error opening file " << filename << std::endl;
+            return 1;
         }
+        if (is_bam) bam_header = static_cast<BamSource *>(in.get())->header();
+        Item it;
+        int rc;
+        bool counting = true;    // the coverage pass stops at the first empty read; the other passes do not
+        while ((rc = in->next(it)) >= 0) {
+            if (it.seq.empty()) counting = false;
+            if (counting) seqlen += it.seq.length();
+            longest = std::max(longest, it.seq.length());
+            ++n_reads;
+            groups.index_of(it.rg);
+        }
+        if (rc == SRC_FATAL) return 1;
     }
     if (longest > KBBQ_MAX_READ_LEN) {
         std::cerr << put_now << " Error: reads longer than " << KBBQ_MAX_READ_LEN << " bases are not supported by the GPU engine." << std::endl;
@@ -244,12 +383,23 @@ int main(int argc, char *argv[]) {
     kbbq_engine *e = nullptr;
     const size_t batch_reads = 1 << 20;
     Batch batch;
-    bool bad_name = false;
 
     if (!fixed_mode) {
         if (genomelen == 0) {
-            std::cerr << put_now << " Error: --genomelen must be specified if input is not a bam." << std::endl;
-            return 1;
+            if (is_bam) {   // kbbq.cc:196-216
+                std::cerr << put_now << " Estimating genome length" << std::endl;
+                genomelen = bam_header.genome_length();
+                if (genomelen == 0) {
+                    std::cerr << put_now << " Header does not contain genome information."
+                              << " Unable to estimate genome length; please provide it on the command line"
+                              << " using the --genomelen option." << std::endl;
+                    return 1;
+                }
+                std::cerr << put_now << " Genome length is " << genomelen << " bp." << std::endl;
+            } else {
+                std::cerr << put_now << " Error: --genomelen must be specified if input is not a bam." << std::endl;
+                return 1;
+            }
         }
         if (alpha == 0) {   // kbbq.cc:227-252
             std::cerr << put_now << " Estimating alpha." << std::endl;
@@ -294,14 +444,15 @@ int main(int argc, char *argv[]) {
 
         // pass 1, kbbq.cc:277-283
         {
-            FastqReader in(filename);
+            std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
             uint64_t ordinal = 0, nk = 0;
             batch.stop_at_empty = true;
-            while (batch.fill(in, groups, batch_reads, false, bad_name)) {
+            while (batch.fill(*in, groups, batch_reads, false)) {
                 if (kbbq_sample_batch(e, &batch.c, ordinal) < 0) return fail_engine("sampling");
                 if (kbbq_count_kmer_positions(e, &batch.c, &nk) < 0) return fail_engine("sampling");
                 ordinal += nk;
             }
+            if (batch.fatal) return 1;
             batch.stop_at_empty = false;
             uint64_t inserted = 0;
             if (kbbq_sample_finish(e, &inserted) < 0) return fail_engine("sampling");
@@ -330,17 +481,19 @@ int main(int argc, char *argv[]) {
         // pass 2, kbbq.cc:333-337
         std::cerr << put_now << " Finding trusted kmers" << std::endl;
         {
-            FastqReader in(filename);
-            while (batch.fill(in, groups, batch_reads, false, bad_name))
+            std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
+            while (batch.fill(*in, groups, batch_reads, false))
                 if (kbbq_trusted_batch(e, &batch.c, nullptr) < 0) return fail_engine("finding trusted kmers");
+            if (batch.fatal) return 1;
             if (kbbq_trusted_finish(e, nullptr) < 0) return fail_engine("finding trusted kmers");
         }
         // pass 3, kbbq.cc:363-366
         std::cerr << put_now << " Finding errors" << std::endl;
         {
-            FastqReader in(filename);
-            while (batch.fill(in, groups, batch_reads, false, bad_name))
+            std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
+            while (batch.fill(*in, groups, batch_reads, false))
                 if (kbbq_errors_batch(e, &batch.c, nullptr) < 0) return fail_engine("finding errors");
+            if (batch.fatal) return 1;
         }
     } else {
         // --fixed, kbbq.cc:367-378: errors = bases that differ from the corrected file
@@ -352,11 +505,15 @@ int main(int argc, char *argv[]) {
         p.fpr_sampled = 0.01; p.fpr_trusted = 0.0005; p.bloom_seed = KBBQ_DEFAULT_BLOOM_SEED;
         p.max_read_len = (int32_t)std::max<size_t>(1, longest);
         if (kbbq_engine_create(&p, &e) < 0) return fail_engine("cannot create the engine");
-        FastqReader in(filename), fixed(fixedinput);
+        // the second file is opened in the FIRST file's format (kbbq.cc:370 passes is_bam)
+        std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq), fixed = open_source(fixedinput, is_bam, use_oq);
+        if (!fixed->ok()) {
+            std::cerr << put_now << " Error opening file " << fixedinput << std::endl;
+            return 1;
+        }
         Batch fb;
         ReadGroups fixed_groups;
-        bool bad2 = false;
-        while (batch.fill(in, groups, batch_reads, false, bad_name) && fb.fill(fixed, fixed_groups, batch.c.n_reads, false, bad2)) {
+        while (batch.fill(*in, groups, batch_reads, false) && fb.fill(*fixed, fixed_groups, batch.c.n_reads, false)) {
             std::vector<uint64_t> err(batch.c.n_bases / 64 + 2, 0);
             const size_t nr = std::min<size_t>(batch.c.n_reads, fb.c.n_reads);
             for (size_t r = 0; r < nr; ++r) {
@@ -364,12 +521,13 @@ int main(int argc, char *argv[]) {
                 for (uint64_t i = 0; i < len && i < flen; ++i)
                     if (batch.seq[a + i] != fb.seq[b + i]) err[(a + i) >> 6] |= 1ULL << ((a + i) & 63);
             }
+            if (fb.c.n_reads < batch.c.n_reads) {   // the fixed file ended first: the reference stops consuming there
+                batch.c.n_reads = nr;
+                batch.c.n_bases = batch.off[nr];
+            }
             if (kbbq_tally_batch(e, &batch.c, err.data()) < 0) return fail_engine("tally");
         }
-    }
-    if (bad_name) {
-        std::cerr << put_now << " Error: a read name is shorter than 2 characters before the first '_'." << std::endl;
-        return 1;
+        if (batch.fatal || fb.fatal) return 1;
     }
 
     // kbbq.cc:405-407
@@ -379,20 +537,40 @@ int main(int argc, char *argv[]) {
     // pass 4, kbbq.cc:455-457: recalibrate_and_write(file, dqs, "-")
     std::cerr << put_now << " Recalibrating file" << std::endl;
     {
-        FastqReader in(filename);
+        std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
         BgzfWriter out(stdout);
+        BamWriter bam_out(out);
+        if (is_bam && !bam_out.write_header(bam_header)) return 1;      // BamFile::open_out, htsiter.cc:35-42
         std::vector<uint8_t> newq;
         std::string qtext;
-        while (batch.fill(in, groups, batch_reads, true, bad_name)) {
+        while (batch.fill(*in, groups, batch_reads, true, is_bam)) {
             newq.assign(batch.c.n_bases + 16, 0);
             if (kbbq_recalibrate_batch(e, &batch.c, newq.data()) < 0) return fail_engine("recalibrating");
-            for (size_t r = 0; r < batch.recs.size(); ++r) {
+            for (size_t r = 0; r < batch.c.n_reads; ++r) {
                 const uint64_t a = batch.off[r], len = batch.off[r + 1] - a;
-                qtext.resize(len);
-                for (uint64_t i = 0; i < len; ++i) qtext[i] = (char)(newq[a + i] + 33);   // htsiter.cc:61-65
-                if (!write_fastq_record(out, batch.recs[r], qtext)) return 1;
+                if (!is_bam) {
+                    qtext.resize(len);
+                    for (uint64_t i = 0; i < len; ++i) qtext[i] = (char)(newq[a + i] + 33);   // htsiter.cc:61-65
+                    if (!write_fastq_record(out, batch.fq_recs[r], qtext)) return 1;
+                    continue;
+                }
+                BamRecord &b = batch.bam_recs[r];                       // BamFile::recalibrate, htsiter.cc:11-34
+                if (set_oq) {
+                    qtext.resize(len);
+                    for (uint64_t i = 0; i < len; ++i) qtext[i] = (char)(b.qual()[i] + 33);
+                    int status = 0;
+                    if (!b.aux_update_string("OQ", qtext, status)) {
+                        std::cerr << "Tag data is corrupt. Repair the tags and try again." << std::endl;
+                        return 1;   // std::invalid_argument("Unable to update OQ tag.") in the reference
+                    }
+                }
+                uint8_t *q = b.qual();
+                if (b.reverse()) std::reverse_copy(newq.begin() + a, newq.begin() + a + len, q);
+                else std::copy(newq.begin() + a, newq.begin() + a + len, q);
+                if (!bam_out.write(b)) return 1;
             }
         }
+        if (batch.fatal) return 1;
         if (!out.close()) return 1;
     }
     kbbq_engine_destroy(e);

@@ -134,3 +134,117 @@ def test_cli_error_paths(tmp_path):
     # a genome length far too small for the data: the sampled filter overflows its false-positive gate (kbbq.cc:311-316)
     rc, out, err = run_cli(["-g", 30, "-c", 10, fq], {"KBBQ_SEED": "1"})
     assert rc != 0 and "false positive rate is too high" in err
+
+
+# ------------------------------------------------------------------ BAM (BASELINE.json configs[3]) ----
+import bamutil  # noqa: E402
+
+
+def bam_dataset(tmp_path, use_oq=False, **kw):
+    """Unaligned BAM with RG:Z (and OQ:Z) tags, about half of the records reverse-flagged: those store the
+    reverse complement of what was sequenced, qualities reversed (readutils.cc:36-39, htsiter.cc:27-31)."""
+    d = common.make_dataset(**kw)
+    n = len(d["off"]) - 1
+    rng = np.random.RandomState(kw.get("seed", 0))
+    off = d["off"].astype(np.int64)
+    groups = ["lane1", "lane2", "lane:3"]
+    seen, rg_index, recs = {}, [], []
+    seq_text = d["seq"].tobytes().decode()
+    for r in range(n):
+        s, q = seq_text[off[r]:off[r + 1]], d["qual"][off[r]:off[r + 1]]
+        flag = 1 | 4 | (128 if r & 1 else 64) | (16 if rng.rand() < 0.5 else 0)
+        rg = groups[(r // 3) % 3]
+        rg_index.append(seen.setdefault(rg, len(seen)))
+        stored_s, stored_q = (bamutil.as_sequenced(s, q, flag) if flag & 16 else (s, q))     # the mapping is an involution on ACGTN
+        tags = [("NM", "C", r % 200), ("RG", "Z", rg)]
+        if use_oq:
+            # the real qualities live in OQ; the record's own are something else entirely
+            tags.append(("OQ", "Z", "".join(chr(33 + int(x)) for x in stored_q)))
+            stored_q = np.full(len(s), 11, dtype=np.uint8)
+        elif r % 4 == 0:
+            tags.insert(1, ("OQ", "Z", "#" * len(s)))       # a stale OQ that --set-oq must overwrite in place
+        if r % 5 == 0:
+            tags.append(("XB", "BS", [r & 0xFFFF, 7]))
+        recs.append(dict(name="read%d" % (r // 2), flag=flag, seq=stored_s, qual=stored_q, tags=tags))
+    d["rg"] = np.array(rg_index, dtype=np.int32)
+    d["second"] = (np.arange(n) & 1).astype(np.uint8)
+    refs = [("chr1", d["genome_len"] - 1000), ("chr2", 1000)]
+    stream = bamutil.header("@HD\tVN:1.6\tSO:unsorted\n", refs) + b"".join(
+        bamutil.record(r["name"], r["flag"], r["seq"], r["qual"], r["tags"]) for r in recs)
+    path = tmp_path / "in.bam"
+    path.write_bytes(bamutil.bgzf_compress(stream, ragged_seed=5))
+    return d, recs, path, len(seen)
+
+
+@pytest.mark.parametrize("use_oq,set_oq", [(False, False), (False, True), (True, True)])
+def test_cli_recalibrates_bam(tmp_path, use_oq, set_oq):
+    d, recs, path, n_rg = bam_dataset(tmp_path, use_oq=use_oq, seed=77, genome_len=25000, coverage=24, n_per_million=3000, ragged=True,
+                                      extra_errors=100)
+    args = (["--use-oq"] if use_oq else []) + (["--set-oq"] if set_oq else []) + [path]
+    rc, out, err = run_cli(args, {"KBBQ_SEED": "4242"})
+    assert rc == 0, err
+    total = int(d["off"][-1])
+    coverage = total // d["genome_len"]
+    for line in ("Estimating genome length", "Genome length is %d bp." % d["genome_len"], "Estimated coverage: %d" % coverage):   # kbbq.cc:196-216
+        assert line in err, line
+    ora = common.run_oracle(dict(d, coverage=coverage), seed=4242, n_rg=n_rg)
+    text, refs, got = bamutil.parse(bamutil.bgzf_decompress(out))
+    assert text == "@HD\tVN:1.6\tSO:unsorted\n" and refs == [("chr1", d["genome_len"] - 1000), ("chr2", 1000)]
+    assert len(got) == len(recs)
+    off = d["off"].astype(np.int64)
+    changed = 0
+    for r, (src, g) in enumerate(zip(recs, got)):
+        want = ora["recal"][off[r]:off[r + 1]]
+        if src["flag"] & 16:
+            want = want[::-1]                                                  # htsiter.cc:27-31
+        assert np.array_equal(g["qual"], want), "read %d" % r
+        assert g["name"] == src["name"] and g["flag"] == src["flag"] and g["seq"] == src["seq"]
+        tags = list(src["tags"])
+        if set_oq:
+            oq = "".join(chr(33 + int(x)) for x in src["qual"])                # the record's stored qualities (htsiter.cc:12-17)
+            tags = [("OQ", "Z", oq) if t[0] == "OQ" else t for t in tags] if any(t[0] == "OQ" for t in tags) else tags + [("OQ", "Z", oq)]
+        assert g["aux"] == bamutil.aux_bytes(tags), "read %d" % r
+        changed += int((g["qual"] != src["qual"]).sum())
+    assert changed > 0
+
+
+def test_cli_bam_fixed_mode_and_errors(tmp_path):
+    d, recs, path, n_rg = bam_dataset(tmp_path, seed=78, genome_len=12000, coverage=20, read_len=100)
+    # the corrected file: same records, about 1 % of the stored bases changed
+    rng = np.random.RandomState(9)
+    fixed_recs, errors = [], []
+    for r in recs:
+        s = list(r["seq"])
+        flip = rng.rand(len(s)) < 0.01
+        for i in np.nonzero(flip)[0]:
+            s[i] = "ACGT"[("ACGT".find(s[i]) + 1) % 4] if s[i] in "ACGT" else "A"
+        fixed_recs.append(dict(r, seq="".join(s)))
+        errors.append(flip[::-1] if r["flag"] & 16 else flip)                  # in sequencing orientation
+    fixed = tmp_path / "fixed.bam"
+    fixed.write_bytes(bamutil.bgzf_compress(bamutil.header("", []) + b"".join(
+        bamutil.record(r["name"], r["flag"], r["seq"], r["qual"], r["tags"]) for r in fixed_recs)))
+    rc, out, err = run_cli(["--fixed", fixed, path])
+    assert rc == 0, err
+    alpha_ld, cov, approx = common.plan_parameters(d["genome_len"], 20, None)
+    o = common.pyoracle.Oracle(32, alpha_ld, 1, approx)
+    e = np.concatenate(errors).astype(np.uint8)
+    o.tally(d["seq"], d["qual"], d["off"], d["rg"], d["second"], e)
+    o.train()
+    want = o.recalibrate(d["seq"], d["qual"], d["off"], d["rg"], d["second"])
+    _, _, got = bamutil.parse(bamutil.bgzf_decompress(out))
+    off = d["off"].astype(np.int64)
+    for r, g in enumerate(got):
+        w = want[off[r]:off[r + 1]]
+        assert np.array_equal(g["qual"], w[::-1] if recs[r]["flag"] & 16 else w)
+    # no reference lengths in the header and no --genomelen
+    bare = tmp_path / "bare.bam"
+    bare.write_bytes(bamutil.bgzf_compress(bamutil.header("", []) + bamutil.record("r0", 4, "ACGT" * 10, [30] * 40, [("RG", "Z", "g")])))
+    rc, out, err = run_cli([bare])
+    assert rc != 0 and "Header does not contain genome information." in err
+    # a record without RG
+    bare.write_bytes(bamutil.bgzf_compress(bamutil.header("", [("c", 100)]) + bamutil.record("r0", 4, "ACGT" * 10, [30] * 40, [])))
+    rc, out, err = run_cli([bare])
+    assert rc != 0 and "Unable to read RG tag on read r0" in err and out == b""
+    bare.write_bytes(b"CRAM" + b"\0" * 40)
+    rc, out, err = run_cli([bare])
+    assert rc != 0 and "CRAM" in err
