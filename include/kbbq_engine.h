@@ -106,6 +106,8 @@ typedef struct kbbq_filter_info {
     uint32_t n_hash;          /* optimal_parameters.number_of_hashes */
     uint32_t n_salt;          /* max(n_hash, 2) */
     uint32_t salt[128];
+    uint64_t table_bytes;     /* size of the DEVICE bit array: n_blocks * 16 (the engine keeps the 128 bits of a
+                               * block the reference's patterns can reach, see kbbq_filter_device_table) */
 } kbbq_filter_info;
 
 /* ---- engine life cycle ------------------------------------------------ */
@@ -123,14 +125,22 @@ void *kbbq_engine_stream(kbbq_engine *e);
 const char *kbbq_last_error(void);
 
 int kbbq_filter_info_get(kbbq_engine *e, int which, kbbq_filter_info *out);
-/* Device address of a filter's bit array (n_blocks * 64 bytes), for collectives. */
+/* Device address of a filter's bit array, for collectives: kbbq_filter_info.table_bytes bytes in the ENGINE's
+ * layout.  The reference sets bit b (0..511) of a pattern in 64-bit word (b>>8)*4 + ((b>>3)&3) at bit b&63
+ * (get_vector_unit, bloom.hh:110-113,228), so only 16 bits of every word -- bytes w&3 and 4+(w&3) of word w --
+ * can ever be set; the engine stores those: block = 2 x u64, word w of the reference = 16-bit field w&3 of
+ * u64 w>>2 (low byte = byte w&3 of the word, high byte = byte 4+(w&3)).  Bitwise OR commutes with that
+ * mapping, so the multi-GPU exchange works on this array directly. */
 void *kbbq_filter_device_table(kbbq_engine *e, int which);
 /* Device address of the 8-byte insert counter of a filter. */
 void *kbbq_filter_device_counter(kbbq_engine *e, int which);
+/* The bit array / the pattern table in the REFERENCE's layout (n_blocks*8 resp. 65536*8 words of 64 bits,
+ * pattern_blocked_bf's table and patterns, bloom.hh:175-231), expanded from the device copies. */
 int kbbq_filter_download(kbbq_engine *e, int which, uint64_t *host_words, uint64_t n_words);
 int kbbq_filter_patterns_download(kbbq_engine *e, int which, uint64_t *host_words /* 65536*8 */);
-/* dst |= src over the whole bit array of a filter; src is a device buffer of the
- * same size (the OR step of the multi-GPU all-reduce; RCCL has no bitwise OR). */
+/* dst |= src over a range of a filter's device bit array; src is a device buffer in the same (engine)
+ * layout, offsets and counts in u64 words of it (the OR step of the multi-GPU all-reduce; RCCL has no
+ * bitwise OR). */
 int kbbq_filter_or_from(kbbq_engine *e, int which, const void *src_device, uint64_t word_offset, uint64_t n_words);
 /* dst |= src for two arbitrary 16-byte-aligned device buffers of n_words u64
  * (reducing the pieces received in the OR all-reduce). */
@@ -257,6 +267,10 @@ int kbbq_stats_get(kbbq_engine *e, uint64_t *out, int32_t n);
 /* Filter sizing, salts and pattern table (bloom_filter.hpp:108-160,467-549; bloom.hh:36-56,189-231). */
 int kbbq_host_filter_spec(uint64_t approx_kmers, double fpr, uint64_t bloom_seed, kbbq_filter_info *info,
                           uint64_t *patterns_out /* 65536*8 words or NULL */);
+/* Between the reference's 512-bit blocks (8 words) and the engine's 128-bit ones (2 words), see
+ * kbbq_filter_device_table.  Squeezing fails with KBBQ_ERANGE on a bit no pattern can set. */
+int kbbq_host_blocks_squeeze(const uint64_t *reference_words, uint64_t n_blocks, uint64_t *engine_words);
+int kbbq_host_blocks_expand(const uint64_t *engine_words, uint64_t n_blocks, uint64_t *reference_words);
 /* kbbq.cc:304-313 from the sampled filter's size and insert count; returns 1 when fpr > .15. */
 int kbbq_host_thresholds(int32_t k, uint64_t filter_bits, uint64_t inserted, uint32_t n_salt, const char *alpha_text,
                          int32_t *thresholds_out, double *fpr_out, char *p_text_out, size_t p_text_len);

@@ -42,7 +42,7 @@ class Reads(ctypes.Structure):
 class FilterInfo(ctypes.Structure):
     _fields_ = [("bits", c_u64), ("bits_unblocked", c_u64), ("n_blocks", c_u64), ("random_seed", c_u64),
                 ("inserted", c_u64), ("n_hash", ctypes.c_uint32), ("n_salt", ctypes.c_uint32),
-                ("salt", ctypes.c_uint32 * 128)]
+                ("salt", ctypes.c_uint32 * 128), ("table_bytes", c_u64)]
 
 
 class Covariates(ctypes.Structure):
@@ -105,6 +105,8 @@ SYMBOLS = {
     "kbbq_profile_reset": (ctypes.c_int, [c_vp]),
     "kbbq_stats_get": (ctypes.c_int, [c_vp, c_u64p, ctypes.c_int32]),
     "kbbq_host_filter_spec": (ctypes.c_int, [c_u64, ctypes.c_double, c_u64, ctypes.POINTER(FilterInfo), c_u64p]),
+    "kbbq_host_blocks_squeeze": (ctypes.c_int, [c_u64p, c_u64, c_u64p]),
+    "kbbq_host_blocks_expand": (ctypes.c_int, [c_u64p, c_u64, c_u64p]),
     "kbbq_host_thresholds": (ctypes.c_int, [ctypes.c_int32, c_u64, c_u64, ctypes.c_uint32, ctypes.c_char_p, c_i32p,
                                             ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_size_t]),
     "kbbq_host_train": (ctypes.c_int, [ctypes.POINTER(Covariates), ctypes.POINTER(Dq)]),

@@ -101,7 +101,7 @@ struct Corrector {
     __device__ __forceinline__ bool query(const Km &m) {   // Bloom::query, bloom.hh:398
         if (!kvalid(m)) return false;
         ++queries;
-        return bloom_query1(f, m.fw < m.rc ? m.fw : m.rc);
+        return bloom_has(f, m.fw < m.rc ? m.fw : m.rc);
     }
 
     // get_next_trusted_char, bloom.cc:83-94; -1 = none

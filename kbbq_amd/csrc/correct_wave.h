@@ -148,12 +148,12 @@ struct WaveCorrector {
         p.fw = rev2(w) >> (64 - 2 * K.k);
         return p;
     }
-    // Bloom::query for one k-mer per lane (all 64 lanes call together)
+    // Bloom::query for one k-mer per lane
     __device__ __forceinline__ bool ask(bool active, const Pair &p) {
         const bool go = active && p.valid;
         const uint64_t key = p.fw < p.rc ? p.fw : p.rc;
         queries += __popcll(__ballot(go));
-        return bloom_coop<false, 4>(f, go, block_of(f, key), pattern_of(f, key)) && go;
+        return go && bloom_has(f, key);
     }
 
     // trusted mask of the working sequence for k-mer starts in [lo, lo+n-k]

@@ -80,11 +80,20 @@ __device__ __forceinline__ uint32_t hash_ap8(uint64_t key, uint32_t h) {
     return h;
 }
 
+// The filter in the engine's layout.  The reference's pattern generator sends sampled bit number b
+// (0..511) to 64-bit word (b>>8)*4 + ((b>>3)&3) and to bit b&63 of that word (get_vector_unit,
+// bloom.hh:110-113,228): bits 3-4 of the bit index always equal the word's unit number, so every
+// 64-bit word of a pattern -- and therefore of the table, which only ever receives ORs of patterns --
+// uses just 16 of its bits, 128 of the 512 in a block.  The engine stores exactly those: a block and a
+// pattern are 128 bits (two u64; word w of the reference is the 16-bit field w&3 of u64 w>>2, field bit
+// c = reference bit ((c>>3)<<5) | ((w&3)<<3) | (c&7)).  One lane fetches a whole block with one 16-byte
+// load, the pattern table is 1 MiB and stays in L2, the filters are a quarter of the reference's size.
+// kbbq_filter_download expands to the reference layout (host_model.h: expand_block).
 struct FiltDev {
-    uint64_t *table;           // n_blocks x 8 words
-    const uint64_t *patterns;  // 65536 x 8 words
+    ulonglong2 *table;           // n_blocks x 16 bytes
+    const ulonglong2 *patterns;  // 65536 x 16 bytes
     uint64_t n_blocks;
-    uint64_t mod_magic;        // 2^64 / n_blocks + 1 (fastmod), 0 when n_blocks >= 2^32
+    uint64_t mod_magic;          // 2^64 / n_blocks + 1 (fastmod), 0 when n_blocks >= 2^32
     uint32_t salt0, salt1;
 };
 
@@ -100,96 +109,28 @@ __device__ __forceinline__ uint32_t pattern_of(const FiltDev &f, uint64_t key) {
     return hash_ap8(key, f.salt1) & 0xFFFFu;
 }
 
-// The cooperative Bloom access.  A wavefront holds one k-mer per lane (active, blk, pat); the 64-byte
-// block and the 64-byte pattern of every active k-mer are fetched by a GROUP of lanes so that each
-// block is exactly one fully used 64-byte request (tools/probe_hbm: only such shapes reach the chip's
-// random-64-byte ceiling):
-//   LANES = 8: eight lanes x 8 bytes, 8 rounds of 8 k-mers.  One atomic request per inserted block:
-//              used by the kernels that insert.
-//   LANES = 4: four lanes x 16 bytes, 4 rounds of 16 k-mers: half the shuffles and ballots, shorter
-//              dependent chain: used by the latency-bound correction walk.
-// Returns, in the OWNING lane, whether the filter contained the pattern before this call
-// (pattern_blocked_bf::contains, bloom.hh:276-292).  With INSERT the missing bits are OR-ed in
-// atomically (pattern_blocked_bf::insert, bloom.hh:255-267); a block that already holds the pattern is
-// not written at all, which is legal because bits are only ever set.
-// ALL 64 LANES MUST CALL THIS TOGETHER (never behind a short-circuit || or &&).
-template <bool INSERT, int LANES = 8>
-__device__ __forceinline__ bool bloom_coop(const FiltDev &f, bool active, uint32_t blk, uint32_t pat) {
-    const int lane = threadIdx.x & 63;
-    const unsigned long long live = __ballot(active);
-    const uint32_t pa = pat | ((uint32_t)active << 16);   // pattern index and the active flag travel in one shuffle
-    bool contained = false;
-    if constexpr (LANES == 8) {
-        const int sub = lane & 7, grp = lane >> 3;
-        uint64_t tv[8], pv[8];
-        uint32_t bb[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            tv[j] = 0;
-            pv[j] = 0;
-            bb[j] = 0;
-            if (((live >> (8 * j)) & 0xFFull) == 0) continue;   // wave-uniform: nobody owns a k-mer in this round
-            const int src = j * 8 + grp;
-            bb[j] = __shfl(blk, src);
-            const uint32_t q = __shfl(pa, src);
-            const uint32_t p = q & 0xFFFFu;
-            if (q >> 16) {
-                pv[j] = f.patterns[(uint64_t)p * 8 + sub];
-                tv[j] = f.table[(uint64_t)bb[j] * 8 + sub];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint64_t miss = pv[j] & ~tv[j];
-            if (INSERT) {
-                if (miss) atomicOr((unsigned long long *)&f.table[(uint64_t)bb[j] * 8 + sub], (unsigned long long)miss);
-            }
-            const unsigned long long bal = __ballot(miss != 0);
-            if (grp == j) contained = ((bal >> (8 * sub)) & 0xFFull) == 0;
-        }
-    } else {
-        const int sub = lane & 3, grp = lane >> 2;
-        ulonglong2 tv[4], pv[4];
-        uint32_t bb[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            tv[j] = make_ulonglong2(0, 0);
-            pv[j] = make_ulonglong2(0, 0);
-            bb[j] = 0;
-            if (((live >> (16 * j)) & 0xFFFFull) == 0) continue;
-            const int src = j * 16 + grp;
-            bb[j] = __shfl(blk, src);
-            const uint32_t q = __shfl(pa, src);
-            const uint32_t p = q & 0xFFFFu;
-            if (q >> 16) {
-                pv[j] = *reinterpret_cast<const ulonglong2 *>(f.patterns + (uint64_t)p * 8 + sub * 2);
-                tv[j] = *reinterpret_cast<const ulonglong2 *>(f.table + (uint64_t)bb[j] * 8 + sub * 2);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint64_t mx = pv[j].x & ~tv[j].x, my = pv[j].y & ~tv[j].y;
-            if (INSERT) {
-                if (mx) atomicOr((unsigned long long *)&f.table[(uint64_t)bb[j] * 8 + sub * 2], (unsigned long long)mx);
-                if (my) atomicOr((unsigned long long *)&f.table[(uint64_t)bb[j] * 8 + sub * 2 + 1], (unsigned long long)my);
-            }
-            const unsigned long long bal = __ballot((mx | my) != 0);
-            if ((lane >> 4) == j) contained = ((bal >> (4 * (lane & 15))) & 0xFull) == 0;
-        }
-    }
-    return contained;
+// One lane, one k-mer.  tools/probe_hbm: 64 lanes x one random 16-byte block each reach the chip's
+// random-access ceiling (about 50 G blocks/s) with a single load in flight per lane.
+// pattern_blocked_bf::contains, bloom.hh:276-292
+__device__ __forceinline__ bool bloom_has(const FiltDev &f, uint32_t blk, uint32_t pat) {
+    const ulonglong2 t = f.table[blk];
+    const ulonglong2 p = f.patterns[pat];
+    return ((p.x & ~t.x) | (p.y & ~t.y)) == 0;
 }
-
-// One lane, one k-mer: 64-byte block + 64-byte pattern as four 16-byte loads each.
-__device__ __forceinline__ bool bloom_query1(const FiltDev &f, uint64_t key) {
-    const uint32_t blk = block_of(f, key), pat = pattern_of(f, key);
-    const ulonglong2 *t = reinterpret_cast<const ulonglong2 *>(f.table + (uint64_t)blk * 8);
-    const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(f.patterns + (uint64_t)pat * 8);
-    const ulonglong2 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
-    const ulonglong2 p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3];
-    const uint64_t miss = (p0.x & ~t0.x) | (p0.y & ~t0.y) | (p1.x & ~t1.x) | (p1.y & ~t1.y) | (p2.x & ~t2.x) |
-                          (p2.y & ~t2.y) | (p3.x & ~t3.x) | (p3.y & ~t3.y);
-    return miss == 0;
+__device__ __forceinline__ bool bloom_has(const FiltDev &f, uint64_t key) {
+    return bloom_has(f, block_of(f, key), pattern_of(f, key));
+}
+// pattern_blocked_bf::insert, bloom.hh:255-267; returns whether the pattern was already there.  Only the
+// missing bits are OR-ed in, so a block that already holds the pattern is not written at all (legal
+// because bits are only ever set).
+__device__ __forceinline__ bool bloom_put(const FiltDev &f, uint32_t blk, uint32_t pat) {
+    const ulonglong2 t = f.table[blk];
+    const ulonglong2 p = f.patterns[pat];
+    const uint64_t mx = p.x & ~t.x, my = p.y & ~t.y;
+    unsigned long long *w = reinterpret_cast<unsigned long long *>(f.table + blk);
+    if (mx) atomicOr(w, (unsigned long long)mx);
+    if (my) atomicOr(w + 1, (unsigned long long)my);
+    return (mx | my) == 0;
 }
 
 // OR the 64 flags of one chunk (bit l = position `first` + l of the batch) into a shared bit array

@@ -141,16 +141,14 @@ __device__ __forceinline__ uint64_t kmer_base(const uint64_t *kofs, uint64_t r, 
 }
 
 // ---- passes 1b and 2b: insert the marked k-mers of every read into a filter --------------
-// One wavefront per read, one lane per k-mer start.  BY_BASE = false: `mask` is the sampler's draw
-// mask, one bit per k-mer position in file order (pass 1: insert where drawn and valid, and record
-// that in hint_sampled).  BY_BASE = true: `mask` has one bit per base of the batch and already
-// means "insert the k-mer starting here" (pass 2: the decisions of k_infer).
+// One wavefront per read, one lane per k-mer start, one 128-bit block per lane.  BY_BASE = false:
+// `mask` is the sampler's draw mask, one bit per k-mer position in file order (pass 1: insert where
+// drawn and valid, and record that in hint_sampled).  BY_BASE = true: `mask` has one bit per base of
+// the batch and already means "insert the k-mer starting here" (pass 2: the decisions of k_infer).
 template <int NW, bool BY_BASE>
 __global__ void __launch_bounds__(256) k_insert_marked(ReadsDev R, KParams K, FiltDev F, const uint64_t *mask,
                                                         const uint64_t *kofs, unsigned long long *inserted) {
-    __shared__ uint2 pack[4][64];
     const int lane = threadIdx.x & 63;
-    uint2 *slots = pack[threadIdx.x >> 6];
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     unsigned long long mine = 0;
@@ -160,41 +158,40 @@ __global__ void __launch_bounds__(256) k_insert_marked(ReadsDev R, KParams K, Fi
         if (len < (uint32_t)K.k) continue;
         const int nk = (int)len - K.k + 1;
         const uint64_t kb = BY_BASE ? off : kmer_base(kofs, r, R.read_len, K.k);
-        // Only ~alpha of the positions are sampled: the sampled k-mers of the read are first packed into
-        // the low lanes (through a per-wave LDS row), so the cooperative insert runs ceil(count/8) rounds
-        // instead of 8 per 64-position chunk.
-        uint32_t q_blk = 0, q_pat = 0;
-        int filled = 0;
-#pragma unroll 1
-        for (int c = 0; c * 64 < nk; ++c) {
-            const int s = c * 64 + lane;
-            bool take = false;
-            uint32_t blk = 0, pat = 0;
-            if (s < nk) {
-                const uint64_t o = kb + s;
-                const bool drawn = (mask[o >> 6] >> (o & 63)) & 1;
-                bool valid;
-                const uint64_t key = kmer_at(R, K, off + s, valid);
-                take = drawn && (BY_BASE || valid);
-                blk = block_of(F, key);
-                pat = pattern_of(F, key);
+        bool take[NW];
+        uint32_t blk[NW], pat[NW];
+#pragma unroll
+        for (int c = 0; c < NW; ++c) {
+            take[c] = false; blk[c] = 0; pat[c] = 0;
+            if (c * 64 < nk) {
+                const int s = c * 64 + lane;
+                if (s < nk) {
+                    const uint64_t o = kb + s;
+                    const bool drawn = (mask[o >> 6] >> (o & 63)) & 1;
+                    bool valid;
+                    const uint64_t key = kmer_at(R, K, off + s, valid);
+                    take[c] = drawn && (BY_BASE || valid);
+                    blk[c] = block_of(F, key);
+                    pat[c] = pattern_of(F, key);
+                }
+                const unsigned long long bal = __ballot(take[c]);
+                if (!BY_BASE && R.hint_sampled) or_bits64(R.hint_sampled, off + (uint64_t)c * 64, bal, lane);
+                mine += __popcll(bal);
             }
-            const unsigned long long bal = __ballot(take);
-            const int cnt = __popcll(bal);
-            if (!BY_BASE && R.hint_sampled) or_bits64(R.hint_sampled, off + (uint64_t)c * 64, bal, lane);
-            if (filled + cnt > 64) {
-                bloom_coop<true>(F, lane < filled, q_blk, q_pat);
-                filled = 0;
-            }
-            const int slot = filled + __popcll(bal & ((1ULL << lane) - 1));
-            if (take) slots[slot] = make_uint2(blk, pat);
-            __builtin_amdgcn_wave_barrier();
-            if (lane >= filled && lane < filled + cnt) { const uint2 v = slots[lane]; q_blk = v.x; q_pat = v.y; }
-            __builtin_amdgcn_wave_barrier();
-            filled += cnt;
-            mine += cnt;
         }
-        if (filled) bloom_coop<true>(F, lane < filled, q_blk, q_pat);
+        // all block and pattern loads of the read are issued before the first is used
+        ulonglong2 t[NW], p[NW];
+#pragma unroll
+        for (int c = 0; c < NW; ++c)
+            if (take[c]) { t[c] = F.table[blk[c]]; p[c] = F.patterns[pat[c]]; }
+#pragma unroll
+        for (int c = 0; c < NW; ++c)
+            if (take[c]) {
+                const uint64_t mx = p[c].x & ~t[c].x, my = p[c].y & ~t[c].y;
+                unsigned long long *w = reinterpret_cast<unsigned long long *>(F.table + blk[c]);
+                if (mx) atomicOr(w, (unsigned long long)mx);
+                if (my) atomicOr(w + 1, (unsigned long long)my);
+            }
     }
     if (inserted && lane == 0 && mine) atomicAdd(inserted, mine);
 }
@@ -221,27 +218,35 @@ __global__ void __launch_bounds__(256) k_infer(ReadsDev R, KParams K, FiltDev S,
         if (len < (uint32_t)k) continue;   // engine-defined: the reference underflows size_t here
         const int L = (int)len, nk = L - k + 1;
         uint64_t P[NW], E[NW], V[NW];
+        // every lane's block and pattern loads go out before the first result is needed
+        bool valid[NW], known[NW];
+        ulonglong2 t[NW], p[NW];
 #pragma unroll
         for (int c = 0; c < NW; ++c) {
             P[c] = 0; E[c] = 0; V[c] = 0;
-            if (c * 64 < nk) {
-                const int s = c * 64 + lane;
-                bool valid = false;
-                uint32_t blk = 0, pat = 0;
-                bool known = false;   // this read put the k-mer into the sampled filter itself (pass 1)
-                if (s < nk) {
-                    const uint64_t key = kmer_at(R, K, off + s, valid);
-                    blk = block_of(S, key);
-                    pat = pattern_of(S, key);
-                    if (R.hint_sampled) {
-                        const uint64_t g = off + s;
-                        known = (R.hint_sampled[g >> 5] >> (g & 31)) & 1;
-                    }
+            valid[c] = false;
+            known[c] = false;   // this read put the k-mer into the sampled filter itself (pass 1)
+            t[c] = make_ulonglong2(0, 0);
+            p[c] = make_ulonglong2(0, 0);
+            const int s = c * 64 + lane;
+            if (s < nk) {
+                const uint64_t key = kmer_at(R, K, off + s, valid[c]);
+                if (R.hint_sampled) {
+                    const uint64_t g = off + s;
+                    known[c] = (R.hint_sampled[g >> 5] >> (g & 31)) & 1;
                 }
-                const bool looked = bloom_coop<false>(S, valid && !known, blk, pat);   // every lane must take part
-                const bool present = known || (looked && valid);
+                if (valid[c] && !known[c]) {
+                    t[c] = S.table[block_of(S, key)];
+                    p[c] = S.patterns[pattern_of(S, key)];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NW; ++c) {
+            if (c * 64 < nk) {
+                const bool present = known[c] || (valid[c] && ((p[c].x & ~t[c].x) | (p[c].y & ~t[c].y)) == 0);
                 P[c] = __ballot(present);
-                V[c] = __ballot(valid);
+                V[c] = __ballot(valid[c]);
             }
         }
 #pragma unroll
@@ -297,25 +302,32 @@ __global__ void __launch_bounds__(256) k_scan_trusted(ReadsDev R, KParams K, Fil
         const int nk = (int)len - k + 1;
         uint64_t M[NW];
         int trusted = 0;
+        bool valid[NW], known[NW];
+        ulonglong2 t[NW], p[NW];
 #pragma unroll
         for (int c = 0; c < NW; ++c) {
             M[c] = 0;
-            if (c * 64 < nk) {
-                const int s = c * 64 + lane;
-                bool valid = false;
-                uint32_t blk = 0, pat = 0;
-                bool known = false;   // this read put the k-mer into the trusted filter itself (pass 2)
-                if (s < nk) {
-                    const uint64_t key = kmer_at(R, K, off + s, valid);
-                    blk = block_of(T, key);
-                    pat = pattern_of(T, key);
-                    if (R.hint_trusted) {
-                        const uint64_t g = off + s;
-                        known = (R.hint_trusted[g >> 5] >> (g & 31)) & 1;
-                    }
+            valid[c] = false;
+            known[c] = false;   // this read put the k-mer into the trusted filter itself (pass 2)
+            t[c] = make_ulonglong2(0, 0);
+            p[c] = make_ulonglong2(0, 0);
+            const int s = c * 64 + lane;
+            if (s < nk) {
+                const uint64_t key = kmer_at(R, K, off + s, valid[c]);
+                if (R.hint_trusted) {
+                    const uint64_t g = off + s;
+                    known[c] = (R.hint_trusted[g >> 5] >> (g & 31)) & 1;
                 }
-                const bool looked = bloom_coop<false>(T, valid && !known, blk, pat);   // every lane must take part
-                const bool ok = known || (looked && valid);
+                if (valid[c] && !known[c]) {
+                    t[c] = T.table[block_of(T, key)];
+                    p[c] = T.patterns[pattern_of(T, key)];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NW; ++c) {
+            if (c * 64 < nk) {
+                const bool ok = known[c] || (valid[c] && ((p[c].x & ~t[c].x) | (p[c].y & ~t[c].y)) == 0);
                 M[c] = __ballot(ok);
                 trusted += __popcll(M[c]);
             }
@@ -444,7 +456,7 @@ __global__ void __launch_bounds__(256) k_fix_single(ReadsDev R, KParams K, FiltD
                 const uint64_t key = key_of(st, p, y, valid);
                 const bool go = act && valid;
                 q_total += __popcll(__ballot(go));
-                const bool t = bloom_coop<false>(T, go, block_of(T, key), pattern_of(T, key)) && go;
+                const bool t = go && bloom_has(T, key);
                 alive = (int)(__ballot(t) & 0xFFFF);
             }
             // round 2: every covering k-mer of the survivors, two (run, alternative) pairs per lookup
@@ -463,7 +475,7 @@ __global__ void __launch_bounds__(256) k_fix_single(ReadsDev R, KParams K, FiltD
                 const uint64_t key = key_of(act ? st : z0, p, y, valid);
                 const bool go = act && valid;
                 q_total += __popcll(__ballot(go));
-                const bool t = bloom_coop<false>(T, go, block_of(T, key), pattern_of(T, key)) && go;
+                const bool t = go && bloom_has(T, key);
                 const unsigned long long bal = __ballot(t);
                 const int ra = a >> 2;
                 if (__popcll(bal & 0xFFFFFFFFULL) == pick(z1s, ra) - pick(z0s, ra) + 1) full += 1 << (3 * ra);
@@ -990,13 +1002,14 @@ __global__ void __launch_bounds__(256) k_synth(SynthDev S, uint64_t *bases, uint
 
 struct FilterHost {
     FilterSpec spec;
-    uint64_t *d_table = nullptr;
-    uint64_t *d_patterns = nullptr;
+    uint64_t *d_table = nullptr;      // n_blocks x 2 words: the engine's 128-bit blocks
+    uint64_t *d_patterns = nullptr;   // 65536 x 2 words
     unsigned long long *d_inserted = nullptr;
+    uint64_t table_bytes() const { return spec.n_blocks * kEngineBlockBytes; }
     FiltDev dev() const {
         FiltDev f;
-        f.table = d_table;
-        f.patterns = d_patterns;
+        f.table = reinterpret_cast<ulonglong2 *>(d_table);
+        f.patterns = reinterpret_cast<const ulonglong2 *>(d_patterns);
         f.n_blocks = spec.n_blocks;
         f.mod_magic = spec.n_blocks > 0xFFFFFFFFULL ? 0 : (~0ULL / spec.n_blocks + 1);
         f.salt0 = spec.salt[0];
@@ -1260,10 +1273,17 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
     CREATE_TRY(hipMemset(e->d_counters, 0, 64));
     for (int w = 0; w < 2; ++w) {
         FilterHost &f = e->filt[w];
-        CREATE_TRY(hipMalloc(&f.d_table, f.spec.n_blocks * 64));
-        CREATE_TRY(hipMalloc(&f.d_patterns, kNumPatterns * 64));
+        CREATE_TRY(hipMalloc(&f.d_table, f.table_bytes()));
+        CREATE_TRY(hipMalloc(&f.d_patterns, kNumPatterns * kEngineBlockBytes));
         CREATE_TRY(hipMalloc(&f.d_inserted, 8));
-        CREATE_TRY(hipMemcpy(f.d_patterns, f.spec.patterns.data(), kNumPatterns * 64, hipMemcpyHostToDevice));
+        std::vector<uint64_t> packed(kNumPatterns * 2);
+        for (uint64_t i = 0; i < kNumPatterns; ++i) {
+            if (!squeeze_block(&f.spec.patterns[i * 8], &packed[i * 2])) {
+                kbbq_engine_destroy(e);
+                return fail(KBBQ_ESTATE, "pattern %llu uses a bit outside the 128 the generator can reach", (unsigned long long)i);
+            }
+        }
+        CREATE_TRY(hipMemcpy(f.d_patterns, packed.data(), kNumPatterns * kEngineBlockBytes, hipMemcpyHostToDevice));
     }
     e->hist_cycle_words = (uint64_t)params->n_rg * kNQ * 2 * params->max_read_len * 2;
     e->hist_dinuc_words = (uint64_t)params->n_rg * kNQ * 16 * 2;
@@ -1306,7 +1326,7 @@ void kbbq_engine_destroy(kbbq_engine *e) {
 int kbbq_engine_reset(kbbq_engine *e) {
     if (!e) return fail(KBBQ_EINVAL, "null engine");
     for (int w = 0; w < 2; ++w) {
-        HIP_TRY(hipMemsetAsync(e->filt[w].d_table, 0, e->filt[w].spec.n_blocks * 64, e->stream));
+        HIP_TRY(hipMemsetAsync(e->filt[w].d_table, 0, e->filt[w].table_bytes(), e->stream));
         HIP_TRY(hipMemsetAsync(e->filt[w].d_inserted, 0, 8, e->stream));
     }
     HIP_TRY(hipMemsetAsync(e->d_hist, 0, (e->hist_cycle_words + e->hist_dinuc_words) * 8, e->stream));
@@ -1331,6 +1351,7 @@ int kbbq_filter_info_get(kbbq_engine *e, int which, kbbq_filter_info *out) {
     out->bits = s.bits;
     out->bits_unblocked = s.bits_unblocked;
     out->n_blocks = s.n_blocks;
+    out->table_bytes = e->filt[which].table_bytes();
     out->random_seed = s.random_seed;
     out->n_hash = s.n_hash;
     out->n_salt = s.n_salt;
@@ -1346,22 +1367,32 @@ void *kbbq_filter_device_counter(kbbq_engine *e, int which) { return e && which 
 
 int kbbq_filter_download(kbbq_engine *e, int which, uint64_t *host_words, uint64_t n_words) {
     if (!e || !host_words || which < 0 || which > 1) return fail(KBBQ_EINVAL, "bad argument");
-    if (n_words != e->filt[which].spec.n_blocks * 8) return fail(KBBQ_EINVAL, "filter has %llu words", (unsigned long long)e->filt[which].spec.n_blocks * 8);
+    const uint64_t n_blocks = e->filt[which].spec.n_blocks;
+    if (n_words != n_blocks * 8) return fail(KBBQ_EINVAL, "filter has %llu words", (unsigned long long)n_blocks * 8);
     int rc = sync_engine(e);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(host_words, e->filt[which].d_table, n_words * 8, hipMemcpyDeviceToHost));
+    // the device holds 128-bit blocks; the caller gets the reference's 512-bit ones
+    const uint64_t chunk = 1 << 20;
+    std::vector<uint64_t> packed(chunk * 2);
+    for (uint64_t b0 = 0; b0 < n_blocks; b0 += chunk) {
+        const uint64_t nb = std::min(chunk, n_blocks - b0);
+        HIP_TRY(hipMemcpy(packed.data(), e->filt[which].d_table + b0 * 2, nb * kEngineBlockBytes, hipMemcpyDeviceToHost));
+        for (uint64_t b = 0; b < nb; ++b) expand_block(&packed[b * 2], host_words + (b0 + b) * 8);
+    }
     return KBBQ_OK;
 }
 
 int kbbq_filter_patterns_download(kbbq_engine *e, int which, uint64_t *host_words) {
     if (!e || !host_words || which < 0 || which > 1) return fail(KBBQ_EINVAL, "bad argument");
-    HIP_TRY(hipMemcpy(host_words, e->filt[which].d_patterns, kNumPatterns * 64, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> packed(kNumPatterns * 2);
+    HIP_TRY(hipMemcpy(packed.data(), e->filt[which].d_patterns, kNumPatterns * kEngineBlockBytes, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < kNumPatterns; ++i) expand_block(&packed[i * 2], host_words + i * 8);
     return KBBQ_OK;
 }
 
 int kbbq_filter_or_from(kbbq_engine *e, int which, const void *src_device, uint64_t word_offset, uint64_t n_words) {
     if (!e || !src_device || which < 0 || which > 1) return fail(KBBQ_EINVAL, "bad argument");
-    const uint64_t total = e->filt[which].spec.n_blocks * 8;
+    const uint64_t total = e->filt[which].spec.n_blocks * 2;   // words of the engine's 128-bit blocks
     if (word_offset > total || n_words > total - word_offset || (word_offset & 1)) return fail(KBBQ_EINVAL, "range outside the filter");
     if (!n_words) return KBBQ_OK;
     Timed t(e, "k_or_words");
@@ -1991,9 +2022,24 @@ int kbbq_host_filter_spec(uint64_t approx_kmers, double fpr, uint64_t bloom_seed
         return fail(KBBQ_EINVAL, "Error: Invalid bloom filter parameters. Adjust parameters and try again.");
     memset(info, 0, sizeof *info);
     info->bits = s.bits; info->bits_unblocked = s.bits_unblocked; info->n_blocks = s.n_blocks;
+    info->table_bytes = s.n_blocks * kEngineBlockBytes;
     info->random_seed = s.random_seed; info->n_hash = s.n_hash; info->n_salt = s.n_salt;
     for (uint32_t i = 0; i < s.n_salt; ++i) info->salt[i] = s.salt[i];
     if (patterns_out) memcpy(patterns_out, s.patterns.data(), kNumPatterns * 64);
+    return KBBQ_OK;
+}
+
+int kbbq_host_blocks_squeeze(const uint64_t *reference_words, uint64_t n_blocks, uint64_t *engine_words) {
+    if (!reference_words || !engine_words) return fail(KBBQ_EINVAL, "null argument");
+    for (uint64_t b = 0; b < n_blocks; ++b)
+        if (!squeeze_block(reference_words + b * 8, engine_words + b * 2))
+            return fail(KBBQ_ERANGE, "block %llu has a bit no pattern can set", (unsigned long long)b);
+    return KBBQ_OK;
+}
+
+int kbbq_host_blocks_expand(const uint64_t *engine_words, uint64_t n_blocks, uint64_t *reference_words) {
+    if (!reference_words || !engine_words) return fail(KBBQ_EINVAL, "null argument");
+    for (uint64_t b = 0; b < n_blocks; ++b) expand_block(engine_words + b * 2, reference_words + b * 8);
     return KBBQ_OK;
 }
 

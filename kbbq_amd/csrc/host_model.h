@@ -33,6 +33,29 @@ struct FilterSpec {
     std::vector<uint64_t> patterns;  // 65536 x 8 words
 };
 
+// The engine's 128-bit form of a 512-bit block or pattern (device_common.h: FiltDev).  Word w of the
+// reference only ever uses the 16 bits whose index has bits 3-4 equal to w&3 (get_vector_unit,
+// bloom.hh:110-113,228): bytes w&3 and 4+(w&3) of the word.
+constexpr uint64_t kEngineBlockBytes = 16;
+inline uint64_t expand_field(uint16_t f, int unit) {
+    return ((uint64_t)(f & 0xFF) << (8 * unit)) | ((uint64_t)(f >> 8) << (32 + 8 * unit));
+}
+inline void expand_block(const uint64_t in[2], uint64_t out[8]) {
+    for (int w = 0; w < 8; ++w) out[w] = expand_field((uint16_t)(in[w >> 2] >> (16 * (w & 3))), w & 3);
+}
+// false if the block has a bit the engine's form cannot hold (never the case for a table built from patterns)
+inline bool squeeze_block(const uint64_t in[8], uint64_t out[2]) {
+    out[0] = out[1] = 0;
+    bool exact = true;
+    for (int w = 0; w < 8; ++w) {
+        const int unit = w & 3;
+        const uint16_t f = (uint16_t)(((in[w] >> (8 * unit)) & 0xFF) | (((in[w] >> (32 + 8 * unit)) & 0xFF) << 8));
+        exact = exact && expand_field(f, unit) == in[w];
+        out[w >> 2] |= (uint64_t)f << (16 * unit);
+    }
+    return exact;
+}
+
 // false when the parameters are ones the reference rejects (bloom.cc:18-21)
 bool make_filter_spec(uint64_t projected, double fpr, uint64_t seed, FilterSpec &out);
 

@@ -167,7 +167,7 @@ class EnginePeer:
 
     def table_tensor(self, which):
         info = self.e.filter_info(which)
-        return self._dt(self.e.L.kbbq_filter_device_table(self.e.h, which), info["n_blocks"] * 64, torch.int64,
+        return self._dt(self.e.L.kbbq_filter_device_table(self.e.h, which), info["table_bytes"], torch.int64,
                         self.e.params.device)
 
     def or_into(self, dst, src):

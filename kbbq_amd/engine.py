@@ -138,7 +138,8 @@ class Engine:
     def filter_info(self, which):
         fi = _lib.FilterInfo()
         _lib.check(self.L.kbbq_filter_info_get(self.h, which, ctypes.byref(fi)))
-        return dict(bits=fi.bits, bits_unblocked=fi.bits_unblocked, n_blocks=fi.n_blocks, random_seed=fi.random_seed,
+        return dict(bits=fi.bits, bits_unblocked=fi.bits_unblocked, n_blocks=fi.n_blocks, table_bytes=fi.table_bytes,
+                    random_seed=fi.random_seed,
                     inserted=fi.inserted, nhash=fi.n_hash, nsalt=fi.n_salt,
                     salts=np.array(fi.salt[:fi.n_salt], dtype=np.uint32))
 

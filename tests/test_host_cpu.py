@@ -243,3 +243,46 @@ def test_shard_ranges_partition_the_reads():
             cover.append((a, b))
         assert cover[0][0] == 0 and cover[-1][1] == n_reads
         assert all(cover[i][1] == cover[i + 1][0] for i in range(n - 1))
+
+
+def test_engine_block_layout_holds_everything_the_reference_can_set():
+    """The engine keeps 128 of the 512 bits of a block (include/kbbq_engine.h: kbbq_filter_device_table):
+    every pattern of both pattern tables, and every table the oracle builds, must survive squeeze -> expand
+    unchanged, and a bit outside the reachable set must be refused."""
+    L = _lib.lib()
+    info = _lib.FilterInfo()
+    for fpr in (0.01, 0.0005):
+        pat = np.zeros(65536 * 8, dtype=np.uint64)
+        assert L.kbbq_host_filter_spec(700000, fpr, _lib.DEFAULT_BLOOM_SEED, ctypes.byref(info), pat.ctypes.data_as(_lib.c_u64p)) == 0
+        assert info.table_bytes == info.n_blocks * 16
+        small = np.zeros(65536 * 2, dtype=np.uint64)
+        assert L.kbbq_host_blocks_squeeze(pat.ctypes.data_as(_lib.c_u64p), 65536, small.ctypes.data_as(_lib.c_u64p)) == 0
+        back = np.zeros_like(pat)
+        assert L.kbbq_host_blocks_expand(small.ctypes.data_as(_lib.c_u64p), 65536, back.ctypes.data_as(_lib.c_u64p)) == 0
+        assert np.array_equal(back, pat)
+        # 512 sampled bit numbers fold 4-to-1 onto 128 places, so some patterns have fewer than n_salt bits
+        assert 65536 * 2 < int(np.unpackbits(small.view(np.uint8)).sum()) == int(np.unpackbits(pat.view(np.uint8)).sum()) < 65536 * info.n_salt
+    # the bit positions: word w keeps bytes w&3 and 4+(w&3)
+    one = np.zeros(8, dtype=np.uint64)
+    out = np.zeros(2, dtype=np.uint64)
+    for w in range(8):
+        for bit in range(64):
+            one[:] = 0
+            one[w] = np.uint64(1) << np.uint64(bit)
+            rc = L.kbbq_host_blocks_squeeze(one.ctypes.data_as(_lib.c_u64p), 1, out.ctypes.data_as(_lib.c_u64p))
+            reachable = ((bit >> 3) & 3) == (w & 3)
+            assert rc == (0 if reachable else -34), (w, bit)
+            if reachable:
+                c = ((bit >> 5) << 3) | (bit & 7)
+                assert int(out[w >> 2]) == 1 << (16 * (w & 3) + c) and int(out[1 - (w >> 2)]) == 0
+    # an oracle run's tables
+    import common
+    d = common.make_dataset(seed=3, genome_len=5000, coverage=20, read_len=100)
+    ora = common.run_oracle(d)
+    for key in ("sampled_table", "trusted_table"):
+        t = ora[key]
+        small = np.zeros(len(t) // 4, dtype=np.uint64)
+        assert L.kbbq_host_blocks_squeeze(t.ctypes.data_as(_lib.c_u64p), len(t) // 8, small.ctypes.data_as(_lib.c_u64p)) == 0
+        back = np.zeros_like(t)
+        L.kbbq_host_blocks_expand(small.ctypes.data_as(_lib.c_u64p), len(t) // 8, back.ctypes.data_as(_lib.c_u64p))
+        assert np.array_equal(back, t) and t.any()

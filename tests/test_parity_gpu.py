@@ -124,8 +124,9 @@ def test_device_resident_batches_match_host_batches():
     assert np.array_equal(out.cpu().numpy()[:hb.n_bases], host_run["recal"])
     # filters are visible to torch without a copy (what the multi-GPU exchange relies on)
     info = e.filter_info(1)
-    t = device_tensor(e.L.kbbq_filter_device_table(e.h, 1), info["n_blocks"] * 64, torch.int64)
-    assert np.array_equal(t.cpu().numpy().view(np.uint64), host_run["trusted_table"])
+    assert info["table_bytes"] == info["n_blocks"] * 16          # the engine's 128-bit blocks
+    t = device_tensor(e.L.kbbq_filter_device_table(e.h, 1), info["table_bytes"], torch.int64)
+    assert np.array_equal(expand_blocks(t.cpu().numpy().view(np.uint64)), host_run["trusted_table"])
     db.free()
     e.close()
 
@@ -175,6 +176,15 @@ def test_device_pattern_tables_equal_the_oracle():
     e.close()
 
 
+def expand_blocks(engine_words):
+    """The engine's 128-bit blocks as the reference's 512-bit ones (include/kbbq_engine.h: kbbq_filter_device_table)."""
+    engine_words = np.ascontiguousarray(engine_words, dtype=np.uint64)
+    out = np.zeros(len(engine_words) * 4, dtype=np.uint64)
+    _lib.check(_lib.lib().kbbq_host_blocks_expand(engine_words.ctypes.data_as(_lib.c_u64p), len(engine_words) // 2,
+                                                  out.ctypes.data_as(_lib.c_u64p)))
+    return out
+
+
 def test_or_kernels_of_the_exchange_step():
     """kbbq_device_or / kbbq_device_or_pieces / kbbq_filter_or_from: the reduce step of the OR all-reduce."""
     import torch
@@ -197,11 +207,12 @@ def test_or_kernels_of_the_exchange_step():
     assert torch.equal(a, recv[:n] | recv[n:2 * n])
     # into the filter itself
     info = e.filter_info(0)
-    words = info["n_blocks"] * 8
-    src = torch.randint(0, 2 ** 62, (words,), dtype=torch.int64, generator=g).cuda()
+    words = info["table_bytes"] // 8
+    src = torch.randint(-2 ** 62, 2 ** 62, (words,), dtype=torch.int64, generator=g).cuda()
     torch.cuda.synchronize()
     _lib.check(e.L.kbbq_filter_or_from(e.h, 0, src.data_ptr(), 0, words))
-    assert np.array_equal(e.filter_table(0), src.cpu().numpy().view(np.uint64))
+    assert np.array_equal(e.filter_table(0), expand_blocks(src.cpu().numpy().view(np.uint64)))
+    assert e.L.kbbq_filter_or_from(e.h, 0, src.data_ptr(), 2, words) == -22      # past the end
     e.close()
 
 
