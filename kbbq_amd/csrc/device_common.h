@@ -133,6 +133,60 @@ __device__ __forceinline__ bool bloom_put(const FiltDev &f, uint32_t blk, uint32
     return (mx | my) == 0;
 }
 
+// ---- per-wave staging of one read's packed words in LDS -------------------------------------------
+// The streaming kernels handle one read per wavefront.  Instead of every lane fetching its own
+// unaligned 64-bit windows from global memory (four dependent round trips per 64 k-mers), the wave
+// loads the read's words once -- one u64 per lane, next read's words in flight while this one is
+// processed -- parks them in its LDS slice and every lane cuts its windows out of LDS with
+// v_alignbit.  Streams: 2-bit bases, N mask, the pass's hint bits, one extra 1-bit stream.
+template <int NW>
+struct Stage {
+    static constexpr int NB = 2 * NW + 2;   // u64 words: NW*64 bases at any alignment + the window's spill word
+    static constexpr int NM = NW + 2;       // same for a 1-bit-per-base stream
+    static constexpr int B = 0, M = NB, H = NB + NM, X = NB + 2 * NM;
+    static constexpr int WORDS = NB + 3 * NM;          // 48 for NW = 8: one word per lane
+    static constexpr int RES = 2 * NW + 4;             // u32: zero, 2*NW result dwords, zero, zero (+1 to stay even)
+    static constexpr int LDS_U32 = 2 * WORDS + 2 * RES;
+    static_assert(WORDS <= 64, "one staged word per lane");
+};
+
+template <int NW>
+__device__ __forceinline__ uint64_t stage_fetch(const ReadsDev &R, const uint64_t *hint, const uint64_t *extra,
+                                                uint64_t extra_pos, uint64_t extra_max, uint64_t off, int lane) {
+    using S = Stage<NW>;
+    const uint64_t *p = nullptr;
+    uint64_t idx = 0, mx = 0;
+    if (lane < S::M) { p = R.bases; idx = (off >> 5) + lane; mx = R.n_bases / 32 + 1; }
+    else if (lane < S::H) { p = R.nmask; idx = (off >> 6) + (lane - S::M); mx = R.n_bases / 64 + 1; }
+    else if (lane < S::X) { p = hint; idx = (off >> 6) + (lane - S::H); mx = R.n_bases / 64 + 1; }
+    else if (lane < S::WORDS) { p = extra; idx = (extra_pos >> 6) + (lane - S::X); mx = extra_max; }
+    return p ? p[idx < mx ? idx : mx] : 0;
+}
+
+// the LDS slice is dwords throughout (windows are cut with 32-bit funnel shifts)
+__device__ __forceinline__ void stage_store(uint32_t *slice, int lane, uint64_t word) {
+    reinterpret_cast<uint2 *>(slice)[lane] = make_uint2((uint32_t)word, (uint32_t)(word >> 32));
+}
+
+// 64 / 32 bits of an LDS bit stream (viewed as dwords) starting at bit `pos`
+__device__ __forceinline__ uint64_t lds_window64(const uint32_t *d, int pos) {
+    const int i = pos >> 5, sh = pos & 31;
+    const uint32_t a = d[i], b = d[i + 1], c = d[i + 2];
+    return (uint64_t)__builtin_amdgcn_alignbit(b, a, sh) | ((uint64_t)__builtin_amdgcn_alignbit(c, b, sh) << 32);
+}
+__device__ __forceinline__ uint32_t lds_window32(const uint32_t *d, int pos) {
+    const int i = pos >> 5, sh = pos & 31;
+    return __builtin_amdgcn_alignbit(d[i + 1], d[i], sh);
+}
+__device__ __forceinline__ uint32_t lds_bit(const uint32_t *d, int pos) { return (d[pos >> 5] >> (pos & 31)) & 1u; }
+
+// canonical key of the k bases in the low 2k bits of w (bloom::Kmer, bloom.hh:350-360; see kmer_at)
+__device__ __forceinline__ uint64_t canon_key(uint64_t w, const KParams &K) {
+    const uint64_t rc = (~w) & K.mask;
+    const uint64_t fw = rev2(w) >> (64 - 2 * K.k);
+    return fw < rc ? fw : rc;
+}
+
 // OR the 64 flags of one chunk (bit l = position `first` + l of the batch) into a shared bit array
 __device__ __forceinline__ void or_bits64(uint32_t *bits, uint64_t first, uint64_t word, int lane) {
     if (lane < 2) {

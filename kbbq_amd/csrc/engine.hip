@@ -147,43 +147,61 @@ __device__ __forceinline__ uint64_t kmer_base(const uint64_t *kofs, uint64_t r, 
 // the batch and already means "insert the k-mer starting here" (pass 2: the decisions of k_infer).
 template <int NW, bool BY_BASE>
 __global__ void __launch_bounds__(256) k_insert_marked(ReadsDev R, KParams K, FiltDev F, const uint64_t *mask,
-                                                        const uint64_t *kofs, unsigned long long *inserted) {
+                                                        uint64_t mask_words, const uint64_t *kofs,
+                                                        unsigned long long *inserted) {
+    using S = Stage<NW>;
+    __shared__ uint32_t lds[4][2 * S::WORDS];
     const int lane = threadIdx.x & 63;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t *L32 = lds[threadIdx.x >> 6];
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const int k = K.k;
     unsigned long long mine = 0;
+    uint64_t off = 0, kb = 0, word = 0;
+    uint32_t len = 0;
+    if (wave < R.n_reads) {
+        read_span(R, wave, off, len);
+        kb = BY_BASE ? off : kmer_base(kofs, wave, R.read_len, k);
+        word = stage_fetch<NW>(R, nullptr, mask, kb, mask_words - 1, off, lane);
+    }
     for (uint64_t r = wave; r < R.n_reads; r += n_waves) {
-        uint64_t off; uint32_t len;
-        read_span(R, r, off, len);
-        if (len < (uint32_t)K.k) continue;
-        const int nk = (int)len - K.k + 1;
-        const uint64_t kb = BY_BASE ? off : kmer_base(kofs, r, R.read_len, K.k);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < S::WORDS) stage_store(L32, lane, word);
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t cur = off;
+        const int o31 = (int)(off & 31), o63 = (int)(off & 63), x63 = (int)(kb & 63);
+        const int nk = (int)len - k + 1;
+        if (r + n_waves < R.n_reads) {   // the next read's words travel while this one is processed
+            read_span(R, r + n_waves, off, len);
+            kb = BY_BASE ? off : kmer_base(kofs, r + n_waves, R.read_len, k);
+            word = stage_fetch<NW>(R, nullptr, mask, kb, mask_words - 1, off, lane);
+        }
+        if (nk <= 0) continue;
+        // all block and pattern loads of the read are issued before the first is used
         bool take[NW];
-        uint32_t blk[NW], pat[NW];
+        uint32_t blk[NW];
+        ulonglong2 t[NW], p[NW];
 #pragma unroll
         for (int c = 0; c < NW; ++c) {
-            take[c] = false; blk[c] = 0; pat[c] = 0;
+            take[c] = false;
+            blk[c] = 0;
+            const int s = c * 64 + lane;
             if (c * 64 < nk) {
-                const int s = c * 64 + lane;
-                if (s < nk) {
-                    const uint64_t o = kb + s;
-                    const bool drawn = (mask[o >> 6] >> (o & 63)) & 1;
-                    bool valid;
-                    const uint64_t key = kmer_at(R, K, off + s, valid);
-                    take[c] = drawn && (BY_BASE || valid);
+                if (s < nk && lds_bit(L32 + 2 * S::X, x63 + s)) {
+                    const bool valid = (lds_window32(L32 + 2 * S::M, o63 + s) & K.nmask_bits) == 0;
+                    take[c] = BY_BASE || valid;
+                }
+                if (take[c]) {
+                    const uint64_t key = canon_key(lds_window64(L32 + 2 * S::B, 2 * (o31 + s)), K);
                     blk[c] = block_of(F, key);
-                    pat[c] = pattern_of(F, key);
+                    t[c] = F.table[blk[c]];
+                    p[c] = F.patterns[pattern_of(F, key)];
                 }
                 const unsigned long long bal = __ballot(take[c]);
-                if (!BY_BASE && R.hint_sampled) or_bits64(R.hint_sampled, off + (uint64_t)c * 64, bal, lane);
+                if (!BY_BASE && R.hint_sampled) or_bits64(R.hint_sampled, cur + (uint64_t)c * 64, bal, lane);
                 mine += __popcll(bal);
             }
         }
-        // all block and pattern loads of the read are issued before the first is used
-        ulonglong2 t[NW], p[NW];
-#pragma unroll
-        for (int c = 0; c < NW; ++c)
-            if (take[c]) { t[c] = F.table[blk[c]]; p[c] = F.patterns[pat[c]]; }
 #pragma unroll
         for (int c = 0; c < NW; ++c)
             if (take[c]) {
@@ -207,76 +225,105 @@ struct Thresholds { int v[KBBQ_MAX_KMER + 1]; };
 template <int NW>
 __global__ void __launch_bounds__(256) k_infer(ReadsDev R, KParams K, FiltDev S, Thresholds thr, uint32_t *take_bits,
                                                 unsigned long long *inserted, uint32_t *err_out) {
+    using St = Stage<NW>;
+    __shared__ uint32_t lds[4][St::LDS_U32];
+    __shared__ int thr_lds[KBBQ_MAX_KMER + 1];
     const int lane = threadIdx.x & 63;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (threadIdx.x <= KBBQ_MAX_KMER) thr_lds[threadIdx.x] = thr.v[threadIdx.x];
+    __syncthreads();
+    uint32_t *L32 = lds[threadIdx.x >> 6];
+    uint32_t *PW = L32 + 2 * St::WORDS;            // present bits: dword 0 = 0, dwords 1..2NW, then zeros
+    uint32_t *EW = PW + St::RES;                   // error bits, same shape
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t *hint = reinterpret_cast<const uint64_t *>(R.hint_sampled);
     const int k = K.k;
     unsigned long long mine = 0;
+    if (lane < St::RES) { PW[lane] = 0; EW[lane] = 0; }
+    uint64_t off = 0, word = 0;
+    uint32_t len = 0;
+    if (wave < R.n_reads) {
+        read_span(R, wave, off, len);
+        word = stage_fetch<NW>(R, hint, nullptr, 0, 0, off, lane);
+    }
     for (uint64_t r = wave; r < R.n_reads; r += n_waves) {
-        uint64_t off; uint32_t len;
-        read_span(R, r, off, len);
-        if (len < (uint32_t)k) continue;   // engine-defined: the reference underflows size_t here
-        const int L = (int)len, nk = L - k + 1;
-        uint64_t P[NW], E[NW], V[NW];
-        // every lane's block and pattern loads go out before the first result is needed
+        __builtin_amdgcn_wave_barrier();
+        if (lane < St::WORDS) stage_store(L32, lane, word);
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t cur = off;
+        const int o31 = (int)(off & 31), o63 = (int)(off & 63);
+        const int Lr = (int)len, nk = Lr - k + 1;
+        if (r + n_waves < R.n_reads) {   // the next read's words travel while this one is processed
+            read_span(R, r + n_waves, off, len);
+            word = stage_fetch<NW>(R, hint, nullptr, 0, 0, off, lane);
+        }
+        if (nk <= 0) continue;           // engine-defined: the reference underflows size_t here
+        // every lane's block and pattern loads (and its quality byte) go out before the first result is needed
         bool valid[NW], known[NW];
         ulonglong2 t[NW], p[NW];
+        uint8_t q[NW];
 #pragma unroll
         for (int c = 0; c < NW; ++c) {
-            P[c] = 0; E[c] = 0; V[c] = 0;
             valid[c] = false;
             known[c] = false;   // this read put the k-mer into the sampled filter itself (pass 1)
             t[c] = make_ulonglong2(0, 0);
             p[c] = make_ulonglong2(0, 0);
+            q[c] = 0;
             const int s = c * 64 + lane;
-            if (s < nk) {
-                const uint64_t key = kmer_at(R, K, off + s, valid[c]);
-                if (R.hint_sampled) {
-                    const uint64_t g = off + s;
-                    known[c] = (R.hint_sampled[g >> 5] >> (g & 31)) & 1;
-                }
+            if (c * 64 < Lr && s < Lr) q[c] = R.qual[cur + s];
+            if (c * 64 < nk && s < nk) {
+                const uint64_t key = canon_key(lds_window64(L32 + 2 * St::B, 2 * (o31 + s)), K);
+                valid[c] = (lds_window32(L32 + 2 * St::M, o63 + s) & K.nmask_bits) == 0;
+                known[c] = hint && lds_bit(L32 + 2 * St::H, o63 + s);
                 if (valid[c] && !known[c]) {
                     t[c] = S.table[block_of(S, key)];
                     p[c] = S.patterns[pattern_of(S, key)];
                 }
             }
         }
+        uint64_t V[NW];
 #pragma unroll
         for (int c = 0; c < NW; ++c) {
+            V[c] = 0;
             if (c * 64 < nk) {
                 const bool present = known[c] || (valid[c] && ((p[c].x & ~t[c].x) | (p[c].y & ~t[c].y)) == 0);
-                P[c] = __ballot(present);
+                const uint64_t P = __ballot(present);
                 V[c] = __ballot(valid[c]);
+                if (lane < 2) PW[1 + 2 * c + lane] = (uint32_t)(P >> (32 * lane));
+            } else if (lane < 2) {
+                PW[1 + 2 * c + lane] = 0;
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        // in[i] = present k-mers among the starts max(0,i-k+1)..min(i,nk-1): the k bits of the present
+        // stream that end at bit i (bits before 0 and from nk on are zero)
 #pragma unroll
         for (int c = 0; c < NW; ++c) {
-            if (c * 64 < L) {
+            if (c * 64 < Lr) {
                 const int i = c * 64 + lane;
                 bool err = false;
-                if (i < L) {
-                    const int lo = max(0, i - k + 1), hi = min(i, nk - 1);
-                    const int possible = hi - lo + 1;
-                    const int in = range_popc<NW>(P, lo, hi);
-                    err = in <= thr.v[possible] || R.qual[off + i] <= 2;
+                if (i < Lr) {
+                    const int possible = min(i, nk - 1) - max(0, i - k + 1) + 1;
+                    const int in = __popc(lds_window32(PW, i - k + 1 + 32) & K.nmask_bits);
+                    err = in <= thr_lds[possible] || q[c] <= 2;
                 }
-                E[c] = __ballot(err);
+                const uint64_t E = __ballot(err);
+                if (lane < 2) EW[1 + 2 * c + lane] = (uint32_t)(E >> (32 * lane));
+                if (err_out) or_bits64(err_out, cur + (uint64_t)c * 64, E, lane);
+            } else if (lane < 2) {
+                EW[1 + 2 * c + lane] = 0;
             }
         }
-        if (err_out) {
-#pragma unroll
-            for (int c = 0; c < NW; ++c)
-                if (c * 64 < L) or_bits64(err_out, off + (uint64_t)c * 64, E[c], lane);
-        }
+        __builtin_amdgcn_wave_barrier();
         // the k-mer ending at i goes into the trusted filter iff it is valid and its k bases are all
         // unflagged (recalibrateutils.cc:26-38); the inserts themselves are k_insert_marked's
 #pragma unroll
         for (int c = 0; c < NW; ++c) {
             if (c * 64 < nk) {
                 const int s = c * 64 + lane;
-                const bool take = s < nk && ((V[c] >> lane) & 1) && range_popc<NW>(E, s, s + k - 1) == 0;
+                const bool take = s < nk && ((V[c] >> lane) & 1) && (lds_window32(EW, s + 32) & K.nmask_bits) == 0;
                 const unsigned long long bal = __ballot(take);
-                or_bits64(take_bits, off + (uint64_t)c * 64, bal, lane);
+                or_bits64(take_bits, cur + (uint64_t)c * 64, bal, lane);
                 mine += __popcll(bal);
             }
         }
@@ -291,15 +338,31 @@ __global__ void __launch_bounds__(256) k_infer(ReadsDev R, KParams K, FiltDev S,
 template <int NW>
 __global__ void __launch_bounds__(256) k_scan_trusted(ReadsDev R, KParams K, FiltDev T, uint64_t *tmask,
                                                        uint8_t *dirty) {
+    using S = Stage<NW>;
+    __shared__ uint32_t lds[4][2 * S::WORDS];
     const int lane = threadIdx.x & 63;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t *L32 = lds[threadIdx.x >> 6];
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t *hint = reinterpret_cast<const uint64_t *>(R.hint_trusted);
     const int k = K.k;
+    uint64_t off = 0, word = 0;
+    uint32_t len = 0;
+    if (wave < R.n_reads) {
+        read_span(R, wave, off, len);
+        word = stage_fetch<NW>(R, hint, nullptr, 0, 0, off, lane);
+    }
     for (uint64_t r = wave; r < R.n_reads; r += n_waves) {
-        uint64_t off; uint32_t len;
-        read_span(R, r, off, len);
-        if (len < (uint32_t)k) { if (lane == 0) dirty[r] = 0; continue; }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < S::WORDS) stage_store(L32, lane, word);
+        __builtin_amdgcn_wave_barrier();
+        const int o31 = (int)(off & 31), o63 = (int)(off & 63);
         const int nk = (int)len - k + 1;
+        if (r + n_waves < R.n_reads) {   // the next read's words travel while this one is processed
+            read_span(R, r + n_waves, off, len);
+            word = stage_fetch<NW>(R, hint, nullptr, 0, 0, off, lane);
+        }
+        if (nk <= 0) { if (lane == 0) dirty[r] = 0; continue; }
         uint64_t M[NW];
         int trusted = 0;
         bool valid[NW], known[NW];
@@ -312,12 +375,10 @@ __global__ void __launch_bounds__(256) k_scan_trusted(ReadsDev R, KParams K, Fil
             t[c] = make_ulonglong2(0, 0);
             p[c] = make_ulonglong2(0, 0);
             const int s = c * 64 + lane;
-            if (s < nk) {
-                const uint64_t key = kmer_at(R, K, off + s, valid[c]);
-                if (R.hint_trusted) {
-                    const uint64_t g = off + s;
-                    known[c] = (R.hint_trusted[g >> 5] >> (g & 31)) & 1;
-                }
+            if (c * 64 < nk && s < nk) {
+                const uint64_t key = canon_key(lds_window64(L32 + 2 * S::B, 2 * (o31 + s)), K);
+                valid[c] = (lds_window32(L32 + 2 * S::M, o63 + s) & K.nmask_bits) == 0;
+                known[c] = hint && lds_bit(L32 + 2 * S::H, o63 + s);
                 if (valid[c] && !known[c]) {
                     t[c] = T.table[block_of(T, key)];
                     p[c] = T.patterns[pattern_of(T, key)];
@@ -373,18 +434,46 @@ template <int NW>
 __global__ void __launch_bounds__(256) k_fix_single(ReadsDev R, KParams K, FiltDev T, const uint32_t *list,
                                                      const unsigned long long *n_list, const uint64_t *tmask,
                                                      uint32_t *err_bits, uint8_t *dirty, unsigned long long *stats) {
+    using S = Stage<NW>;
     constexpr int MAXRUN = 4;
+    __shared__ uint32_t lds[4][2 * S::WORDS];
     const int lane = threadIdx.x & 63;
+    uint32_t *L32 = lds[threadIdx.x >> 6];
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t n = *n_list;
     const int k = K.k;
     unsigned long long q_total = 0;
-    for (uint64_t slot = wave; slot < n; slot += n_waves) {
-        const uint64_t r = list[slot];
-        uint64_t off; uint32_t len32;
-        read_span(R, r, off, len32);
-        const int len = (int)len32, nk = len - k + 1;
+    // Three reads are in flight per wave: A is being decided, B's words are travelling, C's list entry
+    // and span are travelling -- the dependent chain list -> offsets -> words never sits in front of
+    // the two lookup rounds.
+    uint64_t rA = 0, offA = 0, wordA = 0, rB = 0, offB = 0, rC = 0, slotC = wave + 2 * n_waves;
+    uint64_t tmA[NW], tmB[NW];                        // trusted masks: wave-uniform, scalar loads
+#pragma unroll
+    for (int c = 0; c < NW; ++c) { tmA[c] = 0; tmB[c] = 0; }
+    uint32_t lenA = 0, lenB = 0;
+    bool hasA = wave < n, hasB = wave + n_waves < n, hasC = slotC < n;
+    if (hasA) {
+        rA = list[wave];
+        read_span(R, rA, offA, lenA);
+        wordA = stage_fetch<NW>(R, nullptr, nullptr, 0, 0, offA, lane);
+#pragma unroll
+        for (int c = 0; c < NW; ++c) tmA[c] = tmask[rA * NW + c];
+    }
+    if (hasB) {
+        rB = list[wave + n_waves];
+        read_span(R, rB, offB, lenB);
+#pragma unroll
+        for (int c = 0; c < NW; ++c) tmB[c] = tmask[rB * NW + c];
+    }
+    if (hasC) rC = list[slotC];
+    while (hasA) {
+        __builtin_amdgcn_wave_barrier();
+        if (lane < S::WORDS) stage_store(L32, lane, wordA);
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t r = rA, off = offA;
+        const int len = (int)lenA, nk = len - k + 1;
+        const int o31 = (int)(off & 31), o63 = (int)(off & 63);
         // runs of untrusted k-mer starts: z = complement of the trusted mask inside [0, nk)
         uint64_t Z[NW];
         int zeros = 0;
@@ -393,10 +482,11 @@ __global__ void __launch_bounds__(256) k_fix_single(ReadsDev R, KParams K, FiltD
             Z[c] = 0;
             if (c * 64 < nk) {
                 const int rem = nk - c * 64;
-                Z[c] = ~tmask[r * NW + c] & (rem >= 64 ? ~0ULL : ((1ULL << rem) - 1));
+                Z[c] = ~tmA[c] & (rem >= 64 ? ~0ULL : ((1ULL << rem) - 1));
                 zeros += __popcll(Z[c]);
             }
         }
+        if (hasB) wordA = stage_fetch<NW>(R, nullptr, nullptr, 0, 0, offB, lane);
         auto next_bit = [&](int from, bool one) -> int {      // first index >= from with Z bit == one, nk if none
             while (from < nk) {
                 uint64_t x = sel_word<NW>(Z, from >> 6);
@@ -421,6 +511,9 @@ __global__ void __launch_bounds__(256) k_fix_single(ReadsDev R, KParams K, FiltD
             pos = next_bit(z1 + 1, true);
         }
         int singles = 0;   // runs with exactly one full alternative
+        uint64_t offC = 0;
+        uint32_t lenC = 0;
+        bool spanC_done = false;
         if (eligible) {
             auto pick = [&](const int (&a)[MAXRUN], int idx) -> int {
                 int v = a[0];
@@ -430,14 +523,13 @@ __global__ void __launch_bounds__(256) k_fix_single(ReadsDev R, KParams K, FiltD
             };
             // k-mer starting at st with base p := y
             auto key_of = [&](int st, int p, int y, bool &valid) -> uint64_t {
-                uint64_t w = window64(R.bases, 2 * (off + st));
-                uint32_t nm = (uint32_t)window64(R.nmask, off + st) & K.nmask_bits;
+                uint64_t w = lds_window64(L32 + 2 * S::B, 2 * (o31 + st));
+                uint32_t nm = lds_window32(L32 + 2 * S::M, o63 + st) & K.nmask_bits;
                 const int j = p - st;
                 w = (w & ~(3ULL << (2 * j))) | ((uint64_t)y << (2 * j));
                 nm &= ~(1u << j);
                 valid = nm == 0;
-                const uint64_t rc = (~w) & K.mask, fw = rev2(w) >> (64 - 2 * k);
-                return fw < rc ? fw : rc;
+                return canon_key(w, K);
             };
             // round 1: one covering k-mer per (run, alternative): lane 4*run + y
             int alive;
@@ -448,8 +540,7 @@ __global__ void __launch_bounds__(256) k_fix_single(ReadsDev R, KParams K, FiltD
                 if (act) {
                     p = pick(ps, run);
                     st = pick(z0s, run);
-                    const uint64_t gp = off + p;
-                    const int cur = ((R.nmask[gp >> 6] >> (gp & 63)) & 1) ? 4 : (int)((R.bases[gp >> 5] >> ((gp & 31) * 2)) & 3);
+                    const int cur = lds_bit(L32 + 2 * S::M, o63 + p) ? 4 : (int)((L32[2 * S::B + ((o31 + p) >> 4)] >> (((o31 + p) & 15) * 2)) & 3);
                     act = y != cur;
                 }
                 bool valid = false;
@@ -457,6 +548,7 @@ __global__ void __launch_bounds__(256) k_fix_single(ReadsDev R, KParams K, FiltD
                 const bool go = act && valid;
                 q_total += __popcll(__ballot(go));
                 const bool t = go && bloom_has(T, key);
+                if (hasC) { read_span(R, rC, offC, lenC); spanC_done = true; }
                 alive = (int)(__ballot(t) & 0xFFFF);
             }
             // round 2: every covering k-mer of the survivors, two (run, alternative) pairs per lookup
@@ -491,6 +583,15 @@ __global__ void __launch_bounds__(256) k_fix_single(ReadsDev R, KParams K, FiltD
             atomicOr(&err_bits[g >> 5], 1u << (g & 31));
             if (lane == 0) dirty[r] = 2;
         }
+        // rotate the pipeline
+        if (hasC && !spanC_done) read_span(R, rC, offC, lenC);
+        hasA = hasB; rA = rB; offA = offB; lenA = lenB;
+        hasB = hasC; rB = rC; offB = offC; lenB = lenC;
+#pragma unroll
+        for (int c = 0; c < NW; ++c) { tmA[c] = tmB[c]; tmB[c] = hasC ? tmask[rC * NW + c] : 0; }
+        slotC += n_waves;
+        hasC = slotC < n;
+        if (hasC) rC = list[slotC];
     }
     if (lane == 0 && q_total) atomicAdd(&stats[1], q_total);
 }
@@ -1511,10 +1612,10 @@ extern "C" {
 
 }  // extern "C"
 template <int NW> struct LaunchSample {
-    static int go(kbbq_engine *e, ReadsDev R, const uint64_t *mask, const uint64_t *kofs) {
+    static int go(kbbq_engine *e, ReadsDev R, const uint64_t *mask, uint64_t mask_words, const uint64_t *kofs) {
         Timed t(e, "k_insert_sampled");
         hipLaunchKernelGGL((k_insert_marked<NW, false>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
-                           e->filt[0].dev(), mask, kofs, e->filt[0].d_inserted);
+                           e->filt[0].dev(), mask, mask_words, kofs, e->filt[0].d_inserted);
         HIP_TRY(hipGetLastError());
         return KBBQ_OK;
     }
@@ -1540,7 +1641,7 @@ int kbbq_sample_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t first_km
                            first_kmer_ordinal, n_draws, e->draw_threshold, e->draw_always ? 1 : 0, mask);
         HIP_TRY(hipGetLastError());
     }
-    return dispatch_nw<LaunchSample>(max_len, e, R, (const uint64_t *)mask, kofs);
+    return dispatch_nw<LaunchSample>(max_len, e, R, (const uint64_t *)mask, n_draws / 64 + 2, kofs);
 }
 
 int kbbq_sample_finish(kbbq_engine *e, uint64_t *inserted) {
@@ -1595,8 +1696,8 @@ template <int NW> struct LaunchTrusted {
         {
             Timed t(e, "k_insert_trusted");
             hipLaunchKernelGGL((k_insert_marked<NW, true>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
-                               e->filt[1].dev(), (const uint64_t *)take_bits, (const uint64_t *)nullptr,
-                               (unsigned long long *)nullptr);
+                               e->filt[1].dev(), (const uint64_t *)take_bits, R.n_bases / 64 + 2,
+                               (const uint64_t *)nullptr, (unsigned long long *)nullptr);
             HIP_TRY(hipGetLastError());
         }
         return KBBQ_OK;
