@@ -217,7 +217,7 @@ def main():
         dom = max((k for k in kernels if "achieved_GBps" in kernels[k]), key=lambda k: kernels[k]["total_ms"])
         roof = dict(bound="hbm", kernel=dom, achieved=kernels[dom]["achieved_GBps"], peak=HBM_PEAK_GBPS, unit="GB/s",
                     frac=round(kernels[dom]["achieved_GBps"] / HBM_PEAK_GBPS, 4), traffic=None,
-                    note="random 64-byte blocks: tools/probe_hbm measures 3100 GB/s as this chip's ceiling for the "
+                    note="one random 64-byte line per lookup: tools/probe_hbm measures about 3100 GB/s as this chip's ceiling for the "
                          "Bloom access pattern; PMC traffic per kernel is in profiles/ (separate rocprofv3 --pmc runs)")
         line = {
             "metric": "recalibrated Gbases/sec", "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world,

@@ -659,7 +659,7 @@ __global__ void __launch_bounds__(BLOCK) k_correct(ReadsDev R, KParams K, FiltDe
 
 // ---- pass 3b (default): the correction walk, one read per WAVEFRONT (correct_wave.h) ----
 template <int NB, int NN>
-__global__ void __launch_bounds__(256, 4) k_correct_wave(ReadsDev R, KParams K, FiltDev T, const uint32_t *list,
+__global__ void __launch_bounds__(256, 5) k_correct_wave(ReadsDev R, KParams K, FiltDev T, const uint32_t *list,
                                                        const unsigned long long *n_list, const uint64_t *tmask,
                                                        int tmask_words, uint32_t *err_bits, uint32_t *patch,
                                                        unsigned long long *stats) {
