@@ -215,10 +215,26 @@ def main():
                 ent["achieved_GBps"] = round(model / (ms / launches) / 1e6, 1)
             kernels[name] = ent
         dom = max((k for k in kernels if "achieved_GBps" in kernels[k]), key=lambda k: kernels[k]["total_ms"])
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
+        # is the committed rocprofv3 --pmc summary of this same command at the same launch size
+        traffic, traffic_note = None, "no PMC summary for this launch size"
+        try:
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_latest.json")))
+            k = pmc["kernels"].get(dom)
+            launches_per_step = kernels[dom]["launches"] // args.steps
+            full_launches = (n_local // BATCH_READS) >= 1 and READ_LEN == 150
+            if k and full_launches:
+                traffic = round((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0)
+                traffic_note = ("FETCH_SIZE + WRITE_SIZE per launch of %d reads, %s (%d launches per step here, the last one partial)"
+                                % (BATCH_READS, pmc["summary_file"], launches_per_step))
+        except (OSError, ValueError, KeyError):
+            pass
         roof = dict(bound="hbm", kernel=dom, achieved=kernels[dom]["achieved_GBps"], peak=HBM_PEAK_GBPS, unit="GB/s",
-                    frac=round(kernels[dom]["achieved_GBps"] / HBM_PEAK_GBPS, 4), traffic=None,
+                    frac=round(kernels[dom]["achieved_GBps"] / HBM_PEAK_GBPS, 4), traffic=traffic,
+                    algorithmic_bytes_per_launch=kernels[dom]["alg_bytes_per_launch"], avg_launch_ms=kernels[dom]["avg_ms"],
+                    traffic_note=traffic_note,
                     note="one random 64-byte line per lookup: tools/probe_hbm measures about 3100 GB/s as this chip's ceiling for the "
-                         "Bloom access pattern; PMC traffic per kernel is in profiles/ (separate rocprofv3 --pmc runs)")
+                         "Bloom access pattern; traffic below the algorithmic bytes = lookups answered by hint bits")
         line = {
             "metric": "recalibrated Gbases/sec", "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
