@@ -160,6 +160,13 @@ int kbbq_pack_bases(const uint8_t *seq, uint64_t n_bases, uint64_t *bases_out, u
  * device pointers (on_device=1).  Free with kbbq_reads_free. */
 int kbbq_reads_upload(kbbq_engine *e, const kbbq_reads *host, kbbq_reads *dev);
 int kbbq_reads_free(kbbq_engine *e, kbbq_reads *dev);
+/* For both, e may be NULL (current device): a driver can make its batches resident in HBM while it is
+ * still counting the bases that size the engine (kbbq.cc:229-264), then run every pass from HBM.
+ * kbbq_reads_alloc_hints gives a device batch zeroed hint arrays (see kbbq_reads.hint_*), owned by the
+ * library until kbbq_reads_free_hints.  kbbq_device_memory: hipMemGetInfo of a device (-1 = current). */
+int kbbq_reads_alloc_hints(kbbq_reads *dev);
+int kbbq_reads_free_hints(kbbq_reads *dev);
+int kbbq_device_memory(int32_t device, uint64_t *free_bytes, uint64_t *total_bytes);
 
 /* ---- pass 1: recalibrateutils::subsample_kmers (recalibrateutils.cc:7-13) -- */
 
@@ -230,6 +237,8 @@ int kbbq_set_dq(kbbq_engine *e, const kbbq_dq *dq); /* e.g. tables computed on a
 
 /* qual_out: n_bases bytes, device or host like the batch. */
 int kbbq_recalibrate_batch(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qual_out);
+/* Same, but qual_out is always HOST memory (a device-resident batch whose new qualities go to a writer). */
+int kbbq_recalibrate_batch_host(kbbq_engine *e, const kbbq_reads *reads, uint8_t *host_qual_out);
 
 /* ---- synthetic input and measurement ------------------------------------- */
 

@@ -99,6 +99,10 @@ SYMBOLS = {
     "kbbq_dq_get": (ctypes.c_int, [c_vp, ctypes.POINTER(Dq)]),
     "kbbq_set_dq": (ctypes.c_int, [c_vp, ctypes.POINTER(Dq)]),
     "kbbq_recalibrate_batch": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads), c_vp]),
+    "kbbq_recalibrate_batch_host": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads), c_vp]),
+    "kbbq_reads_alloc_hints": (ctypes.c_int, [ctypes.POINTER(Reads)]),
+    "kbbq_reads_free_hints": (ctypes.c_int, [ctypes.POINTER(Reads)]),
+    "kbbq_device_memory": (ctypes.c_int, [ctypes.c_int32, c_u64p, c_u64p]),
     "kbbq_synth_tables": (ctypes.c_int, [ctypes.POINTER(SynthParams), c_u32p, c_u32p]),
     "kbbq_synth_reads": (ctypes.c_int, [c_vp, ctypes.POINTER(SynthParams), c_u64, c_u64, ctypes.POINTER(Reads)]),
     "kbbq_profile_get": (ctypes.c_int, [c_vp, ctypes.POINTER(ProfileEntry), ctypes.c_int32, c_i32p]),

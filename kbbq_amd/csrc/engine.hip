@@ -1553,7 +1553,8 @@ int kbbq_pack_bases(const uint8_t *seq, uint64_t n_bases, uint64_t *bases_out, u
 }
 
 int kbbq_reads_upload(kbbq_engine *e, const kbbq_reads *host, kbbq_reads *dev) {
-    if (!e || !host || !dev) return fail(KBBQ_EINVAL, "null argument");
+    (void)e;   // may be NULL: batches can be made resident before the engine (whose size depends on them) exists
+    if (!host || !dev) return fail(KBBQ_EINVAL, "null argument");
     if (host->on_device) return fail(KBBQ_EINVAL, "batch is already on the device");
     *dev = *host;
     dev->on_device = 1;
@@ -1580,13 +1581,56 @@ int kbbq_reads_upload(kbbq_engine *e, const kbbq_reads *host, kbbq_reads *dev) {
 }
 
 int kbbq_reads_free(kbbq_engine *e, kbbq_reads *dev) {
-    if (!e || !dev) return fail(KBBQ_EINVAL, "null argument");
+    if (!dev) return fail(KBBQ_EINVAL, "null argument");
     if (!dev->on_device) return fail(KBBQ_EINVAL, "not a device batch");
-    int rc = sync_engine(e);
-    if (rc) return rc;
+    if (e) {
+        int rc = sync_engine(e);
+        if (rc) return rc;
+    } else {
+        HIP_TRY(hipDeviceSynchronize());
+    }
     hipFree((void *)dev->bases); hipFree((void *)dev->nmask); hipFree((void *)dev->qual);
     hipFree((void *)dev->offsets); hipFree((void *)dev->flags); hipFree((void *)dev->rg);
     memset(dev, 0, sizeof *dev);
+    return KBBQ_OK;
+}
+
+int kbbq_reads_alloc_hints(kbbq_reads *dev) {
+    if (!dev || !dev->on_device) return fail(KBBQ_EINVAL, "not a device batch");
+    if (dev->hint_sampled || dev->hint_trusted) return fail(KBBQ_ESTATE, "batch already has hint arrays");
+    const size_t bytes = (dev->n_bases / 64 + 2) * 8;
+    void *a = nullptr, *b = nullptr;
+    hipError_t he = hipMalloc(&a, bytes);
+    if (he == hipSuccess) he = hipMalloc(&b, bytes);
+    if (he == hipSuccess) he = hipMemset(a, 0, bytes);
+    if (he == hipSuccess) he = hipMemset(b, 0, bytes);
+    if (he != hipSuccess) {
+        hipFree(a); hipFree(b);
+        return fail(he == hipErrorOutOfMemory ? KBBQ_ENOMEM : KBBQ_EIO, "hint arrays: %s", hipGetErrorString(he));
+    }
+    dev->hint_sampled = (uint64_t *)a;
+    dev->hint_trusted = (uint64_t *)b;
+    return KBBQ_OK;
+}
+
+int kbbq_reads_free_hints(kbbq_reads *dev) {
+    if (!dev || !dev->on_device) return fail(KBBQ_EINVAL, "not a device batch");
+    HIP_TRY(hipDeviceSynchronize());
+    hipFree(dev->hint_sampled); hipFree(dev->hint_trusted);
+    dev->hint_sampled = nullptr;
+    dev->hint_trusted = nullptr;
+    return KBBQ_OK;
+}
+
+int kbbq_device_memory(int32_t device, uint64_t *free_bytes, uint64_t *total_bytes) {
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    if (device >= 0 && device != cur) HIP_TRY(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (device >= 0 && device != cur) HIP_TRY(hipSetDevice(cur));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
     return KBBQ_OK;
 }
 
@@ -1991,14 +2035,25 @@ int kbbq_set_dq(kbbq_engine *e, const kbbq_dq *in) {
 }
 
 // ---- pass 4
+static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qual_out, bool out_on_host);
+
 int kbbq_recalibrate_batch(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qual_out) {
-    if (!e || !qual_out) return fail(KBBQ_EINVAL, "null argument");
+    if (!reads) return fail(KBBQ_EINVAL, "null argument");
+    return recalibrate_impl(e, reads, qual_out, !reads->on_device);
+}
+
+int kbbq_recalibrate_batch_host(kbbq_engine *e, const kbbq_reads *reads, uint8_t *host_qual_out) {
+    return recalibrate_impl(e, reads, host_qual_out, true);
+}
+
+static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qual_out, bool out_on_host) {
+    if (!e || !qual_out || !reads) return fail(KBBQ_EINVAL, "null argument");
     if (!e->dq_set) return fail(KBBQ_ESTATE, "no delta-Q tables yet");
     ReadsDev R; int max_len;
     int rc = device_view(e, reads, &R, &max_len);
     if (rc) return rc;
     uint8_t *d_out = qual_out;
-    if (!reads->on_device) {
+    if (out_on_host) {
         if ((rc = ensure_scratch(e, 2, R.n_bases + 16))) return rc;
         d_out = (uint8_t *)e->scratch[2];
     }
@@ -2016,7 +2071,7 @@ int kbbq_recalibrate_batch(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qua
                            R, D, d_out, 6, vec_ok, lds_rgs);
         HIP_TRY(hipGetLastError());
     }
-    if (!reads->on_device) {
+    if (out_on_host) {
         HIP_TRY(hipMemcpyAsync(qual_out, d_out, R.n_bases, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
     }

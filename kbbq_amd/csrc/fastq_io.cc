@@ -121,8 +121,8 @@ const unsigned char kEofBlock[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff
                                      0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 }
 
-// one BGZF block from data[0..len); halves the input if the compressed form does not fit 64 KiB
-static bool emit_block(FILE *out, const unsigned char *data, size_t len) {
+// one BGZF block from data[0..len) appended to `out`; halves the input if the compressed form does not fit 64 KiB
+static bool deflate_block(const unsigned char *data, size_t len, std::vector<unsigned char> &out) {
     if (!len) return true;
     unsigned char block[0x10000];
     z_stream zs;
@@ -137,7 +137,7 @@ static bool emit_block(FILE *out, const unsigned char *data, size_t len) {
     deflateEnd(&zs);
     if (rc != Z_STREAM_END) {
         if (len < 2) return false;
-        return emit_block(out, data, len / 2) && emit_block(out, data + len / 2, len - len / 2);
+        return deflate_block(data, len / 2, out) && deflate_block(data + len / 2, len - len / 2, out);
     }
     const size_t total = clen + 18 + 8;
     // gzip header with the BGZF 'BC' extra field carrying the block size - 1
@@ -148,13 +148,77 @@ static bool emit_block(FILE *out, const unsigned char *data, size_t len) {
     const uint32_t isize = (uint32_t)len;
     unsigned char *tail = block + 18 + clen;
     for (int i = 0; i < 4; ++i) { tail[i] = (unsigned char)(crc >> (8 * i)); tail[4 + i] = (unsigned char)(isize >> (8 * i)); }
-    return fwrite(block, 1, total, out) == total;
+    out.insert(out.end(), block, block + total);
+    return true;
 }
 
-bool BgzfWriter::flush_block() {
-    const bool ok = emit_block(out_, pending_.data(), pending_.size());
-    pending_.clear();
-    return ok;
+BgzfWriter::BgzfWriter(FILE *out, int threads) : out_(out) {
+    pending_.reserve(kBlock);
+    for (int i = 0; i < threads && threads > 1; ++i) pool_.emplace_back(&BgzfWriter::worker, this);
+}
+
+BgzfWriter::~BgzfWriter() {
+    close();
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        stop_ = true;
+    }
+    cv_todo_.notify_all();
+    for (auto &t : pool_) t.join();
+}
+
+void BgzfWriter::worker() {
+    for (;;) {
+        std::shared_ptr<Job> job;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_todo_.wait(lk, [&] { return stop_ || !todo_.empty(); });
+            if (todo_.empty()) return;
+            job = todo_.front();
+            todo_.pop_front();
+        }
+        const bool ok = deflate_block(job->in.data(), job->in.size(), job->out);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job->ok = ok;
+            job->done = true;
+        }
+        cv_done_.notify_all();
+    }
+}
+
+bool BgzfWriter::drain(size_t keep) {
+    while (order_.size() > keep) {
+        std::shared_ptr<Job> job = order_.front();
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_done_.wait(lk, [&] { return job->done; });
+        }
+        order_.pop_front();
+        if (!job->ok || fwrite(job->out.data(), 1, job->out.size(), out_) != job->out.size()) failed_ = true;
+    }
+    return !failed_;
+}
+
+bool BgzfWriter::submit() {
+    if (pending_.empty()) return !failed_;
+    if (pool_.empty()) {
+        std::vector<unsigned char> out;
+        const bool ok = deflate_block(pending_.data(), pending_.size(), out) && fwrite(out.data(), 1, out.size(), out_) == out.size();
+        pending_.clear();
+        if (!ok) failed_ = true;
+        return ok;
+    }
+    auto job = std::make_shared<Job>();
+    job->in.swap(pending_);
+    pending_.reserve(kBlock);
+    order_.push_back(job);
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        todo_.push_back(job);
+    }
+    cv_todo_.notify_one();
+    return drain(pool_.size() * 8);    // bounded memory: at most 8 blocks per worker in flight
 }
 
 bool BgzfWriter::write(const char *data, size_t n) {
@@ -164,15 +228,15 @@ bool BgzfWriter::write(const char *data, size_t n) {
         pending_.insert(pending_.end(), (const unsigned char *)data, (const unsigned char *)data + take);
         data += take;
         n -= take;
-        if (pending_.size() == kBlock && !flush_block()) return false;
+        if (pending_.size() == kBlock && !submit()) return false;
     }
-    return true;
+    return !failed_;
 }
 
 bool BgzfWriter::close() {
-    if (closed_) return true;
+    if (closed_) return !failed_;
     closed_ = true;
-    if (!flush_block()) return false;
+    if (!submit() || !drain(0)) return false;
     if (fwrite(kEofBlock, 1, sizeof kEofBlock, out_) != sizeof kEofBlock) return false;
     return fflush(out_) == 0;
 }

@@ -11,9 +11,14 @@
 #pragma once
 #include <zlib.h>
 
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -64,19 +69,35 @@ private:
 // reference would throw (name shorter than two characters, readutils.cc:90).
 bool parse_read_name(const std::string &fullname, std::string &rg, bool &second, std::string &first_name);
 
+// BGZF output.  Blocks are cut at fixed input boundaries (0xff00 bytes, htslib's BGZF_BLOCK_SIZE), so the
+// compressed stream does not depend on the number of threads: with threads > 1 the blocks are deflated by a
+// small pool (what hts_set_thread_pool buys the reference, htsiter.cc:69) and written in order.
 class BgzfWriter {
 public:
-    explicit BgzfWriter(FILE *out) : out_(out) { pending_.reserve(kBlock); }
-    ~BgzfWriter() { close(); }
+    explicit BgzfWriter(FILE *out, int threads = 1);
+    ~BgzfWriter();
     bool write(const char *data, size_t n);
     bool close();   // flushes and appends the 28-byte EOF block; idempotent
 
 private:
     static constexpr size_t kBlock = 0xff00;   // BGZF_BLOCK_SIZE of htslib
-    bool flush_block();
+    struct Job {
+        std::vector<unsigned char> in, out;
+        bool done = false, ok = true;
+    };
+    bool submit();                 // pending_ -> a job (or compress inline when there is no pool)
+    bool drain(size_t keep);       // write finished jobs in order until at most `keep` are outstanding
+    void worker();
     FILE *out_;
     std::vector<unsigned char> pending_;
-    bool closed_ = false;
+    bool closed_ = false, failed_ = false;
+    // pool
+    std::vector<std::thread> pool_;
+    std::deque<std::shared_ptr<Job>> order_;     // submission order (writer thread only)
+    std::deque<std::shared_ptr<Job>> todo_;      // guarded by mu_
+    std::mutex mu_;
+    std::condition_variable cv_todo_, cv_done_;
+    bool stop_ = false;
 };
 
 inline bool write_fastq_record(BgzfWriter &w, const FastqRecord &r, const std::string &qual) {

@@ -13,7 +13,10 @@
 //     the engine is created; the reference grows its tables on the fly;
 //   * the sampler seed can be fixed with KBBQ_SEED=<u32> (the reference always draws it from time+pid,
 //     kbbq.cc:268-270, so two of its own runs differ: SURVEY hazard H1);
-//   * --threads is accepted and ignored (it only sizes htslib's BGZF pool, kbbq.cc:159-168);
+//   * --threads sizes the BGZF output pool (it sizes htslib's pool in the reference, kbbq.cc:159-168);
+//     0 = up to 16 threads instead of none.  The compressed stream does not depend on the thread count;
+//   * the packed reads stay resident in GPU memory between the passes when they fit (KBBQ_RESIDENT=0
+//     turns that off): same results, four decodes of the input fewer;
 //   * where the reference prints an error and then crashes or throws (missing --genomelen on FASTQ,
 //     kbbq.cc:218; missing RG / OQ tags, readutils.cc:20-30,42-53) this prints the same text and exits 1.
 #include <getopt.h>
@@ -29,6 +32,7 @@
 #include <memory>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/kbbq_engine.h"
@@ -184,17 +188,23 @@ struct Batch {
     kbbq_reads c;
     bool stop_at_empty = false;   // next_str() != "" loops end at the first empty read (kbbq.cc:234, htsiter.cc:95)
     bool fatal = false;
+    bool saw_empty = false;       // an empty read went into this batch
+    size_t longest = 0;           // longest read of this batch
     Item it;
 
     // returns false when no read was collected
     bool fill(Source &in, ReadGroups &groups, size_t max_reads, bool keep_records, bool is_bam = false) {
         fq_recs.clear(); bam_recs.clear(); seq.clear(); qual.clear(); flags.clear(); rg.clear();
         off.assign(1, 0);
+        saw_empty = false;
+        longest = 0;
         while (rg.size() < max_reads) {
             const int rc = in.next(it);
             if (rc == SRC_FATAL) { fatal = true; return false; }
             if (rc < 0) break;                       // -1 end of file; < -1 error: the reference's loops also just end
             if (stop_at_empty && it.seq.empty()) break;
+            if (it.seq.empty()) saw_empty = true;
+            longest = std::max(longest, it.seq.size());
             seq.insert(seq.end(), it.seq.begin(), it.seq.end());
             qual.insert(qual.end(), it.qual.begin(), it.qual.end());
             qual.resize(seq.size(), 0);
@@ -284,8 +294,8 @@ static int io_test(int argc, char *argv[]) {
         }
         return out.close() ? 0 : 1;
     }
-    if (what == "bgzf") {   // stdin -> BGZF on stdout
-        BgzfWriter out(stdout);
+    if (what == "bgzf") {   // stdin -> BGZF on stdout: --io-test bgzf [threads]
+        BgzfWriter out(stdout, argc > 3 ? atoi(argv[3]) : 1);
         std::vector<char> buf(1 << 16);
         size_t n;
         while ((n = fread(buf.data(), 1, buf.size(), stdin)) > 0)
@@ -331,7 +341,9 @@ int main(int argc, char *argv[]) {
                 return 1;
         }
     }
-    (void)nthreads;
+    // --threads sizes the BGZF compression pool like the reference's htslib pool (kbbq.cc:159-168); unlike the
+    // reference, 0 does not mean "single-threaded" but "pick": the writer is the end-to-end bottleneck
+    const int out_threads = nthreads > 0 ? nthreads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     std::string filename("-");
     if (optind < argc) {
         filename = std::string(argv[optind]);
@@ -350,11 +362,36 @@ int main(int argc, char *argv[]) {
     }
     const bool is_bam = fmt == Format::bam;
 
-    // one read-only scan: total length (the reference's coverage pass, kbbq.cc:229-250), read groups, longest read
+    // One scan before the engine exists: total length (the reference's coverage pass, kbbq.cc:229-250),
+    // read groups, longest read.  The packed batches of this scan are uploaded as they are made and stay
+    // resident in HBM, so passes 1-4 run from device memory instead of decoding the file four more times
+    // (288 GB of HBM hold a 30x human genome beside its filters); the records themselves are decoded once
+    // more, for the output pass.  Falls back to re-reading per pass if the batches do not fit (or with
+    // KBBQ_RESIDENT=0), and for the rare inputs where the passes would not see the same reads (an empty read
+    // ends the reference's sampling and coverage loops but not the others).
     ReadGroups groups;
     uint64_t seqlen = 0, n_reads = 0;
     size_t longest = 0;
     BamHeader bam_header;
+    const size_t batch_reads = 1 << 20;
+    Batch batch;
+    struct Resident {
+        std::vector<kbbq_reads> dev;
+        bool on = true;
+        uint64_t bytes = 0, budget = 0;
+        void drop() {
+            for (auto &d : dev) { kbbq_reads_free_hints(&d); kbbq_reads_free(nullptr, &d); }
+            dev.clear();
+            on = false;
+        }
+    } resident;
+    const bool fixed_mode = !fixedinput.empty();
+    {
+        const char *env = getenv("KBBQ_RESIDENT");
+        uint64_t free_b = 0, total_b = 0;
+        if ((env && !strcmp(env, "0")) || fixed_mode || kbbq_device_memory(-1, &free_b, &total_b) < 0) resident.on = false;
+        resident.budget = (uint64_t)(0.6 * (double)free_b);
+    }
     {
         std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
         if (!in->ok()) {
@@ -362,27 +399,38 @@ int main(int argc, char *argv[]) {
             return 1;
         }
         if (is_bam) bam_header = static_cast<BamSource *>(in.get())->header();
-        Item it;
-        int rc;
         bool counting = true;    // the coverage pass stops at the first empty read; the other passes do not
-        while ((rc = in->next(it)) >= 0) {
-            if (it.seq.empty()) counting = false;
-            if (counting) seqlen += it.seq.length();
-            longest = std::max(longest, it.seq.length());
-            ++n_reads;
-            groups.index_of(it.rg);
+        while (batch.fill(*in, groups, batch_reads, false)) {
+            for (size_t r = 0; r < batch.c.n_reads && counting; ++r) {
+                const uint64_t l = batch.off[r + 1] - batch.off[r];
+                if (l == 0) counting = false; else seqlen += l;
+            }
+            longest = std::max(longest, batch.longest);
+            n_reads += batch.c.n_reads;
+            if (batch.saw_empty && resident.on) resident.drop();
+            if (resident.on && batch.longest <= KBBQ_MAX_READ_LEN) {
+                const uint64_t need = batch.c.n_bases + batch.c.n_bases / 2 + batch.c.n_reads * 16 + 4096;
+                kbbq_reads d;
+                if (resident.bytes + need > resident.budget || kbbq_reads_upload(nullptr, &batch.c, &d) < 0) {
+                    resident.drop();
+                } else if (kbbq_reads_alloc_hints(&d) < 0) {
+                    kbbq_reads_free(nullptr, &d);
+                    resident.drop();
+                } else {
+                    resident.dev.push_back(d);
+                    resident.bytes += need;
+                }
+            }
         }
-        if (rc == SRC_FATAL) return 1;
+        if (batch.fatal) return 1;
     }
     if (longest > KBBQ_MAX_READ_LEN) {
         std::cerr << put_now << " Error: reads longer than " << KBBQ_MAX_READ_LEN << " bases are not supported by the GPU engine." << std::endl;
         return 1;
     }
 
-    const bool fixed_mode = !fixedinput.empty();
     kbbq_engine *e = nullptr;
-    const size_t batch_reads = 1 << 20;
-    Batch batch;
+    if (resident.on) std::cerr << put_now << " Reads are resident on the GPU: " << resident.dev.size() << " batches." << std::endl;
 
     if (!fixed_mode) {
         if (genomelen == 0) {
@@ -444,16 +492,24 @@ int main(int argc, char *argv[]) {
 
         // pass 1, kbbq.cc:277-283
         {
-            std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
             uint64_t ordinal = 0, nk = 0;
-            batch.stop_at_empty = true;
-            while (batch.fill(*in, groups, batch_reads, false)) {
-                if (kbbq_sample_batch(e, &batch.c, ordinal) < 0) return fail_engine("sampling");
-                if (kbbq_count_kmer_positions(e, &batch.c, &nk) < 0) return fail_engine("sampling");
-                ordinal += nk;
+            if (resident.on) {
+                for (auto &d : resident.dev) {
+                    if (kbbq_sample_batch(e, &d, ordinal) < 0) return fail_engine("sampling");
+                    if (kbbq_count_kmer_positions(e, &d, &nk) < 0) return fail_engine("sampling");
+                    ordinal += nk;
+                }
+            } else {
+                std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
+                batch.stop_at_empty = true;
+                while (batch.fill(*in, groups, batch_reads, false)) {
+                    if (kbbq_sample_batch(e, &batch.c, ordinal) < 0) return fail_engine("sampling");
+                    if (kbbq_count_kmer_positions(e, &batch.c, &nk) < 0) return fail_engine("sampling");
+                    ordinal += nk;
+                }
+                if (batch.fatal) return 1;
+                batch.stop_at_empty = false;
             }
-            if (batch.fatal) return 1;
-            batch.stop_at_empty = false;
             uint64_t inserted = 0;
             if (kbbq_sample_finish(e, &inserted) < 0) return fail_engine("sampling");
             std::cerr << put_now << " Sampled " << inserted << " valid kmers." << std::endl;
@@ -481,19 +537,29 @@ int main(int argc, char *argv[]) {
         // pass 2, kbbq.cc:333-337
         std::cerr << put_now << " Finding trusted kmers" << std::endl;
         {
-            std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
-            while (batch.fill(*in, groups, batch_reads, false))
-                if (kbbq_trusted_batch(e, &batch.c, nullptr) < 0) return fail_engine("finding trusted kmers");
-            if (batch.fatal) return 1;
+            if (resident.on) {
+                for (auto &d : resident.dev)
+                    if (kbbq_trusted_batch(e, &d, nullptr) < 0) return fail_engine("finding trusted kmers");
+            } else {
+                std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
+                while (batch.fill(*in, groups, batch_reads, false))
+                    if (kbbq_trusted_batch(e, &batch.c, nullptr) < 0) return fail_engine("finding trusted kmers");
+                if (batch.fatal) return 1;
+            }
             if (kbbq_trusted_finish(e, nullptr) < 0) return fail_engine("finding trusted kmers");
         }
         // pass 3, kbbq.cc:363-366
         std::cerr << put_now << " Finding errors" << std::endl;
         {
-            std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
-            while (batch.fill(*in, groups, batch_reads, false))
-                if (kbbq_errors_batch(e, &batch.c, nullptr) < 0) return fail_engine("finding errors");
-            if (batch.fatal) return 1;
+            if (resident.on) {
+                for (auto &d : resident.dev)
+                    if (kbbq_errors_batch(e, &d, nullptr) < 0) return fail_engine("finding errors");
+            } else {
+                std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
+                while (batch.fill(*in, groups, batch_reads, false))
+                    if (kbbq_errors_batch(e, &batch.c, nullptr) < 0) return fail_engine("finding errors");
+                if (batch.fatal) return 1;
+            }
         }
     } else {
         // --fixed, kbbq.cc:367-378: errors = bases that differ from the corrected file
@@ -538,14 +604,24 @@ int main(int argc, char *argv[]) {
     std::cerr << put_now << " Recalibrating file" << std::endl;
     {
         std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
-        BgzfWriter out(stdout);
+        BgzfWriter out(stdout, out_threads);
         BamWriter bam_out(out);
         if (is_bam && !bam_out.write_header(bam_header)) return 1;      // BamFile::open_out, htsiter.cc:35-42
         std::vector<uint8_t> newq;
         std::string qtext;
+        size_t bi = 0;
         while (batch.fill(*in, groups, batch_reads, true, is_bam)) {
             newq.assign(batch.c.n_bases + 16, 0);
-            if (kbbq_recalibrate_batch(e, &batch.c, newq.data()) < 0) return fail_engine("recalibrating");
+            if (resident.on) {
+                if (bi >= resident.dev.size() || resident.dev[bi].n_bases != batch.c.n_bases || resident.dev[bi].n_reads != batch.c.n_reads) {
+                    std::cerr << put_now << " Error: the input changed between the passes." << std::endl;
+                    return 1;
+                }
+                if (kbbq_recalibrate_batch_host(e, &resident.dev[bi], newq.data()) < 0) return fail_engine("recalibrating");
+                ++bi;
+            } else if (kbbq_recalibrate_batch(e, &batch.c, newq.data()) < 0) {
+                return fail_engine("recalibrating");
+            }
             for (size_t r = 0; r < batch.c.n_reads; ++r) {
                 const uint64_t a = batch.off[r], len = batch.off[r + 1] - a;
                 if (!is_bam) {
@@ -573,6 +649,7 @@ int main(int argc, char *argv[]) {
         if (batch.fatal) return 1;
         if (!out.close()) return 1;
     }
+    resident.drop();
     kbbq_engine_destroy(e);
     return 0;
 }

@@ -81,6 +81,22 @@ def test_cli_recalibrates_fastq_like_the_reference_pipeline(tmp_path):
     assert (ora["recal"] != d["qual"]).any()
 
 
+def test_cli_streaming_and_resident_modes_agree(tmp_path):
+    """Default: the packed reads stay in GPU memory between the passes; KBBQ_RESIDENT=0: every pass decodes the
+    file again like the reference.  Same bytes either way, also with a single compression thread."""
+    d, names, n_rg = named_dataset(seed=11, genome_len=20000, coverage=20, ragged=True, short_reads=20)
+    fq = tmp_path / "in.fq.gz"
+    write_fastq(fq, d, names)
+    rc, out_res, err_res = run_cli(["-g", d["genome_len"], fq], {"KBBQ_SEED": "5"})
+    assert rc == 0 and "Reads are resident on the GPU" in err_res
+    rc, out_str, err_str = run_cli(["-g", d["genome_len"], "-t", 1, fq], {"KBBQ_SEED": "5", "KBBQ_RESIDENT": "0"})
+    assert rc == 0 and "resident" not in err_str
+    assert out_res == out_str
+    ora = common.run_oracle(dict(d, coverage=int(d["off"][-1]) // d["genome_len"]), seed=5, n_rg=n_rg)
+    got = "".join(q for _, _, _, q in read_fastq_text(gzip.decompress(out_res)))
+    assert got == (ora["recal"] + 33).astype(np.uint8).tobytes().decode()
+
+
 def test_cli_options_k_alpha_coverage_and_plain_input(tmp_path):
     d, names, n_rg = named_dataset(seed=5, genome_len=15000, coverage=40, read_len=100)
     fq = tmp_path / "in.fq"

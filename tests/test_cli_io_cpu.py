@@ -113,3 +113,6 @@ def test_bgzf_writer_round_trip_and_block_structure(tmp_path):
             pos += bsize
         assert pos == len(out) and sizes[-1] == 0 and out[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
         assert sum(sizes) == len(payload)
+        # the pool only changes who deflates a block, not the stream
+        threaded = subprocess.run([CLI, "--io-test", "bgzf", "5"], input=payload, capture_output=True, check=True).stdout
+        assert threaded == out
