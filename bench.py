@@ -19,6 +19,7 @@ oracle -- the single-threaded CPU restatement of the reference -- on a bounded
 sample of the same workload; it is a reported baseline, never the product path.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -88,6 +89,68 @@ def kernel_model(name, bases, nk, alpha, f_t, walk_queries=0.0):
     }.get(name)
 
 
+class HostPacked:
+    """A packed batch in host memory (what a driver that decodes on the CPU hands over the boundary)."""
+
+    def __init__(self, e, dev):
+        from kbbq_amd import _lib
+        h = e.download(dev)
+        self.arrays = h
+        self.qual = np.zeros(dev.n_bases + 16, dtype=np.uint8)
+        self.qual[:dev.n_bases] = h["qual"]
+        self.bases = np.concatenate([h["bases"], np.zeros(1, dtype=np.uint64)])
+        self.nmask = np.concatenate([h["nmask"], np.zeros(1, dtype=np.uint64)])
+        self.n_reads, self.n_bases = dev.n_reads, dev.n_bases
+        self.c = _lib.Reads()
+        self.c.n_reads, self.c.n_bases = dev.n_reads, dev.n_bases
+        self.c.bases, self.c.nmask, self.c.qual = self.bases.ctypes.data, self.nmask.ctypes.data, self.qual.ctypes.data
+        self.c.offsets = None
+        self.c.flags = None
+        self.c.rg = None
+        self.c.read_len = READ_LEN
+        self.c.on_device = 0
+
+
+def pcie_inclusive(genome_len, coverage, local_rank):
+    """One step of the same path with every batch handed over as HOST buffers on every pass (the boundary's
+    other mode): H2D of bases + N mask + qualities four times, D2H of the new qualities once, synchronous
+    staging.  Bounded sample; reported beside `value`, never as `value`."""
+    from kbbq_amd import _lib
+    n_reads = genome_len * coverage // READ_LEN
+    alpha_ld, cov, approx = plan_parameters(genome_len, coverage, None)
+    e = Engine(K, alpha_ld, SEED_SAMPLER, approx, n_rg=1, max_read_len=READ_LEN, device=local_rank)
+    sp = synth.synth_params(SEED_DATA, genome_len, n_reads, READ_LEN, n_rg=1, paired=False, n_per_million=100)
+    dev = e.synth_reads(sp, 0, n_reads)
+    host, ordinals = [], []
+    for s in range(0, n_reads, BATCH_READS):
+        n = min(BATCH_READS, n_reads - s)
+        host.append(HostPacked(e, dev.view(s, n)))
+        ordinals.append(s * (READ_LEN - K + 1))
+    dev.free()
+    out = np.zeros(BATCH_READS * READ_LEN + 16, dtype=np.uint8)
+    e.sync()
+    t0 = time.perf_counter()
+    for b, o in zip(host, ordinals):
+        e.subsample_kmers(b, o)
+    e.sample_finish()
+    e.compute_thresholds()
+    for b in host:
+        e.find_trusted_kmers(b)
+    e.trusted_finish()
+    for b in host:
+        e.get_covariatedata(b)
+    e.get_dqs()
+    for b in host:
+        _lib.check(e.L.kbbq_recalibrate_batch(e.h, ctypes.byref(b.c), out.ctypes.data))
+    e.sync()
+    dt = time.perf_counter() - t0
+    nb = n_reads * READ_LEN
+    e.close()
+    return dict(value=round(nb / dt / 1e9, 4), unit="Gbases/s", seconds=round(dt, 3),
+                sample="%d reads x %d bp = %.3g bases as host batches of %d reads, every pass re-submits them (5.5 B/base H2D, 1 B/base D2H)"
+                       % (n_reads, READ_LEN, nb, BATCH_READS))
+
+
 def cpu_baseline(e, genome_len, coverage):
     """Oracle (CPU restatement, 1 thread) on a bounded sample of the same workload."""
     from oracle import pyoracle
@@ -122,6 +185,8 @@ def main():
     ap.add_argument("--coverage", type=int, default=30)
     ap.add_argument("--cpu-genome-len", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pcie", action="store_true", help="also time a bounded step with host-resident batches (PCIe-inclusive rate)")
+    ap.add_argument("--pcie-genome-len", type=int, default=100_000_000)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -253,6 +318,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(e, args.cpu_genome_len, cov)
+        if world == 1 and args.pcie:
+            line["pcie_inclusive"] = pcie_inclusive(args.pcie_genome_len, cov, local_rank)
         print(json.dumps(line), flush=True)
     shard.free()
     e.close()
