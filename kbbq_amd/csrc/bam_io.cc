@@ -101,10 +101,9 @@ bool BamRecord::aux_update_string(const char tag[2], const std::string &text, in
 }
 
 // ------------------------------------------------------------------ reader ----
-BamReader::BamReader(const std::string &path) {
-    fh_ = gzopen(path.c_str(), "rb");     // BGZF is a series of gzip members, which gzread concatenates
+BamReader::BamReader(const std::string &path, int threads) {
+    fh_ = open_bytes(path, threads);      // BGZF blocks inflated by a pool; or gzread, which concatenates the members
     if (!fh_) return;
-    gzbuffer(fh_, 1 << 20);
     unsigned char magic[4];
     uint32_t l_text = 0, n_ref = 0;
     if (!read_exact(magic, 4) || memcmp(magic, "BAM\1", 4) != 0) return;
@@ -123,14 +122,12 @@ BamReader::BamReader(const std::string &path) {
     ok_ = true;
 }
 
-BamReader::~BamReader() {
-    if (fh_) gzclose(fh_);
-}
+BamReader::~BamReader() {}
 
 bool BamReader::read_exact(void *dst, size_t n) {
     unsigned char *p = (unsigned char *)dst;
     while (n) {
-        const int got = gzread(fh_, p, (unsigned)std::min<size_t>(n, 1u << 30));
+        const int got = fh_->read(p, (unsigned)std::min<size_t>(n, 1u << 30));
         if (got <= 0) return false;
         p += got;
         n -= (size_t)got;
@@ -141,11 +138,9 @@ bool BamReader::read_exact(void *dst, size_t n) {
 int BamReader::next(BamRecord &rec) {
     if (!ok_) return -2;
     unsigned char len[4];
-    const int got = gzread(fh_, len, 4);
+    const int got = fh_->read(len, 4);
     if (got == 0) return -1;
-    if (got != 4) {
-        if (got > 0 && read_exact(len + got, 4 - (size_t)got)) { /* short read at a member boundary */ } else return -2;
-    }
+    if (got != 4) return -2;
     const uint32_t block = (uint32_t)len[0] | (uint32_t)len[1] << 8 | (uint32_t)len[2] << 16 | (uint32_t)len[3] << 24;
     if (block < 32 || block > (1u << 29)) return -2;
     rec.data.resize(block);

@@ -68,7 +68,7 @@ struct BamRecord {
 
 class BamReader {
 public:
-    explicit BamReader(const std::string &path);
+    explicit BamReader(const std::string &path, int threads = 1);
     ~BamReader();
     bool ok() const { return ok_; }
     const BamHeader &header() const { return header_; }
@@ -76,7 +76,7 @@ public:
 
 private:
     bool read_exact(void *dst, size_t n);
-    gzFile fh_ = nullptr;
+    std::unique_ptr<ByteSource> fh_;
     BamHeader header_;
     bool ok_ = false;
 };

@@ -1,23 +1,186 @@
 // fastq_io.cc -- see fastq_io.h.
 #include "fastq_io.h"
 
+#include <algorithm>
 #include <cstring>
 
 namespace kbbq {
 
+// ------------------------------------------------------------ byte sources ----
+namespace {
+
+class GzSource : public ByteSource {
+public:
+    explicit GzSource(gzFile f) : f_(f) { gzbuffer(f_, 1 << 20); }
+    ~GzSource() override { gzclose(f_); }
+    int read(void *dst, unsigned n) override { return gzread(f_, dst, n); }
+
+private:
+    gzFile f_;
+};
+
+// size of the BGZF block that starts with this gzip header, or 0 if it is not one
+size_t bgzf_block_size(const unsigned char *h, size_t have) {
+    if (have < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return 0;
+    const size_t xlen = h[10] | (size_t)h[11] << 8;
+    if (have < 12 + xlen) return 0;
+    for (size_t at = 12; at + 4 <= 12 + xlen;) {
+        const size_t slen = h[at + 2] | (size_t)h[at + 3] << 8;
+        if (h[at] == 'B' && h[at + 1] == 'C' && slen == 2 && at + 6 <= 12 + xlen) return (size_t)(h[at + 4] | (size_t)h[at + 5] << 8) + 1;
+        at += 4 + slen;
+    }
+    return 0;
+}
+
+class BgzfSource : public ByteSource {
+public:
+    BgzfSource(FILE *f, int threads) : f_(f) {
+        for (int i = 0; i < threads; ++i) pool_.emplace_back(&BgzfSource::worker, this);
+        depth_ = (size_t)threads * 8;
+    }
+    ~BgzfSource() override {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_todo_.notify_all();
+        for (auto &t : pool_) t.join();
+        fclose(f_);
+    }
+    int read(void *dst, unsigned n) override {
+        unsigned char *out = (unsigned char *)dst;
+        unsigned done = 0;
+        while (done < n) {
+            if (cur_ && pos_ < cur_->out.size()) {
+                const size_t take = std::min<size_t>(n - done, cur_->out.size() - pos_);
+                memcpy(out + done, cur_->out.data() + pos_, take);
+                pos_ += take;
+                done += (unsigned)take;
+                continue;
+            }
+            if (!next_block()) return failed_ ? -1 : (int)done;
+        }
+        return (int)done;
+    }
+
+private:
+    struct Job {
+        std::vector<unsigned char> in, out;
+        size_t data_at = 0;
+        bool done = false, ok = true;
+    };
+    void worker() {
+        for (;;) {
+            std::shared_ptr<Job> job;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_todo_.wait(lk, [&] { return stop_ || !todo_.empty(); });
+                if (todo_.empty()) return;
+                job = todo_.front();
+                todo_.pop_front();
+            }
+            bool ok = true;
+            const size_t total = job->in.size();
+            const unsigned char *tail = job->in.data() + total - 8;
+            const uint32_t crc = tail[0] | (uint32_t)tail[1] << 8 | (uint32_t)tail[2] << 16 | (uint32_t)tail[3] << 24;
+            const uint32_t isize = tail[4] | (uint32_t)tail[5] << 8 | (uint32_t)tail[6] << 16 | (uint32_t)tail[7] << 24;
+            job->out.resize(isize);
+            if (isize) {
+                z_stream zs;
+                memset(&zs, 0, sizeof zs);
+                ok = inflateInit2(&zs, -15) == Z_OK;
+                if (ok) {
+                    zs.next_in = job->in.data() + job->data_at;
+                    zs.avail_in = (uInt)(total - 8 - job->data_at);
+                    zs.next_out = job->out.data();
+                    zs.avail_out = isize;
+                    ok = inflate(&zs, Z_FINISH) == Z_STREAM_END && zs.total_out == isize;
+                    inflateEnd(&zs);
+                }
+                ok = ok && (uint32_t)crc32(crc32(0L, Z_NULL, 0), job->out.data(), isize) == crc;
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                job->ok = ok;
+                job->done = true;
+            }
+            cv_done_.notify_all();
+        }
+    }
+    // read compressed blocks ahead until `depth_` are outstanding
+    void feed() {
+        while (!eof_ && order_.size() < depth_) {
+            unsigned char head[18];
+            const size_t got = fread(head, 1, sizeof head, f_);
+            if (got == 0) { eof_ = true; break; }
+            size_t total = bgzf_block_size(head, got);
+            // the size sits in the first subfield in every BGZF writer; anything else ends the stream as an error
+            if (!total || total < 26) { eof_ = true; failed_ = true; break; }
+            auto job = std::make_shared<Job>();
+            job->in.resize(total);
+            memcpy(job->in.data(), head, sizeof head);
+            if (fread(job->in.data() + sizeof head, 1, total - sizeof head, f_) != total - sizeof head) { eof_ = true; failed_ = true; break; }
+            job->data_at = 12 + (job->in[10] | (size_t)job->in[11] << 8);
+            if (job->data_at + 8 > total) { eof_ = true; failed_ = true; break; }
+            order_.push_back(job);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                todo_.push_back(job);
+            }
+            cv_todo_.notify_one();
+        }
+    }
+    bool next_block() {
+        feed();
+        if (order_.empty()) return false;
+        std::shared_ptr<Job> job = order_.front();
+        order_.pop_front();
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_done_.wait(lk, [&] { return job->done; });
+        }
+        if (!job->ok) { failed_ = true; return false; }
+        cur_ = job;
+        pos_ = 0;
+        return true;
+    }
+    FILE *f_;
+    std::vector<std::thread> pool_;
+    std::deque<std::shared_ptr<Job>> order_, todo_;
+    std::shared_ptr<Job> cur_;
+    size_t pos_ = 0, depth_ = 8;
+    std::mutex mu_;
+    std::condition_variable cv_todo_, cv_done_;
+    bool stop_ = false, eof_ = false, failed_ = false;
+};
+
+}  // namespace
+
+std::unique_ptr<ByteSource> open_bytes(const std::string &path, int threads) {
+    if (threads > 1 && path != "-") {
+        FILE *f = fopen(path.c_str(), "rb");
+        if (!f) return nullptr;
+        unsigned char head[18];
+        const size_t got = fread(head, 1, sizeof head, f);
+        if (bgzf_block_size(head, got)) {
+            rewind(f);
+            return std::unique_ptr<ByteSource>(new BgzfSource(f, threads));
+        }
+        fclose(f);
+    }
+    gzFile g = path == "-" ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");
+    if (!g) return nullptr;
+    return std::unique_ptr<ByteSource>(new GzSource(g));
+}
+
 // ------------------------------------------------------------------ reader ----
-FastqReader::FastqReader(const std::string &path) : buf_(1 << 18) {
-    fh_ = path == "-" ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");
-    if (fh_) gzbuffer(fh_, 1 << 20);
-}
-FastqReader::~FastqReader() {
-    if (fh_) gzclose(fh_);
-}
+FastqReader::FastqReader(const std::string &path, int threads) : fh_(open_bytes(path, threads)), buf_(1 << 18) {}
+FastqReader::~FastqReader() {}
 
 int FastqReader::getc_() {
     if (pos_ >= end_) {
         if (eof_) return -1;
-        const int n = gzread(fh_, buf_.data(), (unsigned)buf_.size());
+        const int n = fh_->read(buf_.data(), (unsigned)buf_.size());
         if (n <= 0) { eof_ = true; return -1; }
         pos_ = 0;
         end_ = (size_t)n;
@@ -31,7 +194,7 @@ bool FastqReader::getline_(std::string &out, bool append) {
     for (;;) {
         if (pos_ >= end_) {
             if (eof_) return any;
-            const int n = gzread(fh_, buf_.data(), (unsigned)buf_.size());
+            const int n = fh_->read(buf_.data(), (unsigned)buf_.size());
             if (n <= 0) { eof_ = true; return any; }
             pos_ = 0;
             end_ = (size_t)n;

@@ -24,13 +24,24 @@
 
 namespace kbbq {
 
+// Decompressed bytes of a plain, gzip or BGZF file.  BGZF (every BAM; bgzip-ed FASTQ) is a series of
+// independent <= 64 KiB gzip members whose size is in the header, so with threads > 1 its blocks are inflated
+// by a pool ahead of the consumer (bgzf_mt of htslib, which the reference gets from hts_set_thread_pool,
+// htsiter.hh:64-66,110-112); anything else goes through zlib's gzread on the calling thread.
+class ByteSource {
+public:
+    virtual ~ByteSource() {}
+    virtual int read(void *dst, unsigned n) = 0;   // bytes delivered (short only at the end), 0 at EOF, < 0 on error
+};
+std::unique_ptr<ByteSource> open_bytes(const std::string &path, int threads);
+
 struct FastqRecord {
     std::string name, comment, seq, qual;
 };
 
 class FastqReader {
 public:
-    explicit FastqReader(const std::string &path);
+    explicit FastqReader(const std::string &path, int threads = 1);
     ~FastqReader();
     bool ok() const { return fh_ != nullptr; }
     // >= 0: sequence length; -1: end of file; -2: truncated quality (kseq_read's return values)
@@ -39,7 +50,7 @@ public:
 private:
     int getc_();
     bool getline_(std::string &out, bool append);   // without the line terminator; false at EOF with nothing read
-    gzFile fh_ = nullptr;
+    std::unique_ptr<ByteSource> fh_;
     std::vector<unsigned char> buf_;
     size_t pos_ = 0, end_ = 0;
     int last_char_ = 0;

@@ -107,7 +107,7 @@ public:
 
 class FastqSource : public Source {   // FastqFile + CReadData(kseq_t*), htsiter.cc:49-59, readutils.cc:64-104
 public:
-    explicit FastqSource(const std::string &path) : in_(path) {}
+    FastqSource(const std::string &path, int threads) : in_(path, threads) {}
     bool ok() const override { return in_.ok(); }
     int next(Item &it) override {
         const int rc = in_.next(it.fq);
@@ -129,7 +129,7 @@ private:
 
 class BamSource : public Source {     // BamFile + CReadData(bam1_t*, use_oq), htsiter.cc:5-9, readutils.cc:13-61
 public:
-    BamSource(const std::string &path, bool use_oq) : in_(path), use_oq_(use_oq) {}
+    BamSource(const std::string &path, bool use_oq, int threads) : in_(path, threads), use_oq_(use_oq) {}
     bool ok() const override { return in_.ok(); }
     const BamHeader &header() const { return in_.header(); }
     int next(Item &it) override {
@@ -173,9 +173,10 @@ private:
     bool use_oq_;
 };
 
+static int g_io_threads = 1;   // inflate pool of BGZF inputs (hts_set_thread_pool on the input handle, htsiter.hh:64-66,110-112)
 static std::unique_ptr<Source> open_source(const std::string &path, bool is_bam, bool use_oq) {   // open_file, kbbq.cc:55-64
-    if (is_bam) return std::unique_ptr<Source>(new BamSource(path, use_oq));
-    return std::unique_ptr<Source>(new FastqSource(path));
+    if (is_bam) return std::unique_ptr<Source>(new BamSource(path, use_oq, g_io_threads));
+    return std::unique_ptr<Source>(new FastqSource(path, g_io_threads));
 }
 
 // One batch of reads in the engine's layout, plus the records themselves for the output pass.
@@ -242,8 +243,9 @@ static int fail_engine(const char *what) {
 // without touching the GPU
 static int io_test(int argc, char *argv[]) {
     const std::string what = argc > 2 ? argv[2] : "";
+    const int io_threads = getenv("KBBQ_IO_THREADS") ? atoi(getenv("KBBQ_IO_THREADS")) : 1;
     if (what == "parse" && argc > 3) {
-        FastqReader in(argv[3]);
+        FastqReader in(argv[3], io_threads);
         if (!in.ok()) return 2;
         FastqRecord r;
         ReadGroups groups;
@@ -259,7 +261,7 @@ static int io_test(int argc, char *argv[]) {
         return 0;
     }
     if (what == "bam" && argc > 3) {     // what the passes see of a BAM: --io-test bam FILE [use-oq]
-        BamSource in(argv[3], argc > 4 && std::string(argv[4]) == "use-oq");
+        BamSource in(argv[3], argc > 4 && std::string(argv[4]) == "use-oq", io_threads);
         if (!in.ok()) return 2;
         printf("#text %zu genome %llu refs %zu\n", in.header().text.size(), (unsigned long long)in.header().genome_length(), in.header().refs.size());
         Item it;
@@ -275,7 +277,7 @@ static int io_test(int argc, char *argv[]) {
         return 0;
     }
     if (what == "bamcopy" && argc > 3) { // reader -> (OQ update) -> writer: --io-test bamcopy FILE [set-oq]
-        BamReader in(argv[3]);
+        BamReader in(argv[3], io_threads);
         if (!in.ok()) return 2;
         const bool set_oq = argc > 4 && std::string(argv[4]) == "set-oq";
         BgzfWriter out(stdout);
@@ -344,6 +346,7 @@ int main(int argc, char *argv[]) {
     // --threads sizes the BGZF compression pool like the reference's htslib pool (kbbq.cc:159-168); unlike the
     // reference, 0 does not mean "single-threaded" but "pick": the writer is the end-to-end bottleneck
     const int out_threads = nthreads > 0 ? nthreads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    g_io_threads = out_threads;
     std::string filename("-");
     if (optind < argc) {
         filename = std::string(argv[optind]);

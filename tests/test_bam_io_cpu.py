@@ -1,6 +1,7 @@
 """The BAM codec behind the `kbbq` command line (kbbq_amd/csrc/bam_io.*), without a GPU, through the binary's
 --io-test helpers.  Expected values come from tests/bamutil.py, an independent Python writer/reader, and from
 the rules the reference applies to a record (readutils.hh:30-42, readutils.cc:13-61, htsiter.cc:11-34)."""
+import os
 import subprocess
 
 import numpy as np
@@ -37,10 +38,20 @@ def write_bam(path, recs, refs=(("chr1", 1000), ("chrUn_x", 234567)), text="@HD\
     return stream
 
 
+THREADS = {"KBBQ_IO_THREADS": "1"}      # set per test: 1 = zlib's gzread on the caller, > 1 = pool of inflaters over the BGZF blocks
+
+
 def io_bam(path, *more):
-    p = subprocess.run([CLI, "--io-test", "bam", str(path)] + list(more), capture_output=True, text=True)
+    p = subprocess.run([CLI, "--io-test", "bam", str(path)] + list(more), capture_output=True, text=True, env=dict(os.environ, **THREADS))
     lines = p.stdout.rstrip("\n").split("\n")
     return lines[0], [ln.split("\t") for ln in lines[1:-1]], int(lines[-1].split()[1]), p.stderr
+
+
+@pytest.fixture(params=[1, 4], autouse=True)
+def io_threads(request):
+    THREADS["KBBQ_IO_THREADS"] = str(request.param)
+    yield request.param
+    THREADS["KBBQ_IO_THREADS"] = "1"
 
 
 @pytest.mark.parametrize("ragged", [None, 7])
@@ -108,14 +119,24 @@ def test_truncated_and_foreign_files(tmp_path):
     _, rows, rc, _ = io_bam(p)
     assert rc == -2 and len(rows) == 9                 # sam_read1 reports a truncated record as an error
     p.write_bytes(bamutil.bgzf_compress(b"BAM\2" + stream[4:]))
-    assert subprocess.run([CLI, "--io-test", "bam", str(p)], capture_output=True).returncode == 2
+    assert subprocess.run([CLI, "--io-test", "bam", str(p)], capture_output=True, env=dict(os.environ, **THREADS)).returncode == 2
+    # a block whose checksum does not match its data, and a file cut in the middle of a block
+    good = bamutil.bgzf_compress(stream, block=4000)
+    bad = bytearray(good)
+    bad[len(good) // 2] ^= 0x55
+    for blob in (bytes(bad), good[:len(good) // 2]):
+        p.write_bytes(blob)
+        run = subprocess.run([CLI, "--io-test", "bam", str(p)], capture_output=True, text=True, env=dict(os.environ, **THREADS))
+        lines = run.stdout.rstrip("\n").split("\n")
+        # never a clean end of file: either the header already fails (zlib reads ahead) or the records stop with an error
+        assert run.returncode == 2 or (lines[-1].startswith("#end") and int(lines[-1].split()[1]) < -1 and len(lines) - 2 < 10)
 
 
 def test_writer_round_trip_and_set_oq(tmp_path):
     recs = some_records(seed=5)
     p = tmp_path / "a.bam"
     stream = write_bam(p, recs, ragged=11)
-    out = subprocess.run([CLI, "--io-test", "bamcopy", str(p)], capture_output=True, check=True).stdout
+    out = subprocess.run([CLI, "--io-test", "bamcopy", str(p)], capture_output=True, check=True, env=dict(os.environ, **THREADS)).stdout
     assert out[-28:] == bamutil.BGZF_EOF
     assert bamutil.bgzf_decompress(out) == stream      # header, references and every record byte for byte
     out = subprocess.run([CLI, "--io-test", "bamcopy", str(p), "set-oq"], capture_output=True, check=True).stdout

@@ -67,6 +67,22 @@ def test_reader_plain_gzip_multiline_and_comments(tmp_path):
         assert [r[4] for r in recs] == ["0", "1", "0", "0", "0"]          # second-in-pair from the /2 suffix
 
 
+def test_reader_on_bgzf_input_with_the_inflate_pool(tmp_path):
+    import bamutil
+    rng = np.random.RandomState(5)
+    text = "".join("@r%d_RG:Z:g%d extra\n%s\n+\n%s\n" % (i, i % 3, "".join(rng.choice(list("ACGTN"), 151)), "".join(chr(c) for c in rng.randint(35, 74, 151)))
+                   for i in range(4000))
+    plain, bg = tmp_path / "a.fq", tmp_path / "a.fq.bgz"
+    plain.write_text(text)
+    bg.write_bytes(bamutil.bgzf_compress(text.encode(), ragged_seed=3))
+    want = parse(plain)
+    for threads in ("1", "6"):
+        out = subprocess.run([CLI, "--io-test", "parse", str(bg)], capture_output=True, text=True, check=True,
+                             env=dict(os.environ, KBBQ_IO_THREADS=threads)).stdout
+        lines = out.rstrip("\n").split("\n")
+        assert ([ln.split("\t") for ln in lines[:-1]], int(lines[-1].split()[1])) == want
+
+
 def test_reader_reports_truncated_quality(tmp_path):
     p = tmp_path / "t.fq"
     p.write_text("@a\nACGT\n+\nIIII\n@b\nACGT\n+\nII\n")
