@@ -412,7 +412,8 @@ int main(int argc, char *argv[]) {
             n_reads += batch.c.n_reads;
             if (batch.saw_empty && resident.on) resident.drop();
             if (resident.on && batch.longest <= KBBQ_MAX_READ_LEN) {
-                const uint64_t need = batch.c.n_bases + batch.c.n_bases / 2 + batch.c.n_reads * 16 + 4096;
+                // qualities 1 B + bases 1/4 + N mask 1/8 + two hint arrays 1/4 per base; offsets, flags, read groups per read
+                const uint64_t need = batch.c.n_bases * 13 / 8 + batch.c.n_reads * 16 + (1 << 16);
                 kbbq_reads d;
                 if (resident.bytes + need > resident.budget || kbbq_reads_upload(nullptr, &batch.c, &d) < 0) {
                     resident.drop();
