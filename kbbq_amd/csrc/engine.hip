@@ -55,7 +55,7 @@ static int fail(int code, const char *fmt, ...) {
 // position, htsiter.cc:113-129).  xoshiro256 is linear over GF(2), so the state
 // after n draws is (x^n mod P)(M) applied to the seed state; each lane jumps to
 // its own chunk of DRAWS_PER_LANE consecutive draws and emits a bit mask.
-constexpr int DRAWS_PER_LANE = 2048;   // multiple of 64: each lane owns whole mask words
+constexpr int DRAWS_PER_LANE = 4096;   // multiple of 64: each lane owns whole mask words
 
 __constant__ uint64_t c_jump[64][4];
 
@@ -919,19 +919,23 @@ struct DqDev {
     int n_rg, n_cycle;
 };
 
-__global__ void __launch_bounds__(256) k_recalibrate(ReadsDev R, DqDev D, uint8_t *out, int minqual, int vec_ok, int lds_rgs) {
-    // the delta-Q tables of the first `lds_rgs` read groups sit in LDS (a few tens of KB): 48 dependent
-    // table reads per lane then cost LDS, not L2, latency
+__global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8_t *out, int minqual, int vec_ok, int lds_rgs) {
+    // the delta-Q tables of the first `lds_rgs` read groups sit in LDS: per read group one int16 per
+    // (q, second, cycle) holding meanq + rg + q delta-Q + cycle delta-Q already summed, and the int8
+    // dinucleotide delta-Q -- two dependent LDS reads per base instead of three global ones
     extern __shared__ uint8_t l_tab[];
-    const int cyc_bytes = KBBQ_NQ * 2 * D.n_cycle, di_bytes = KBBQ_NQ * 16, base_bytes = KBBQ_NQ * 2;
-    const int per_rg = (cyc_bytes + di_bytes + base_bytes + 3) & ~3;
-    for (int i = threadIdx.x; i < lds_rgs * per_rg; i += blockDim.x) {
-        const int rg = i / per_rg, o = i % per_rg;
-        uint8_t v = 0;
-        if (o < cyc_bytes) v = (uint8_t)D.cycle[(size_t)rg * cyc_bytes + o];
-        else if (o < cyc_bytes + di_bytes) v = (uint8_t)D.dinuc[(size_t)rg * di_bytes + (o - cyc_bytes)];
-        else if (o < cyc_bytes + di_bytes + base_bytes) v = reinterpret_cast<const uint8_t *>(D.base)[(size_t)rg * base_bytes + (o - cyc_bytes - di_bytes)];
-        l_tab[i] = v;
+    const int cyc_cells = KBBQ_NQ * 2 * D.n_cycle, di_bytes = KBBQ_NQ * 16;
+    const int cyc_bytes = 2 * cyc_cells;
+    const int per_rg = (cyc_bytes + di_bytes + 3) & ~3;
+    for (int i = threadIdx.x; i < lds_rgs * (cyc_cells + di_bytes); i += blockDim.x) {
+        const int rg = i / (cyc_cells + di_bytes), o = i % (cyc_cells + di_bytes);
+        if (o < cyc_cells) {
+            const int q = o / (2 * D.n_cycle);
+            reinterpret_cast<int16_t *>(l_tab + (size_t)rg * per_rg)[o] =
+                (int16_t)(D.base[rg * KBBQ_NQ + q] + D.cycle[(size_t)rg * cyc_cells + o]);
+        } else {
+            l_tab[(size_t)rg * per_rg + cyc_bytes + (o - cyc_cells)] = (uint8_t)D.dinuc[(size_t)rg * di_bytes + (o - cyc_cells)];
+        }
     }
     __syncthreads();
     // persistent blocks: the table load above is paid once per block, not once per 4 KB of qualities
@@ -993,7 +997,7 @@ __global__ void __launch_bounds__(256) k_recalibrate(ReadsDev R, DqDev D, uint8_
             const bool use_di = cyc > 0 && !nn && !prev_n;
             if (rg < lds_rgs) {
                 const uint8_t *t = l_tab + rg * per_rg;
-                v = *reinterpret_cast<const int16_t *>(t + cyc_bytes + di_bytes + 2 * q) + (int8_t)t[(q * 2 + second) * D.n_cycle + cyc];
+                v = reinterpret_cast<const int16_t *>(t)[(q * 2 + second) * D.n_cycle + cyc];
                 if (use_di) v += (int8_t)t[cyc_bytes + q * 16 + ((prev_b << 2) | b)];
             } else {
                 v = D.base[cell] + D.cycle[((uint64_t)cell * 2 + second) * D.n_cycle + cyc];
@@ -1680,9 +1684,13 @@ int kbbq_sample_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t first_km
     {
         Timed t(e, "k_draw_mask");
         const uint64_t lanes = (n_draws + DRAWS_PER_LANE - 1) / DRAWS_PER_LANE;
+        // the host jumps to the batch's first draw (a few thousand xoshiro steps); the lanes then only jump by
+        // their offset inside the batch, which has far fewer set bits than the file-wide ordinal
+        uint64_t st[4];
+        xoshiro_state_at(e->p.seed, first_kmer_ordinal, st);
         hipLaunchKernelGGL(k_draw_mask, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, e->stream,
-                           e->seed_state.s[0], e->seed_state.s[1], e->seed_state.s[2], e->seed_state.s[3],
-                           first_kmer_ordinal, n_draws, e->draw_threshold, e->draw_always ? 1 : 0, mask);
+                           st[0], st[1], st[2], st[3],
+                           (uint64_t)0, n_draws, e->draw_threshold, e->draw_always ? 1 : 0, mask);
         HIP_TRY(hipGetLastError());
     }
     return dispatch_nw<LaunchSample>(max_len, e, R, (const uint64_t *)mask, n_draws / 64 + 2, kofs);
@@ -2064,10 +2072,10 @@ static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qu
         Timed t(e, "k_recalibrate");
         const uint64_t lanes = (R.n_bases + 15) / 16;
         const int vec_ok = (((uintptr_t)R.qual | (uintptr_t)d_out) & 15) == 0;
-        const int per_rg = (KBBQ_NQ * 2 * D.n_cycle + KBBQ_NQ * 16 + KBBQ_NQ * 2 + 3) & ~3;
-        const int lds_rgs = std::max(0, std::min(D.n_rg, (48 * 1024) / per_rg));   // keep >= 3 blocks per CU
-        const unsigned blocks = (unsigned)std::min<uint64_t>((lanes + 255) / 256, 256 * 4);
-        hipLaunchKernelGGL(k_recalibrate, dim3(blocks), dim3(256), (size_t)lds_rgs * per_rg, e->stream,
+        const int per_rg = (2 * KBBQ_NQ * 2 * D.n_cycle + KBBQ_NQ * 16 + 3) & ~3;
+        const int lds_rgs = std::max(0, std::min(D.n_rg, (64 * 1024) / per_rg));   // two 1024-lane blocks per CU share 160 KB
+        const unsigned blocks = (unsigned)std::min<uint64_t>((lanes + 1023) / 1024, 256 * 2);
+        hipLaunchKernelGGL(k_recalibrate, dim3(blocks), dim3(1024), (size_t)lds_rgs * per_rg, e->stream,
                            R, D, d_out, 6, vec_ok, lds_rgs);
         HIP_TRY(hipGetLastError());
     }
