@@ -11,7 +11,7 @@ import pytest
 
 import common
 from kbbq_amd import _lib, synth
-from kbbq_amd.engine import Engine, device_tensor
+from kbbq_amd.engine import Engine, device_tensor, plan_parameters
 from kbbq_amd.reads import ReadBatch
 
 pytestmark = pytest.mark.gpu
@@ -313,4 +313,97 @@ def test_error_codes():
     assert ei.value.code == -1
     with pytest.raises(_lib.KbbqError):
         e.recalibrate(b)              # no delta-Q tables yet
+    e.close()
+
+
+def test_properties_at_scale_on_device_generated_reads():
+    """6·10⁹ bases (1/15 of BASELINE configs[1]; the oracle would need a quarter of an hour), so size-independent
+    properties instead of an oracle comparison: the run must not depend on how the reads are cut into batches or
+    on the hint arrays; the sampler's insert count must be the Bernoulli sum it is; every base is tallied exactly
+    once; the trusted filter only ever receives k-mers whose bases passed; qualities below 6 come out untouched;
+    and filters built by two disjoint halves OR to the filter of the whole (what the multi-GPU exchange relies on)."""
+    import torch
+    G, cov, L, k = 200_000_000, 30, 150, 32
+    n_reads = G * cov // L
+    n_reads -= n_reads % 64
+    alpha_ld, cov, approx = plan_parameters(G, cov, None)
+    sp = synth.synth_params(4711, G, n_reads, L, n_rg=1, paired=False, n_per_million=150)
+    nk = L - k + 1
+
+    def run(cuts, hints, keep_tables=False):
+        e = Engine(k, alpha_ld, 99, approx, n_rg=1, max_read_len=L)
+        dev = e.synth_reads(sp, 0, n_reads)
+        hbuf = None
+        if hints:
+            nbytes = (n_reads * L // 64 + 2) * 8
+            hbuf = torch.zeros(2 * nbytes, dtype=torch.uint8, device="cuda")
+            dev.set_hints(hbuf.data_ptr(), hbuf.data_ptr() + nbytes)
+        views = [dev.view(a, b - a) for a, b in zip(cuts[:-1], cuts[1:])]
+        for v, a in zip(views, cuts[:-1]):
+            e.subsample_kmers(v, a * nk)
+        out = dict(sampled=e.sample_finish())
+        out["thr"] = e.compute_thresholds()
+        for v in views:
+            e.find_trusted_kmers(v)
+        out["trusted"] = e.trusted_finish()
+        for v in views:
+            e.get_covariatedata(v)
+        out["cov"] = e.covariates()
+        out["dq"] = e.get_dqs()
+        q_new = torch.zeros(n_reads * L + 16, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        for v, a in zip(views, cuts[:-1]):
+            e.recalibrate(v, q_new.data_ptr() + a * L)
+        e.sync()
+        q_old = device_tensor(dev.c.qual, n_reads * L, torch.uint8)
+        out.update(sum=0, changed=0, max=0, low_untouched=True)
+        for c0 in range(0, n_reads * L, 1 << 30):      # in pieces: 6e9 elements are beyond 32-bit indexing
+            qn, qo = q_new[c0:min(c0 + (1 << 30), n_reads * L)], q_old[c0:min(c0 + (1 << 30), n_reads * L)]
+            out["sum"] += int(qn.sum(dtype=torch.int64).item())
+            out["changed"] += int((qn != qo).sum().item())
+            out["max"] = max(out["max"], int(qn.max().item()))
+            out["low_untouched"] &= not bool(((qo < 6) & (qn != qo)).any().item())
+        out["pop"] = [int(device_tensor(e.L.kbbq_filter_device_table(e.h, w), e.filter_info(w)["table_bytes"], torch.uint8)
+                          .sum(dtype=torch.int64).item()) for w in (0, 1)]   # byte sums as a cheap fingerprint of the bit arrays
+        out["stats"] = e.stats()
+        if keep_tables:
+            out["tables"] = [device_tensor(e.L.kbbq_filter_device_table(e.h, w), e.filter_info(w)["table_bytes"], torch.int64).clone() for w in (0, 1)]
+            torch.cuda.synchronize()
+        dev.free()
+        e.close()
+        return out
+
+    whole = run([0, n_reads], hints=True, keep_tables=True)
+    third = n_reads // 3 // 64 * 64
+    parts = run([0, 64, third, 2 * third + 640, n_reads], hints=False)
+    for key in ("sampled", "trusted", "sum", "pop", "changed"):
+        assert whole[key] == parts[key], key
+    assert whole["thr"][0].tolist() == parts["thr"][0].tolist()
+    for key in ("cycle", "dinuc"):
+        assert np.array_equal(whole["cov"][key], parts["cov"][key])
+    # the sampler: one Bernoulli(alpha) draw per k-mer position, inserted when the k-mer has no N
+    n_pos = n_reads * nk
+    a = float(alpha_ld)
+    assert abs(whole["sampled"] - a * n_pos) < 6 * (n_pos * a * (1 - a)) ** 0.5 + 0.01 * a * n_pos      # N-containing k-mers are < 1 %
+    assert 0 < whole["trusted"] <= n_pos
+    # every base tallied once (covariateutils.cc:193-202), errors never exceed totals
+    cyc = whole["cov"]["cycle"]
+    assert int(cyc[..., 1].sum()) == n_reads * L and (cyc[..., 0] <= cyc[..., 1]).all()
+    assert int(whole["cov"]["dinuc"][..., 1].sum()) <= n_reads * (L - 1)
+    # (the generator's substitution rate is 10^(-q/10) per base, so at this size the model finds the data
+    # calibrated and may change nothing at all: "changed" is compared between the runs above, not against zero)
+    assert whole["low_untouched"] and whole["max"] <= 93
+    # OR of the filters of two disjoint halves of the reads == filter of all reads (exchange step, SURVEY 8e)
+    half = n_reads // 2 // 64 * 64
+    e = Engine(k, alpha_ld, 99, approx, n_rg=1, max_read_len=L)
+    dev = e.synth_reads(sp, 0, n_reads)
+    tabs = []
+    for a0, b0 in ((0, half), (half, n_reads)):
+        e.reset()
+        e.subsample_kmers(dev.view(a0, b0 - a0), a0 * nk)
+        e.sample_finish()
+        tabs.append(device_tensor(e.L.kbbq_filter_device_table(e.h, 0), e.filter_info(0)["table_bytes"], torch.int64).clone())
+        torch.cuda.synchronize()      # the copy runs on torch's stream, the next reset on the engine's
+    assert torch.equal(tabs[0] | tabs[1], whole["tables"][0])
+    dev.free()
     e.close()
