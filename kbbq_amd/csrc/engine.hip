@@ -1568,10 +1568,16 @@ int kbbq_reads_upload(kbbq_engine *e, const kbbq_reads *host, kbbq_reads *dev) {
 #define UP(field, type, count, pad)                                                               \
     if (host->field) {                                                                            \
         void *d = nullptr;                                                                        \
-        HIP_TRY(hipMalloc(&d, ((count) + (pad)) * sizeof(type)));                                 \
-        HIP_TRY(hipMemset(d, 0, ((count) + (pad)) * sizeof(type)));                               \
-        HIP_TRY(hipMemcpy(d, host->field, (count) * sizeof(type), hipMemcpyHostToDevice));        \
-        dev->field = (const type *)d;                                                             \
+        hipError_t he = hipMalloc(&d, ((count) + (pad)) * sizeof(type));                          \
+        if (he == hipSuccess) {                                                                   \
+            dev->field = (const type *)d;                                                         \
+            he = hipMemset(d, 0, ((count) + (pad)) * sizeof(type));                               \
+        }                                                                                         \
+        if (he == hipSuccess) he = hipMemcpy(d, host->field, (count) * sizeof(type), hipMemcpyHostToDevice); \
+        if (he != hipSuccess) {                                                                   \
+            kbbq_reads_free(nullptr, dev);   /* what was allocated so far */                      \
+            return fail(he == hipErrorOutOfMemory ? KBBQ_ENOMEM : KBBQ_EIO, "upload of %s: %s", #field, hipGetErrorString(he)); \
+        }                                                                                         \
     }
     UP(bases, uint64_t, host->n_bases / 32 + 1, 1)
     UP(nmask, uint64_t, host->n_bases / 64 + 1, 1)
