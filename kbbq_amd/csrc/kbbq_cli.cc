@@ -190,6 +190,7 @@ struct Batch {
     bool stop_at_empty = false;   // next_str() != "" loops end at the first empty read (kbbq.cc:234, htsiter.cc:95)
     bool fatal = false;
     bool saw_empty = false;       // an empty read went into this batch
+    bool ended = false;           // stop_at_empty met its empty read: this pass over the source is over
     size_t longest = 0;           // longest read of this batch
     Item it;
 
@@ -199,11 +200,11 @@ struct Batch {
         off.assign(1, 0);
         saw_empty = false;
         longest = 0;
-        while (rg.size() < max_reads) {
+        while (!ended && rg.size() < max_reads) {
             const int rc = in.next(it);
             if (rc == SRC_FATAL) { fatal = true; return false; }
             if (rc < 0) break;                       // -1 end of file; < -1 error: the reference's loops also just end
-            if (stop_at_empty && it.seq.empty()) break;
+            if (stop_at_empty && it.seq.empty()) { ended = true; break; }
             if (it.seq.empty()) saw_empty = true;
             longest = std::max(longest, it.seq.size());
             seq.insert(seq.end(), it.seq.begin(), it.seq.end());
@@ -513,6 +514,7 @@ int main(int argc, char *argv[]) {
                 }
                 if (batch.fatal) return 1;
                 batch.stop_at_empty = false;
+                batch.ended = false;
             }
             uint64_t inserted = 0;
             if (kbbq_sample_finish(e, &inserted) < 0) return fail_engine("sampling");

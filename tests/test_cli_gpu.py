@@ -264,3 +264,52 @@ def test_cli_bam_fixed_mode_and_errors(tmp_path):
     bare.write_bytes(b"CRAM" + b"\0" * 40)
     rc, out, err = run_cli([bare])
     assert rc != 0 and "CRAM" in err
+
+
+def test_cli_empty_read_ends_sampling_and_coverage_but_not_the_other_passes(tmp_path):
+    """next_str() == "" is the reference's end-of-file test in the coverage pass (kbbq.cc:234) and in the sampler
+    (htsiter.cc:95), so an empty record stops those two loops; find_trusted_kmers, get_covariatedata and the output
+    pass loop on next() >= 0 and see every record (recalibrateutils.cc:21,47,96)."""
+    d, names, n_rg = named_dataset(seed=21, genome_len=20000, coverage=30, read_len=100)
+    n = len(names)
+    cut = n * 2 // 3
+    off = d["off"].astype(np.int64)
+    seq, qual = d["seq"].tobytes(), (d["qual"] + 33).astype(np.uint8).tobytes()
+    fq = tmp_path / "in.fq"
+    with open(fq, "wb") as fh:
+        for r in range(n):
+            if r == cut:
+                fh.write(b"@empty/1\n\n+\n\n")
+            fh.write(b"@" + names[r].encode() + b"\n" + seq[off[r]:off[r + 1]] + b"\n+\n" + qual[off[r]:off[r + 1]] + b"\n")
+    rc, out, err = run_cli(["-g", d["genome_len"], fq], {"KBBQ_SEED": "9"})
+    assert rc == 0, err
+    assert "resident" not in err                       # the passes do not see the same reads: no shortcut
+    total_before = int(off[cut])
+    coverage = total_before // d["genome_len"]
+    assert "Total Sequence length: %d" % total_before in err and "Estimated coverage: %d" % coverage in err
+    # the same thing with the oracle: sample the reads before the empty one, everything else on all reads
+    lens = np.diff(off)
+    lens2 = np.concatenate([lens[:cut], [0], lens[cut:]])
+    off2 = np.concatenate([[0], np.cumsum(lens2)]).astype(np.uint64)
+    rg2 = np.concatenate([d["rg"][:cut], [d["rg"][cut - 1] * 0 + ref_rg_index_of_empty(names, cut)], d["rg"][cut:]]).astype(np.int32)
+    sec2 = np.concatenate([d["second"][:cut], [0], d["second"][cut:]]).astype(np.uint8)
+    alpha_ld, cov, approx = common.plan_parameters(d["genome_len"], coverage, None)
+    o = common.pyoracle.Oracle(32, alpha_ld, 9, approx)
+    o.sample(d["seq"][:total_before], d["off"][:cut + 1])
+    assert " Sampled %d valid kmers." % o.filter_info(0)["inserted"] in err
+    o.compute_thresholds()
+    o.trusted(d["seq"], d["qual"], off2)
+    o.errors(d["seq"], d["qual"], off2, rg2, sec2, tally=True)
+    o.train()
+    want = o.recalibrate(d["seq"], d["qual"], off2, rg2, sec2)
+    recs = read_fastq_text(gzip.decompress(out))
+    assert len(recs) == n + 1 and recs[cut] == ("@empty/1", "", "+", "")
+    got = "".join(q for _, _, _, q in recs)
+    assert got == (want + 33).astype(np.uint8).tobytes().decode()
+
+
+def ref_rg_index_of_empty(names, cut):
+    """Dense read-group index the empty read '@empty/1' gets: its group is "" (no RG field), which the first reads
+    of named_dataset already introduced as index 0."""
+    assert ref_name_rules(names[0])[0] == "" and cut > 0
+    return 0
