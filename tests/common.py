@@ -123,6 +123,10 @@ PARITY_CASES = {
     "k12_clusters": (make_dataset, dict(seed=12, genome_len=6000, coverage=30, read_len=100, clusters=50), dict(k=12),
                      dict(uniform=True)),
     "repeat_ties": (make_repeat_dataset, dict(), dict(k=21), dict(uniform=True)),
+    # BASELINE.json configs[0] (1 Mbp, 20x, k=32: the reference's own CPU-runnable case) and configs[4] (60x, k=21,
+    # -c 60 -a 0.05) at oracle-friendly genome sizes
+    "config0_1Mbp_20x": (make_dataset, dict(seed=2020, genome_len=1_000_000, coverage=20), dict(), dict(uniform=True, n_batches=2)),
+    "config4_60x_k21": (make_dataset, dict(seed=6021, genome_len=40_000, coverage=60), dict(k=21, alpha=0.05), dict(uniform=True)),
     "reads_400": (make_dataset, dict(seed=400, genome_len=20000, coverage=20, read_len=400, n_per_million=500,
                                      extra_errors=60), dict(), dict(uniform=True)),
 }
