@@ -1137,6 +1137,16 @@ struct kbbq_engine {
     kbbq_params p;
     KParams K;
     hipStream_t stream = nullptr;
+    // Pass 3 alternates device-resident batches between two streams: the latency-bound correction walk and the
+    // ALU-bound tally of batch i run beside the memory-bound Bloom scan of batch i+1.  Every scratch array of
+    // the pass and its counters exist twice; an event per side says when a side's buffers are free again.
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_main = nullptr, ev_side[2] = {nullptr, nullptr};
+    bool side_busy[2] = {false, false};     // counters of that side not yet added to stats
+    uint64_t side_reads[2] = {0, 0};
+    int side_turn = 0;
+    hipStream_t cur = nullptr;              // stream and counter pair the pass-3 launch helpers use
+    unsigned long long *cur_cnt = nullptr;
     FilterHost filt[2];
     Xoshiro256 seed_state;
     uint64_t draw_threshold = 0;
@@ -1152,8 +1162,8 @@ struct kbbq_engine {
     int8_t *d_dq_cycle = nullptr;
     int8_t *d_dq_dinuc = nullptr;
     // scratch
-    void *scratch[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    void *scratch[16] = {};
+    size_t scratch_bytes[16] = {};
     unsigned long long *d_counters = nullptr;   // [0] work-list length, [1] correction queries, [2] scan total
     std::vector<void *> staged;   // device copies of host batches, freed at the next sync
     uint64_t stats[4] = {0, 0, 0, 0};
@@ -1170,6 +1180,7 @@ int ensure_scratch(kbbq_engine *e, int idx, size_t bytes) {
     if (e->scratch_bytes[idx] >= bytes) return KBBQ_OK;
     if (e->scratch[idx]) {
         HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream2));
         HIP_TRY(hipFree(e->scratch[idx]));
         e->scratch[idx] = nullptr;
         e->scratch_bytes[idx] = 0;
@@ -1184,7 +1195,8 @@ struct Timed {
     kbbq_engine *e;
     int slot = -1;
     hipEvent_t a = nullptr, b = nullptr;
-    Timed(kbbq_engine *e_, const char *name) : e(e_) {
+    hipStream_t on = nullptr;
+    Timed(kbbq_engine *e_, const char *name, hipStream_t stream = nullptr) : e(e_), on(stream ? stream : e_->stream) {
         if (!(e->p.flags & KBBQ_F_PROFILE)) return;
         for (size_t i = 0; i < e->prof.size(); ++i)
             if (e->prof[i].name == name) slot = (int)i;
@@ -1196,11 +1208,11 @@ struct Timed {
         }
         hipEventCreate(&a);
         hipEventCreate(&b);
-        hipEventRecord(a, e->stream);
+        hipEventRecord(a, on);
     }
     ~Timed() {
         if (slot < 0) return;
-        hipEventRecord(b, e->stream);
+        hipEventRecord(b, on);
         PendingEvent pe = {slot, a, b};
         e->pending.push_back(pe);
     }
@@ -1220,8 +1232,26 @@ void drain_profile(kbbq_engine *e) {
     e->pending.clear();
 }
 
+// add the finished work-list and query counters of one side of pass 3 to the run's statistics
+int collect_side(kbbq_engine *e, int t) {
+    if (!e->side_busy[t]) return KBBQ_OK;
+    HIP_TRY(hipEventSynchronize(e->ev_side[t]));
+    unsigned long long c[2];
+    HIP_TRY(hipMemcpy(c, e->d_counters + 4 * t, 16, hipMemcpyDeviceToHost));
+    e->stats[0] += c[0];
+    e->stats[1] += c[1];
+    e->stats[2] += e->side_reads[t];
+    e->side_busy[t] = false;
+    return KBBQ_OK;
+}
+
 int sync_engine(kbbq_engine *e) {
     HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream2));
+    for (int t = 0; t < 2; ++t) {
+        int rc = collect_side(e, t);
+        if (rc) return rc;
+    }
     drain_profile(e);
     for (size_t i = 0; i < e->staged.size(); ++i) hipFree(e->staged[i]);
     e->staged.clear();
@@ -1363,6 +1393,11 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
         }
     }
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_side[0], hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_side[1], hipEventDisableTiming);
+    e->cur = e->stream;
     if (he != hipSuccess) { delete e; return fail(KBBQ_EIO, "hipStreamCreate: %s", hipGetErrorString(he)); }
 #define CREATE_TRY(expr)                                                                           \
     do {                                                                                           \
@@ -1376,6 +1411,7 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
     } while (0)
     CREATE_TRY(hipMalloc(&e->d_counters, 64));
     CREATE_TRY(hipMemset(e->d_counters, 0, 64));
+    e->cur_cnt = e->d_counters;
     for (int w = 0; w < 2; ++w) {
         FilterHost &f = e->filt[w];
         CREATE_TRY(hipMalloc(&f.d_table, f.table_bytes()));
@@ -1423,13 +1459,18 @@ void kbbq_engine_destroy(kbbq_engine *e) {
     hipFree(e->d_counters);
     hipFree(e->d_qcum);
     hipFree(e->d_errthr);
-    for (int i = 0; i < 10; ++i) hipFree(e->scratch[i]);
+    for (int i = 0; i < 16; ++i) hipFree(e->scratch[i]);
+    if (e->stream2) { hipStreamSynchronize(e->stream2); hipStreamDestroy(e->stream2); }
+    if (e->ev_main) hipEventDestroy(e->ev_main);
+    for (int i = 0; i < 2; ++i) if (e->ev_side[i]) hipEventDestroy(e->ev_side[i]);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
 
 int kbbq_engine_reset(kbbq_engine *e) {
     if (!e) return fail(KBBQ_EINVAL, "null engine");
+    int rc0 = sync_engine(e);     // a tally may still be adding to the histograms on the side stream
+    if (rc0) return rc0;
     for (int w = 0; w < 2; ++w) {
         HIP_TRY(hipMemsetAsync(e->filt[w].d_table, 0, e->filt[w].table_bytes(), e->stream));
         HIP_TRY(hipMemsetAsync(e->filt[w].d_inserted, 0, 8, e->stream));
@@ -1816,17 +1857,17 @@ int kbbq_trusted_finish(kbbq_engine *e, uint64_t *inserted) {
 }  // extern "C"
 template <int NW> struct LaunchFixSingle {
     static int go(kbbq_engine *e, ReadsDev R, const uint32_t *list, const uint64_t *tmask, uint32_t *err_bits, uint8_t *dirty) {
-        Timed t(e, "k_fix_single");
-        hipLaunchKernelGGL(k_fix_single<NW>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K, e->filt[1].dev(),
-                           list, (const unsigned long long *)&e->d_counters[0], tmask, err_bits, dirty, e->d_counters);
+        Timed t(e, "k_fix_single", e->cur);
+        hipLaunchKernelGGL(k_fix_single<NW>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->cur, R, e->K, e->filt[1].dev(),
+                           list, (const unsigned long long *)e->cur_cnt, tmask, err_bits, dirty, e->cur_cnt);
         HIP_TRY(hipGetLastError());
         return KBBQ_OK;
     }
 };
 template <int NW> struct LaunchScan {
     static int go(kbbq_engine *e, ReadsDev R, uint64_t *tmask, uint8_t *dirty) {
-        Timed t(e, "k_scan_trusted");
-        hipLaunchKernelGGL(k_scan_trusted<NW>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
+        Timed t(e, "k_scan_trusted", e->cur);
+        hipLaunchKernelGGL(k_scan_trusted<NW>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->cur, R, e->K,
                            e->filt[1].dev(), tmask, dirty);
         HIP_TRY(hipGetLastError());
         return KBBQ_OK;
@@ -1846,11 +1887,11 @@ static int launch_correct(kbbq_engine *e, ReadsDev R, const uint32_t *list, cons
         HIP_TRY(hipFuncSetAttribute((const void *)k_correct<MAXL, BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    Timed t(e, "k_correct");
+    Timed t(e, "k_correct", e->cur);
     // the work-list length is only known on the device: size the grid for the batch and let lanes stride
     const int blocks = (int)std::min<uint64_t>((R.n_reads + BLOCK - 1) / BLOCK, 256 * 8);
-    hipLaunchKernelGGL((k_correct<MAXL, BLOCK>), dim3(blocks), dim3(BLOCK), lds, e->stream, R, e->K, e->filt[1].dev(), list,
-                       (const unsigned long long *)&e->d_counters[0], tmask, tw, err_bits, patch, e->d_counters);
+    hipLaunchKernelGGL((k_correct<MAXL, BLOCK>), dim3(blocks), dim3(BLOCK), lds, e->cur, R, e->K, e->filt[1].dev(), list,
+                       (const unsigned long long *)e->cur_cnt, tmask, tw, err_bits, patch, e->cur_cnt);
     HIP_TRY(hipGetLastError());
     return KBBQ_OK;
 }
@@ -1862,16 +1903,18 @@ extern "C" {
 template <int NB, int NN>
 static int launch_correct_wave(kbbq_engine *e, ReadsDev R, const uint32_t *list, const uint64_t *tmask, int tw,
                                uint32_t *err_bits, uint32_t *patch) {
-    Timed t(e, "k_correct_wave");
+    Timed t(e, "k_correct_wave", e->cur);
     const int blocks = (int)std::min<uint64_t>((R.n_reads + 3) / 4, 256 * 16);
-    hipLaunchKernelGGL((k_correct_wave<NB, NN>), dim3(blocks), dim3(256), 0, e->stream, R, e->K, e->filt[1].dev(), list,
-                       (const unsigned long long *)&e->d_counters[0], tmask, tw, err_bits, patch, e->d_counters);
+    hipLaunchKernelGGL((k_correct_wave<NB, NN>), dim3(blocks), dim3(256), 0, e->cur, R, e->K, e->filt[1].dev(), list,
+                       (const unsigned long long *)e->cur_cnt, tmask, tw, err_bits, patch, e->cur_cnt);
     HIP_TRY(hipGetLastError());
     return KBBQ_OK;
 }
 extern "C" {
 
-static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits, const uint32_t *patch, int max_len) {
+static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits, const uint32_t *patch, int max_len,
+                     hipStream_t stream = nullptr) {
+    if (!stream) stream = e->cur;
     HistDev H;
     H.cycle = e->d_hist;
     H.dinuc = e->d_hist + e->hist_cycle_words;
@@ -1884,56 +1927,79 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
         HIP_TRY(hipFuncSetAttribute((const void *)k_tally, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
-    Timed t(e, "k_tally");
+    Timed t(e, "k_tally", stream);
     // 16 wavefronts share one LDS table: two blocks (32 waves) per CU at 150-base reads
     const uint64_t groups = (R.n_bases + 15) / 16;
     const int blocks = (int)std::min<uint64_t>((groups + 1023) / 1024, 256);
     const int vec_ok = ((uintptr_t)R.qual & 15) == 0;
-    hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(1024), lds, e->stream, R, H, err_bits, patch, ccap, 6, vec_ok);
+    hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, vec_ok);
     HIP_TRY(hipGetLastError());
     return KBBQ_OK;
 }
 
 int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_out) {
-    if (!e) return fail(KBBQ_EINVAL, "null engine");
-    ReadsDev R; int max_len;
-    int rc = device_view(e, reads, &R, &max_len);
-    if (rc) return rc;
-    const int NW = max_len <= 192 ? 3 : max_len <= 320 ? 5 : 8;
-    // scratch: 3 = trusted masks, 4 = dirty flags, 5 = work list, 6 = error bits, 7 = seq patches
-    if ((rc = ensure_scratch(e, 3, R.n_reads * NW * 8))) return rc;
-    if ((rc = ensure_scratch(e, 4, R.n_reads))) return rc;
-    if ((rc = ensure_scratch(e, 5, R.n_reads * 4))) return rc;
-    if ((rc = ensure_scratch(e, 7, R.n_reads * 4))) return rc;
-    uint32_t *d_err;
+    if (!e || !reads) return fail(KBBQ_EINVAL, "null argument");
     const bool own_err = !(errors_out && reads->on_device);
+    // A device-resident batch stays put after this call returns, so it may still be in flight while the next one
+    // is submitted: such batches alternate between the two sides.  Host batches are staged in buffers the next
+    // call reuses, and a caller's error array is the caller's again on return: those run alone, in order.
+    static const bool no_overlap = getenv("KBBQ_NO_OVERLAP") != nullptr;
+    const bool overlap = reads->on_device && own_err && !no_overlap;
+    int side = 0, rc;
+    if (overlap) {
+        side = e->side_turn;
+        e->side_turn ^= 1;
+        if ((rc = collect_side(e, side))) return rc;       // waits for the batch that last used this side
+    } else {
+        if ((rc = sync_engine(e))) return rc;              // (before the batch is staged: this frees staging buffers)
+    }
+    ReadsDev R; int max_len;
+    if ((rc = device_view(e, reads, &R, &max_len))) return rc;
+    const int NW = max_len <= 192 ? 3 : max_len <= 320 ? 5 : 8;
+    // scratch per side: trusted masks, dirty flags, work list, error bits, seq patches
+    const int s_tmask = side ? 10 : 3, s_dirty = side ? 11 : 4, s_list = side ? 12 : 5, s_err = side ? 8 : 6, s_patch = side ? 9 : 7;
+    if ((rc = ensure_scratch(e, s_tmask, R.n_reads * NW * 8))) return rc;
+    if ((rc = ensure_scratch(e, s_dirty, R.n_reads))) return rc;
+    if ((rc = ensure_scratch(e, s_list, R.n_reads * 4))) return rc;
+    if ((rc = ensure_scratch(e, s_patch, R.n_reads * 4))) return rc;
+    uint32_t *d_err;
     if (own_err) {
-        if ((rc = ensure_scratch(e, 6, (R.n_bases / 64 + 2) * 8))) return rc;
-        d_err = (uint32_t *)e->scratch[6];
+        if ((rc = ensure_scratch(e, s_err, (R.n_bases / 64 + 2) * 8))) return rc;
+        d_err = (uint32_t *)e->scratch[s_err];
     } else {
         d_err = (uint32_t *)errors_out;
     }
-    HIP_TRY(hipMemsetAsync(d_err, 0, (R.n_bases / 64 + 1) * 8, e->stream));
-    HIP_TRY(hipMemsetAsync(e->scratch[7], 0, R.n_reads * 4, e->stream));
-    HIP_TRY(hipMemsetAsync(&e->d_counters[0], 0, 16, e->stream));
-    uint64_t *tmask = (uint64_t *)e->scratch[3];
-    uint8_t *dirty = (uint8_t *)e->scratch[4];
-    uint32_t *list = (uint32_t *)e->scratch[5];
-    uint32_t *patch = (uint32_t *)e->scratch[7];
+    e->cur = e->stream;
+    e->cur_cnt = e->d_counters + 4 * side;
+    struct Restore { kbbq_engine *e; ~Restore() { e->cur = e->stream; e->cur_cnt = e->d_counters; } } restore = {e};
+    HIP_TRY(hipMemsetAsync(d_err, 0, (R.n_bases / 64 + 1) * 8, e->cur));
+    HIP_TRY(hipMemsetAsync(e->scratch[s_patch], 0, R.n_reads * 4, e->cur));
+    HIP_TRY(hipMemsetAsync(e->cur_cnt, 0, 16, e->cur));
+    uint64_t *tmask = (uint64_t *)e->scratch[s_tmask];
+    uint8_t *dirty = (uint8_t *)e->scratch[s_dirty];
+    uint32_t *list = (uint32_t *)e->scratch[s_list];
+    uint32_t *patch = (uint32_t *)e->scratch[s_patch];
     if ((rc = dispatch_nw<LaunchScan>(max_len, e, R, tmask, dirty))) return rc;
     {
-        Timed t(e, "k_compact");
-        hipLaunchKernelGGL(k_compact, dim3((unsigned)((R.n_reads + 1023) / 1024)), dim3(1024), 0, e->stream, dirty, R.n_reads, list, &e->d_counters[0], 0);
+        Timed t(e, "k_compact", e->cur);
+        hipLaunchKernelGGL(k_compact, dim3((unsigned)((R.n_reads + 1023) / 1024)), dim3(1024), 0, e->cur, dirty, R.n_reads, list, e->cur_cnt, 0);
         HIP_TRY(hipGetLastError());
     }
     // isolated single errors are settled by the fast path; the walk gets what is left
     static const bool no_fast = getenv("KBBQ_NO_FASTPATH") != nullptr;
     if (!no_fast && e->p.k >= 3) {
         if ((rc = dispatch_nw<LaunchFixSingle>(max_len, e, R, (const uint32_t *)list, (const uint64_t *)tmask, d_err, dirty))) return rc;
-        HIP_TRY(hipMemsetAsync(&e->d_counters[0], 0, 8, e->stream));
-        Timed t(e, "k_compact");
-        hipLaunchKernelGGL(k_compact, dim3((unsigned)((R.n_reads + 1023) / 1024)), dim3(1024), 0, e->stream, dirty, R.n_reads, list, &e->d_counters[0], 1);
+        HIP_TRY(hipMemsetAsync(e->cur_cnt, 0, 8, e->cur));
+        Timed t(e, "k_compact", e->cur);
+        hipLaunchKernelGGL(k_compact, dim3((unsigned)((R.n_reads + 1023) / 1024)), dim3(1024), 0, e->cur, dirty, R.n_reads, list, e->cur_cnt, 1);
         HIP_TRY(hipGetLastError());
+    }
+    // The scan and the fast path of every batch run on the engine's stream; the walk and the tally of a
+    // device-resident batch move to the side stream, where they overlap the next batch's scan.
+    if (overlap) {
+        HIP_TRY(hipEventRecord(e->ev_main, e->stream));
+        HIP_TRY(hipStreamWaitEvent(e->stream2, e->ev_main, 0));
+        e->cur = e->stream2;
     }
     // one read per wavefront (correct_wave.h); the one-read-per-lane form (correct.h) serves k < 3
     // and KBBQ_CORRECT=lane (A/B checks)
@@ -1948,18 +2014,14 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
         else rc = launch_correct_wave<16, 8>(e, R, list, tmask, NW, d_err, patch);
     }
     if (rc) return rc;
-    if ((rc = run_tally(e, R, d_err, patch, max_len))) return rc;
-    {
-        unsigned long long c[2];
-        HIP_TRY(hipMemcpyAsync(c, e->d_counters, 16, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        e->stats[0] += c[0];
-        e->stats[1] += c[1];
-        e->stats[2] += R.n_reads;
-    }
-    if (errors_out && !reads->on_device) {
-        HIP_TRY(hipMemcpyAsync(errors_out, d_err, (R.n_bases / 64 + 1) * 8, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+    if ((rc = run_tally(e, R, d_err, patch, max_len, e->cur))) return rc;
+    HIP_TRY(hipEventRecord(e->ev_side[side], e->cur));
+    e->side_busy[side] = true;
+    e->side_reads[side] = R.n_reads;
+    if (!overlap) {
+        if ((rc = sync_engine(e))) return rc;
+        if (errors_out && !reads->on_device)
+            HIP_TRY(hipMemcpy(errors_out, d_err, (R.n_bases / 64 + 1) * 8, hipMemcpyDeviceToHost));
     }
     return KBBQ_OK;
 }
@@ -2179,6 +2241,8 @@ int kbbq_profile_reset(kbbq_engine *e) {
 
 int kbbq_stats_get(kbbq_engine *e, uint64_t *out, int32_t n) {
     if (!e || !out) return fail(KBBQ_EINVAL, "null argument");
+    int rc = sync_engine(e);      // batches of pass 3 may still be in flight; their counters are collected here
+    if (rc) return rc;
     for (int i = 0; i < n && i < 4; ++i) out[i] = e->stats[i];
     return KBBQ_OK;
 }

@@ -407,3 +407,41 @@ def test_properties_at_scale_on_device_generated_reads():
     assert torch.equal(tabs[0] | tabs[1], whole["tables"][0])
     dev.free()
     e.close()
+
+
+def test_overlapped_and_in_order_pass3_agree_on_device_batches():
+    """Device-resident batches run the walk and the tally of batch i on a side stream beside the scan of batch
+    i+1 (double-buffered scratch, deferred counters); KBBQ_NO_OVERLAP=1 keeps everything in order.  Same oracle
+    equality either way, with enough small batches to go round the two sides many times."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, 'tests'); import common, numpy as np, torch\n"
+            "from kbbq_amd.engine import Engine, plan_parameters\n"
+            "from kbbq_amd.reads import ReadBatch\n"
+            "d = common.make_dataset(seed=77, genome_len=30000, coverage=30, extra_errors=300, clusters=100)\n"
+            "ora = common.run_oracle(d)\n"
+            "alpha, cov, approx = plan_parameters(d['genome_len'], d['coverage'], None)\n"
+            "e = Engine(32, alpha, 777, approx, n_rg=1, max_read_len=150)\n"
+            "full = ReadBatch(d['seq'], d['qual'], d['off'], d['rg'], d['second'], uniform=True)\n"
+            "n = full.n_reads; cuts = [n * i // 11 // 64 * 64 for i in range(11)] + [n]\n"
+            "devs = [e.upload(full.slice(a, b)) for a, b in zip(cuts[:-1], cuts[1:])]\n"
+            "o = 0\n"
+            "for dv, (a, b) in zip(devs, zip(cuts[:-1], cuts[1:])):\n"
+            "    e.subsample_kmers(dv, a * 119)\n"
+            "e.sample_finish(); e.compute_thresholds()\n"
+            "for dv in devs: e.find_trusted_kmers(dv)\n"
+            "e.trusted_finish()\n"
+            "for rep in range(2):\n"
+            "    for dv in devs: e.get_covariatedata(dv)\n"
+            "cov = e.covariates()\n"
+            "assert np.array_equal(cov['cycle'][:, :, :, :ora['cov']['C']], 2 * ora['cov']['cycle'])\n"
+            "assert np.array_equal(cov['dinuc'], 2 * ora['cov']['dinuc'])\n"
+            "st = e.stats(); assert st['reads'] == 2 * n, st\n"
+            "print('pass3 ok', st['corrected_reads'], st['correction_queries'])\n")
+    outs = []
+    for extra in ({}, {"KBBQ_NO_OVERLAP": "1"}):
+        out = subprocess.run([sys.executable, "-c", code], cwd=common.ROOT, env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "pass3 ok" in out.stdout, out.stdout + out.stderr
+        outs.append(out.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1]
