@@ -47,6 +47,9 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+PASS3_KERNELS = ("k_scan_trusted", "k_compact", "k_fix_single", "k_correct_wave", "k_correct", "k_tally")
+
+
 def run_step(e, xch, batches, ordinals, out_buf, hints):
     """One complete pass of the hot path over this rank's shard."""
     e.reset()
@@ -278,8 +281,13 @@ def main():
             if model:
                 ent["alg_bytes_per_launch"] = model
                 ent["achieved_GBps"] = round(model / (ms / launches) / 1e6, 1)
+            # pass 3 runs on two streams (walk + tally of batch i beside scan + fast path of batch i+1): the event
+            # duration of such a kernel includes time it shared the chip, so it is not an exclusive cost
+            if name in PASS3_KERNELS and not os.environ.get("KBBQ_NO_OVERLAP"):
+                ent["overlapped"] = True
             kernels[name] = ent
-        dom = max((k for k in kernels if "achieved_GBps" in kernels[k]), key=lambda k: kernels[k]["total_ms"])
+        dom = max((k for k in kernels if "achieved_GBps" in kernels[k] and not kernels[k].get("overlapped")),
+                  key=lambda k: kernels[k]["total_ms"])
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
         # is the committed rocprofv3 --pmc summary of this same command at the same launch size
         traffic, traffic_note = None, "no PMC summary for this launch size"
@@ -299,7 +307,8 @@ def main():
                     algorithmic_bytes_per_launch=kernels[dom]["alg_bytes_per_launch"], avg_launch_ms=kernels[dom]["avg_ms"],
                     traffic_note=traffic_note,
                     note="one random 64-byte line per lookup: tools/probe_hbm measures about 3100 GB/s as this chip's ceiling for the "
-                         "Bloom access pattern; traffic below the algorithmic bytes = lookups answered by hint bits")
+                         "Bloom access pattern; traffic below the algorithmic bytes = lookups answered by hint bits; dominant = largest total "
+                         "among the kernels that run alone (pass-3 kernels overlap on two streams, flagged `overlapped`)")
         line = {
             "metric": "recalibrated Gbases/sec", "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
