@@ -1,17 +1,5 @@
-// engine.hip -- MI355X (gfx950) kernels and the C ABI of include/kbbq_engine.h.
-//
-// Pass structure (one kernel or kernel group per reference loop):
-//   pass 1  k_draw_mask        one xoshiro256** draw per k-mer position (htsiter.cc:113-129)
-//           k_insert_marked    sampled & valid k-mers -> sampled filter   (recalibrateutils.cc:7-13)
-//   pass 2  k_infer            infer_read_errors, which k-mers are trusted (recalibrateutils.cc:15-40)
-//           k_insert_marked    those k-mers -> trusted filter
-//   pass 3  k_scan_trusted     trusted mask of every k-mer; clean reads finish here
-//           k_compact          work list of reads that need the correction walk
-//           k_correct          get_errors, one read per lane             (readutils.cc:238-570)
-//           k_tally            covariate histograms                      (covariateutils.cc:30-164,193-202)
-//   pass 4  k_recalibrate      delta-Q apply                             (readutils.cc:572-595)
-// Integer / hash / bit work throughout: no MFMA.  The Bloom traffic (random
-// 64-byte blocks of a multi-GB array) is what bounds passes 1-3.
+// engine.hip -- the engine object and the C ABI of include/kbbq_engine.h: filters, scratch, streams, one
+// entry point per pass that launches the kernels of kernels.h (MI355X, gfx950).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -48,1060 +36,7 @@ static int fail(int code, const char *fmt, ...) {
                         hipGetErrorString(_e), __FILE__, __LINE__);                                    \
     } while (0)
 
-// ============================================================ kernels
-
-// ---- pass 1a: the sampler's draw stream ------------------------------------
-// The reference draws serially (one std::bernoulli_distribution call per k-mer
-// position, htsiter.cc:113-129).  xoshiro256 is linear over GF(2), so the state
-// after n draws is (x^n mod P)(M) applied to the seed state; each lane jumps to
-// its own chunk of DRAWS_PER_LANE consecutive draws and emits a bit mask.
-constexpr int DRAWS_PER_LANE = 4096;   // multiple of 64: each lane owns whole mask words
-
-__constant__ uint64_t c_jump[64][4];
-
-__device__ __forceinline__ uint64_t xo_next(uint64_t (&s)[4]) {
-    uint64_t x = s[1] * 5;
-    x = (x << 7) | (x >> 57);
-    x *= 9;
-    const uint64_t t = s[1] << 17;
-    s[2] ^= s[0];
-    s[3] ^= s[1];
-    s[1] ^= s[2];
-    s[0] ^= s[3];
-    s[2] ^= t;
-    s[3] = (s[3] << 45) | (s[3] >> 19);
-    return x;
-}
-
-__global__ void __launch_bounds__(256) k_draw_mask(uint64_t s0, uint64_t s1, uint64_t s2, uint64_t s3,
-                                                    uint64_t first_ordinal, uint64_t n_draws, uint64_t threshold,
-                                                    int always, uint64_t *mask) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t begin = t * DRAWS_PER_LANE;
-    if (begin >= n_draws) return;
-    uint64_t s[4] = {s0, s1, s2, s3};
-    const uint64_t ordinal = first_ordinal + begin;
-    for (int b = 0; b < 64; ++b) {
-        if (!((ordinal >> b) & 1)) continue;
-        uint64_t acc[4] = {0, 0, 0, 0};
-        for (int w = 0; w < 4; ++w) {
-            const uint64_t poly = c_jump[b][w];
-            for (int i = 0; i < 64; ++i) {
-                const uint64_t m = 0 - ((poly >> i) & 1);
-                acc[0] ^= s[0] & m; acc[1] ^= s[1] & m; acc[2] ^= s[2] & m; acc[3] ^= s[3] & m;
-                xo_next(s);
-            }
-        }
-        s[0] = acc[0]; s[1] = acc[1]; s[2] = acc[2]; s[3] = acc[3];
-    }
-    const uint64_t end = min(begin + (uint64_t)DRAWS_PER_LANE, n_draws);
-    uint64_t *out = mask + begin / 64;
-    for (uint64_t o = begin; o < end; o += 64) {
-        uint64_t bits = 0;
-        const int cnt = (int)min((uint64_t)64, end - o);
-        for (int i = 0; i < cnt; ++i) {
-            const uint64_t u = xo_next(s);
-            bits |= (uint64_t)((always || u < threshold) ? 1 : 0) << i;
-        }
-        *out++ = bits;
-    }
-}
-
-// exclusive prefix of max(0, len-k+1) over the reads of a ragged batch
-__global__ void k_kmer_counts(ReadsDev R, int k, uint64_t *counts) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R.n_reads) return;
-    uint64_t off; uint32_t len;
-    read_span(R, r, off, len);
-    counts[r] = len >= (uint32_t)k ? len - k + 1 : 0;
-}
-// single-block exclusive scan, in place, `n` up to a few tens of millions (test/ragged path)
-__global__ void __launch_bounds__(1024) k_exclusive_scan(uint64_t *data, uint64_t n, uint64_t *total) {
-    __shared__ uint64_t part[1024];
-    const int tid = threadIdx.x;
-    const uint64_t per = (n + 1023) / 1024;
-    const uint64_t b = min(n, per * tid), e = min(n, b + per);
-    uint64_t s = 0;
-    for (uint64_t i = b; i < e; ++i) s += data[i];
-    part[tid] = s;
-    __syncthreads();
-    if (tid == 0) {
-        uint64_t run = 0;
-        for (int i = 0; i < 1024; ++i) { const uint64_t v = part[i]; part[i] = run; run += v; }
-        *total = run;
-    }
-    __syncthreads();
-    uint64_t run = part[tid];
-    for (uint64_t i = b; i < e; ++i) { const uint64_t v = data[i]; data[i] = run; run += v; }
-}
-
-__device__ __forceinline__ uint64_t kmer_base(const uint64_t *kofs, uint64_t r, uint32_t read_len, int k) {
-    if (kofs) return kofs[r];
-    return r * (uint64_t)(read_len >= (uint32_t)k ? read_len - k + 1 : 0);
-}
-
-// ---- passes 1b and 2b: insert the marked k-mers of every read into a filter --------------
-// One wavefront per read, one lane per k-mer start, one 128-bit block per lane.  BY_BASE = false:
-// `mask` is the sampler's draw mask, one bit per k-mer position in file order (pass 1: insert where
-// drawn and valid, and record that in hint_sampled).  BY_BASE = true: `mask` has one bit per base of
-// the batch and already means "insert the k-mer starting here" (pass 2: the decisions of k_infer).
-template <int NW, bool BY_BASE>
-__global__ void __launch_bounds__(256) k_insert_marked(ReadsDev R, KParams K, FiltDev F, const uint64_t *mask,
-                                                        uint64_t mask_words, const uint64_t *kofs,
-                                                        unsigned long long *inserted) {
-    using S = Stage<NW>;
-    __shared__ uint32_t lds[4][2 * S::WORDS];
-    const int lane = threadIdx.x & 63;
-    uint32_t *L32 = lds[threadIdx.x >> 6];
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    const int k = K.k;
-    unsigned long long mine = 0;
-    uint64_t off = 0, kb = 0, word = 0;
-    uint32_t len = 0;
-    if (wave < R.n_reads) {
-        read_span(R, wave, off, len);
-        kb = BY_BASE ? off : kmer_base(kofs, wave, R.read_len, k);
-        word = stage_fetch<NW>(R, nullptr, mask, kb, mask_words - 1, off, lane);
-    }
-    for (uint64_t r = wave; r < R.n_reads; r += n_waves) {
-        __builtin_amdgcn_wave_barrier();
-        if (lane < S::WORDS) stage_store(L32, lane, word);
-        __builtin_amdgcn_wave_barrier();
-        const uint64_t cur = off;
-        const int o31 = (int)(off & 31), o63 = (int)(off & 63), x63 = (int)(kb & 63);
-        const int nk = (int)len - k + 1;
-        if (r + n_waves < R.n_reads) {   // the next read's words travel while this one is processed
-            read_span(R, r + n_waves, off, len);
-            kb = BY_BASE ? off : kmer_base(kofs, r + n_waves, R.read_len, k);
-            word = stage_fetch<NW>(R, nullptr, mask, kb, mask_words - 1, off, lane);
-        }
-        if (nk <= 0) continue;
-        // all block and pattern loads of the read are issued before the first is used
-        bool take[NW];
-        uint32_t blk[NW];
-        ulonglong2 t[NW], p[NW];
-#pragma unroll
-        for (int c = 0; c < NW; ++c) {
-            take[c] = false;
-            blk[c] = 0;
-            const int s = c * 64 + lane;
-            if (c * 64 < nk) {
-                if (s < nk && lds_bit(L32 + 2 * S::X, x63 + s)) {
-                    const bool valid = (lds_window32(L32 + 2 * S::M, o63 + s) & K.nmask_bits) == 0;
-                    take[c] = BY_BASE || valid;
-                }
-                if (take[c]) {
-                    const uint64_t key = canon_key(lds_window64(L32 + 2 * S::B, 2 * (o31 + s)), K);
-                    blk[c] = block_of(F, key);
-                    t[c] = F.table[blk[c]];
-                    p[c] = F.patterns[pattern_of(F, key)];
-                }
-                const unsigned long long bal = __ballot(take[c]);
-                if (!BY_BASE && R.hint_sampled) or_bits64(R.hint_sampled, cur + (uint64_t)c * 64, bal, lane);
-                mine += __popcll(bal);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < NW; ++c)
-            if (take[c]) {
-                const uint64_t mx = p[c].x & ~t[c].x, my = p[c].y & ~t[c].y;
-                unsigned long long *w = reinterpret_cast<unsigned long long *>(F.table + blk[c]);
-                if (mx) atomicOr(w, (unsigned long long)mx);
-                if (my) atomicOr(w + 1, (unsigned long long)my);
-            }
-    }
-    if (inserted && lane == 0 && mine) atomicAdd(inserted, mine);
-}
-
-// ---- pass 2 ------------------------------------------------------------------
-// overlapping_kmers_in_bf (bloom.cc:28-67) + infer_read_errors (readutils.cc:173-193)
-// + the trusted-insert loop of find_trusted_kmers (recalibrateutils.cc:26-38).
-// Wave per read.  present[] and err[] live as wave-uniform bit words produced
-// by __ballot; the sliding counters in[i]/possible[i] and the "k clean bases"
-// window become range pop-counts on those words.
-struct Thresholds { int v[KBBQ_MAX_KMER + 1]; };
-
-template <int NW>
-__global__ void __launch_bounds__(256) k_infer(ReadsDev R, KParams K, FiltDev S, Thresholds thr, uint32_t *take_bits,
-                                                unsigned long long *inserted, uint32_t *err_out) {
-    using St = Stage<NW>;
-    __shared__ uint32_t lds[4][St::LDS_U32];
-    __shared__ int thr_lds[KBBQ_MAX_KMER + 1];
-    const int lane = threadIdx.x & 63;
-    if (threadIdx.x <= KBBQ_MAX_KMER) thr_lds[threadIdx.x] = thr.v[threadIdx.x];
-    __syncthreads();
-    uint32_t *L32 = lds[threadIdx.x >> 6];
-    uint32_t *PW = L32 + 2 * St::WORDS;            // present bits: dword 0 = 0, dwords 1..2NW, then zeros
-    uint32_t *EW = PW + St::RES;                   // error bits, same shape
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    const uint64_t *hint = reinterpret_cast<const uint64_t *>(R.hint_sampled);
-    const int k = K.k;
-    unsigned long long mine = 0;
-    if (lane < St::RES) { PW[lane] = 0; EW[lane] = 0; }
-    uint64_t off = 0, word = 0;
-    uint32_t len = 0;
-    if (wave < R.n_reads) {
-        read_span(R, wave, off, len);
-        word = stage_fetch<NW>(R, hint, nullptr, 0, 0, off, lane);
-    }
-    for (uint64_t r = wave; r < R.n_reads; r += n_waves) {
-        __builtin_amdgcn_wave_barrier();
-        if (lane < St::WORDS) stage_store(L32, lane, word);
-        __builtin_amdgcn_wave_barrier();
-        const uint64_t cur = off;
-        const int o31 = (int)(off & 31), o63 = (int)(off & 63);
-        const int Lr = (int)len, nk = Lr - k + 1;
-        if (r + n_waves < R.n_reads) {   // the next read's words travel while this one is processed
-            read_span(R, r + n_waves, off, len);
-            word = stage_fetch<NW>(R, hint, nullptr, 0, 0, off, lane);
-        }
-        if (nk <= 0) continue;           // engine-defined: the reference underflows size_t here
-        // every lane's block and pattern loads (and its quality byte) go out before the first result is needed
-        bool valid[NW], known[NW];
-        ulonglong2 t[NW], p[NW];
-        uint8_t q[NW];
-#pragma unroll
-        for (int c = 0; c < NW; ++c) {
-            valid[c] = false;
-            known[c] = false;   // this read put the k-mer into the sampled filter itself (pass 1)
-            t[c] = make_ulonglong2(0, 0);
-            p[c] = make_ulonglong2(0, 0);
-            q[c] = 0;
-            const int s = c * 64 + lane;
-            if (c * 64 < Lr && s < Lr) q[c] = R.qual[cur + s];
-            if (c * 64 < nk && s < nk) {
-                const uint64_t key = canon_key(lds_window64(L32 + 2 * St::B, 2 * (o31 + s)), K);
-                valid[c] = (lds_window32(L32 + 2 * St::M, o63 + s) & K.nmask_bits) == 0;
-                known[c] = hint && lds_bit(L32 + 2 * St::H, o63 + s);
-                if (valid[c] && !known[c]) {
-                    t[c] = S.table[block_of(S, key)];
-                    p[c] = S.patterns[pattern_of(S, key)];
-                }
-            }
-        }
-        uint64_t V[NW];
-#pragma unroll
-        for (int c = 0; c < NW; ++c) {
-            V[c] = 0;
-            if (c * 64 < nk) {
-                const bool present = known[c] || (valid[c] && ((p[c].x & ~t[c].x) | (p[c].y & ~t[c].y)) == 0);
-                const uint64_t P = __ballot(present);
-                V[c] = __ballot(valid[c]);
-                if (lane < 2) PW[1 + 2 * c + lane] = (uint32_t)(P >> (32 * lane));
-            } else if (lane < 2) {
-                PW[1 + 2 * c + lane] = 0;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // in[i] = present k-mers among the starts max(0,i-k+1)..min(i,nk-1): the k bits of the present
-        // stream that end at bit i (bits before 0 and from nk on are zero)
-#pragma unroll
-        for (int c = 0; c < NW; ++c) {
-            if (c * 64 < Lr) {
-                const int i = c * 64 + lane;
-                bool err = false;
-                if (i < Lr) {
-                    const int possible = min(i, nk - 1) - max(0, i - k + 1) + 1;
-                    const int in = __popc(lds_window32(PW, i - k + 1 + 32) & K.nmask_bits);
-                    err = in <= thr_lds[possible] || q[c] <= 2;
-                }
-                const uint64_t E = __ballot(err);
-                if (lane < 2) EW[1 + 2 * c + lane] = (uint32_t)(E >> (32 * lane));
-                if (err_out) or_bits64(err_out, cur + (uint64_t)c * 64, E, lane);
-            } else if (lane < 2) {
-                EW[1 + 2 * c + lane] = 0;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // the k-mer ending at i goes into the trusted filter iff it is valid and its k bases are all
-        // unflagged (recalibrateutils.cc:26-38); the inserts themselves are k_insert_marked's
-#pragma unroll
-        for (int c = 0; c < NW; ++c) {
-            if (c * 64 < nk) {
-                const int s = c * 64 + lane;
-                const bool take = s < nk && ((V[c] >> lane) & 1) && (lds_window32(EW, s + 32) & K.nmask_bits) == 0;
-                const unsigned long long bal = __ballot(take);
-                or_bits64(take_bits, cur + (uint64_t)c * 64, bal, lane);
-                mine += __popcll(bal);
-            }
-        }
-    }
-    if (lane == 0 && mine) atomicAdd(inserted, mine);
-}
-
-// ---- pass 3a: trusted mask of every k-mer ------------------------------------
-// Wave per read.  A read whose k-mers are all trusted has no errors
-// (readutils.cc:263-265) and needs nothing more than the tally; the others get
-// their mask stored and a flag for the correction kernel.
-template <int NW>
-__global__ void __launch_bounds__(256) k_scan_trusted(ReadsDev R, KParams K, FiltDev T, uint64_t *tmask,
-                                                       uint8_t *dirty) {
-    using S = Stage<NW>;
-    __shared__ uint32_t lds[4][2 * S::WORDS];
-    const int lane = threadIdx.x & 63;
-    uint32_t *L32 = lds[threadIdx.x >> 6];
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    const uint64_t *hint = reinterpret_cast<const uint64_t *>(R.hint_trusted);
-    const int k = K.k;
-    uint64_t off = 0, word = 0;
-    uint32_t len = 0;
-    if (wave < R.n_reads) {
-        read_span(R, wave, off, len);
-        word = stage_fetch<NW>(R, hint, nullptr, 0, 0, off, lane);
-    }
-    for (uint64_t r = wave; r < R.n_reads; r += n_waves) {
-        __builtin_amdgcn_wave_barrier();
-        if (lane < S::WORDS) stage_store(L32, lane, word);
-        __builtin_amdgcn_wave_barrier();
-        const int o31 = (int)(off & 31), o63 = (int)(off & 63);
-        const int nk = (int)len - k + 1;
-        if (r + n_waves < R.n_reads) {   // the next read's words travel while this one is processed
-            read_span(R, r + n_waves, off, len);
-            word = stage_fetch<NW>(R, hint, nullptr, 0, 0, off, lane);
-        }
-        if (nk <= 0) { if (lane == 0) dirty[r] = 0; continue; }
-        uint64_t M[NW];
-        int trusted = 0;
-        bool valid[NW], known[NW];
-        ulonglong2 t[NW], p[NW];
-#pragma unroll
-        for (int c = 0; c < NW; ++c) {
-            M[c] = 0;
-            valid[c] = false;
-            known[c] = false;   // this read put the k-mer into the trusted filter itself (pass 2)
-            t[c] = make_ulonglong2(0, 0);
-            p[c] = make_ulonglong2(0, 0);
-            const int s = c * 64 + lane;
-            if (c * 64 < nk && s < nk) {
-                const uint64_t key = canon_key(lds_window64(L32 + 2 * S::B, 2 * (o31 + s)), K);
-                valid[c] = (lds_window32(L32 + 2 * S::M, o63 + s) & K.nmask_bits) == 0;
-                known[c] = hint && lds_bit(L32 + 2 * S::H, o63 + s);
-                if (valid[c] && !known[c]) {
-                    t[c] = T.table[block_of(T, key)];
-                    p[c] = T.patterns[pattern_of(T, key)];
-                }
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < NW; ++c) {
-            if (c * 64 < nk) {
-                const bool ok = known[c] || (valid[c] && ((p[c].x & ~t[c].x) | (p[c].y & ~t[c].y)) == 0);
-                M[c] = __ballot(ok);
-                trusted += __popcll(M[c]);
-            }
-        }
-        const bool is_dirty = trusted != nk;
-        if (lane == 0) dirty[r] = is_dirty ? 1 : 0;
-        if (is_dirty && lane < NW) tmask[r * NW + lane] = sel_word<NW>(M, lane);
-    }
-}
-
-__global__ void __launch_bounds__(1024) k_compact(const uint8_t *dirty, uint64_t n, uint32_t *list,
-                                                   unsigned long long *count, int only_one) {
-    // one global atomic per 1024-lane block: wave counts -> LDS scan -> block base
-    __shared__ unsigned int wave_cnt[16];
-    __shared__ unsigned long long block_base;
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool d = i < n && (only_one ? dirty[i] == 1 : dirty[i] != 0);
-    const unsigned long long bal = __ballot(d);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) wave_cnt[w] = (unsigned int)__popcll(bal);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int tot = 0;
-        for (int k = 0; k < 16; ++k) { const unsigned int c = wave_cnt[k]; wave_cnt[k] = tot; tot += c; }
-        block_base = tot ? atomicAdd(count, (unsigned long long)tot) : 0ULL;
-    }
-    __syncthreads();
-    if (d) list[block_base + wave_cnt[w] + __popcll(bal & ((1ULL << lane) - 1))] = (uint32_t)i;
-}
-
-// ---- pass 3a': the isolated-error fast path ------------------------------------------
-// Most reads that need work carry a few ISOLATED errors: their trusted mask has up to four separate
-// runs of untrusted k-mers, each run being exactly the k-mers that cover one base p.  For such a
-// read get_errors (readutils.cc:238-570) reduces to: the anchor is the longest trusted run; walking
-// away from it, find_longest_fix meets the errors one at a time; if exactly one alternative base at
-// p makes every k-mer covering p trusted, that alternative alone has the longest walk, it is
-// applied, and the walk continues through the trusted k-mers to the next run (or the read end).  At
-// most four flags are set, so the over-correction window cannot fire and nothing is left for the
-// recursion: errors = {p1..pm}.  This kernel decides that with two small cooperative lookups per
-// read and marks the read done (dirty = 2); if any run has no or several full alternatives, or the
-// mask has any other shape, the read stays untouched for k_correct_wave.
-template <int NW>
-__global__ void __launch_bounds__(256) k_fix_single(ReadsDev R, KParams K, FiltDev T, const uint32_t *list,
-                                                     const unsigned long long *n_list, const uint64_t *tmask,
-                                                     uint32_t *err_bits, uint8_t *dirty, unsigned long long *stats) {
-    using S = Stage<NW>;
-    constexpr int MAXRUN = 4;
-    __shared__ uint32_t lds[4][2 * S::WORDS];
-    const int lane = threadIdx.x & 63;
-    uint32_t *L32 = lds[threadIdx.x >> 6];
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    const uint64_t n = *n_list;
-    const int k = K.k;
-    unsigned long long q_total = 0;
-    // Three reads are in flight per wave: A is being decided, B's words are travelling, C's list entry
-    // and span are travelling -- the dependent chain list -> offsets -> words never sits in front of
-    // the two lookup rounds.
-    uint64_t rA = 0, offA = 0, wordA = 0, rB = 0, offB = 0, rC = 0, slotC = wave + 2 * n_waves;
-    uint64_t tmA[NW], tmB[NW];                        // trusted masks: wave-uniform, scalar loads
-#pragma unroll
-    for (int c = 0; c < NW; ++c) { tmA[c] = 0; tmB[c] = 0; }
-    uint32_t lenA = 0, lenB = 0;
-    bool hasA = wave < n, hasB = wave + n_waves < n, hasC = slotC < n;
-    if (hasA) {
-        rA = list[wave];
-        read_span(R, rA, offA, lenA);
-        wordA = stage_fetch<NW>(R, nullptr, nullptr, 0, 0, offA, lane);
-#pragma unroll
-        for (int c = 0; c < NW; ++c) tmA[c] = tmask[rA * NW + c];
-    }
-    if (hasB) {
-        rB = list[wave + n_waves];
-        read_span(R, rB, offB, lenB);
-#pragma unroll
-        for (int c = 0; c < NW; ++c) tmB[c] = tmask[rB * NW + c];
-    }
-    if (hasC) rC = list[slotC];
-    while (hasA) {
-        __builtin_amdgcn_wave_barrier();
-        if (lane < S::WORDS) stage_store(L32, lane, wordA);
-        __builtin_amdgcn_wave_barrier();
-        const uint64_t r = rA, off = offA;
-        const int len = (int)lenA, nk = len - k + 1;
-        const int o31 = (int)(off & 31), o63 = (int)(off & 63);
-        // runs of untrusted k-mer starts: z = complement of the trusted mask inside [0, nk)
-        uint64_t Z[NW];
-        int zeros = 0;
-#pragma unroll
-        for (int c = 0; c < NW; ++c) {
-            Z[c] = 0;
-            if (c * 64 < nk) {
-                const int rem = nk - c * 64;
-                Z[c] = ~tmA[c] & (rem >= 64 ? ~0ULL : ((1ULL << rem) - 1));
-                zeros += __popcll(Z[c]);
-            }
-        }
-        if (hasB) wordA = stage_fetch<NW>(R, nullptr, nullptr, 0, 0, offB, lane);
-        auto next_bit = [&](int from, bool one) -> int {      // first index >= from with Z bit == one, nk if none
-            while (from < nk) {
-                uint64_t x = sel_word<NW>(Z, from >> 6);
-                if (!one) x = ~x;
-                x >>= (from & 63);
-                if (x) { const int q = from + __ffsll((unsigned long long)x) - 1; return q < nk ? q : nk; }
-                from = ((from >> 6) + 1) << 6;
-            }
-            return nk;
-        };
-        int m = 0, z0s[MAXRUN], z1s[MAXRUN], ps[MAXRUN];
-        bool eligible = zeros > 0 && zeros < nk;
-        for (int pos = next_bit(0, true); eligible && pos < nk;) {
-            const int z0 = pos, z1 = next_bit(pos, false) - 1;
-            if (m == MAXRUN || z1 - z0 + 1 > k) { eligible = false; break; }
-            const int p = z0 > 0 ? z0 + k - 1 : z1;
-            // the run must be exactly the in-range starts that cover p
-            if (!(z0 == max(0, p - k + 1) && z1 == min(p, nk - 1))) { eligible = false; break; }
-#pragma unroll
-            for (int q = 0; q < MAXRUN; ++q) if (q == m) { z0s[q] = z0; z1s[q] = z1; ps[q] = p; }
-            ++m;
-            pos = next_bit(z1 + 1, true);
-        }
-        int singles = 0;   // runs with exactly one full alternative
-        uint64_t offC = 0;
-        uint32_t lenC = 0;
-        bool spanC_done = false;
-        if (eligible) {
-            auto pick = [&](const int (&a)[MAXRUN], int idx) -> int {
-                int v = a[0];
-#pragma unroll
-                for (int q = 1; q < MAXRUN; ++q) v = (idx == q) ? a[q] : v;
-                return v;
-            };
-            // k-mer starting at st with base p := y
-            auto key_of = [&](int st, int p, int y, bool &valid) -> uint64_t {
-                uint64_t w = lds_window64(L32 + 2 * S::B, 2 * (o31 + st));
-                uint32_t nm = lds_window32(L32 + 2 * S::M, o63 + st) & K.nmask_bits;
-                const int j = p - st;
-                w = (w & ~(3ULL << (2 * j))) | ((uint64_t)y << (2 * j));
-                nm &= ~(1u << j);
-                valid = nm == 0;
-                return canon_key(w, K);
-            };
-            // round 1: one covering k-mer per (run, alternative): lane 4*run + y
-            int alive;
-            {
-                const int run = lane >> 2, y = lane & 3;
-                bool act = lane < 4 * m;
-                int p = 0, st = 0;
-                if (act) {
-                    p = pick(ps, run);
-                    st = pick(z0s, run);
-                    const int cur = lds_bit(L32 + 2 * S::M, o63 + p) ? 4 : (int)((L32[2 * S::B + ((o31 + p) >> 4)] >> (((o31 + p) & 15) * 2)) & 3);
-                    act = y != cur;
-                }
-                bool valid = false;
-                const uint64_t key = key_of(st, p, y, valid);
-                const bool go = act && valid;
-                q_total += __popcll(__ballot(go));
-                const bool t = go && bloom_has(T, key);
-                if (hasC) { read_span(R, rC, offC, lenC); spanC_done = true; }
-                alive = (int)(__ballot(t) & 0xFFFF);
-            }
-            // round 2: every covering k-mer of the survivors, two (run, alternative) pairs per lookup
-            int full = 0;   // 3 bits per run: number of alternatives whose covering k-mers are all trusted
-            while (alive) {
-                const int a = __ffs(alive) - 1;
-                alive &= alive - 1;
-                int b = -1;
-                if (alive) { b = __ffs(alive) - 1; alive &= alive - 1; }
-                const int mine = (lane >> 5) ? b : a;
-                const int run = mine >= 0 ? mine >> 2 : 0, y = mine >= 0 ? (mine & 3) : 0;
-                const int z0 = pick(z0s, run), z1 = pick(z1s, run), p = pick(ps, run);
-                const int st = z0 + (lane & 31);
-                const bool act = mine >= 0 && st <= z1;
-                bool valid = false;
-                const uint64_t key = key_of(act ? st : z0, p, y, valid);
-                const bool go = act && valid;
-                q_total += __popcll(__ballot(go));
-                const bool t = go && bloom_has(T, key);
-                const unsigned long long bal = __ballot(t);
-                const int ra = a >> 2;
-                if (__popcll(bal & 0xFFFFFFFFULL) == pick(z1s, ra) - pick(z0s, ra) + 1) full += 1 << (3 * ra);
-                if (b >= 0) {
-                    const int rb = b >> 2;
-                    if (__popcll(bal >> 32) == pick(z1s, rb) - pick(z0s, rb) + 1) full += 1 << (3 * rb);
-                }
-            }
-            for (int q = 0; q < m; ++q) singles += ((full >> (3 * q)) & 7) == 1 ? 1 : 0;
-        }
-        if (eligible && singles == m && lane < m) {
-            const uint64_t g = off + (lane == 0 ? ps[0] : lane == 1 ? ps[1] : lane == 2 ? ps[2] : ps[3]);
-            atomicOr(&err_bits[g >> 5], 1u << (g & 31));
-            if (lane == 0) dirty[r] = 2;
-        }
-        // rotate the pipeline
-        if (hasC && !spanC_done) read_span(R, rC, offC, lenC);
-        hasA = hasB; rA = rB; offA = offB; lenA = lenB;
-        hasB = hasC; rB = rC; offB = offC; lenB = lenC;
-#pragma unroll
-        for (int c = 0; c < NW; ++c) { tmA[c] = tmB[c]; tmB[c] = hasC ? tmask[rC * NW + c] : 0; }
-        slotC += n_waves;
-        hasC = slotC < n;
-        if (hasC) rC = list[slotC];
-    }
-    if (lane == 0 && q_total) atomicAdd(&stats[1], q_total);
-}
-
-// ---- pass 3b: the correction walk, one read per lane ---------------------------
-template <int MAXL, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_correct(ReadsDev R, KParams K, FiltDev T, const uint32_t *list,
-                                                    const unsigned long long *n_list, const uint64_t *tmask,
-                                                    int tmask_words, uint32_t *err_bits, uint32_t *patch,
-                                                    unsigned long long *stats) {
-    typedef Corrector<MAXL> C;
-    extern __shared__ uint32_t lds[];
-    const uint64_t n = *n_list;
-    unsigned long long q_total = 0;
-    for (uint64_t slot = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; slot < n; slot += (uint64_t)gridDim.x * BLOCK) {
-        const uint64_t r = list[slot];
-        uint64_t off; uint32_t len32;
-        read_span(R, r, off, len32);
-        const int len = (int)len32;
-        C cx;
-        cx.L = lds + threadIdx.x;
-        cx.stride = BLOCK;
-        cx.f = T;
-        cx.K = K;
-        cx.qual = R.qual + off;
-        cx.t_ok = true;
-        cx.queries = 0;
-        // stage the read: 2-bit bases, non-ACGT mask, trusted mask; clear flags
-        for (int w = 0; w < C::NWB; ++w)
-            cx.word(C::OFF_W, w) = w * 16 < len ? (uint32_t)window64(R.bases, 2 * (off + (uint64_t)w * 16)) : 0u;
-        for (int w = 0; w < C::NWN; ++w) {
-            cx.word(C::OFF_NM, w) = w * 32 < len ? (uint32_t)window64(R.nmask, off + (uint64_t)w * 32) : 0u;
-            cx.word(C::OFF_E, w) = 0;
-            const int tw = w >> 1;
-            cx.word(C::OFF_T, w) = tw < tmask_words ? (uint32_t)(tmask[r * tmask_words + tw] >> (32 * (w & 1))) : 0u;
-        }
-        // bits past the read end must not look like bases
-        if (len & 31) cx.word(C::OFF_NM, len >> 5) &= (1u << (len & 31)) - 1;
-        if (len & 15) cx.word(C::OFF_W, len >> 4) &= (1u << ((len & 15) * 2)) - 1;
-
-        const int k = K.k;
-        const CallResult top = cx.run_call(0, len, true, 6);
-        if (top.patch_pos >= 0) patch[r] = 0x80000000u | ((uint32_t)top.patch_pos << 8) | (uint32_t)top.patch_base;
-        // readutils.cc:547-563
-        if (top.bad_prefix > 0 && (top.bad_prefix >= len / 2 || top.bad_prefix >= 2 * k))
-            cx.run_call(0, top.bad_prefix + 1, false, 6);
-        if (top.bad_suffix >= 0 && top.bad_suffix < len &&
-            (len - top.bad_suffix > len / 2 || len - top.bad_suffix > 2 * k))
-            cx.run_call(top.bad_suffix, len - top.bad_suffix, false, 6);
-        // publish the flags into the batch-wide bit array
-        for (int w = 0; w * 32 < len; ++w) {
-            const uint32_t v = cx.word(C::OFF_E, w);
-            if (!v) continue;
-            const uint64_t g = off + (uint64_t)w * 32;
-            atomicOr(&err_bits[g >> 5], v << (g & 31));
-            if (g & 31) atomicOr(&err_bits[(g >> 5) + 1], v >> (32 - (g & 31)));
-        }
-        q_total += cx.queries;
-    }
-    // per-wave reduction of the query counter
-    for (int o = 32; o > 0; o >>= 1) q_total += __shfl_down(q_total, o);
-    if ((threadIdx.x & 63) == 0 && q_total) atomicAdd(&stats[1], q_total);
-}
-
-
-// ---- pass 3b (default): the correction walk, one read per WAVEFRONT (correct_wave.h) ----
-template <int NB, int NN>
-__global__ void __launch_bounds__(256, 5) k_correct_wave(ReadsDev R, KParams K, FiltDev T, const uint32_t *list,
-                                                       const unsigned long long *n_list, const uint64_t *tmask,
-                                                       int tmask_words, uint32_t *err_bits, uint32_t *patch,
-                                                       unsigned long long *stats) {
-    typedef WaveCorrector<NB, NN> C;
-    __shared__ uint64_t lds_words[4 * C::WORDS];
-    const int lane = threadIdx.x & 63;
-    // wave-uniform by construction: lets the compiler keep the read's words and the walk in SGPRs
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    const uint64_t n = *n_list;
-    unsigned long long q_total = 0;
-    for (uint64_t slot = wave; slot < n; slot += n_waves) {
-        const uint64_t r = C::uni((uint64_t)list[slot]);
-        uint64_t off; uint32_t len32;
-        read_span(R, r, off, len32);
-        off = C::uni(off);
-        const int len = C::uni((int)len32);
-        C cx;
-        cx.S = lds_words + (threadIdx.x >> 6) * C::WORDS;
-        cx.f = T;
-        cx.K = K;
-        cx.qual = R.qual + off;
-        cx.lane = lane;
-        cx.queries = 0;
-        // stage the read into the wavefront's LDS slice (lane w writes word w)
-        for (int slot_w = lane; slot_w < C::WORDS; slot_w += 64) {
-            uint64_t v = 0;
-            if (slot_w < NB) {
-                const int w = slot_w;
-                if (w * 32 < len) v = window64(R.bases, 2 * (off + (uint64_t)w * 32));
-                const int rem = len - w * 32;
-                if (rem < 32) v &= rem > 0 ? ((1ULL << (2 * rem)) - 1) : 0ULL;
-            } else if (slot_w >= C::NM && slot_w < C::NM + NN) {
-                const int c = slot_w - C::NM;
-                if (c * 64 < len) v = window64(R.nmask, off + (uint64_t)c * 64);
-                const int rem = len - c * 64;
-                if (rem < 64) v &= rem > 0 ? ((1ULL << rem) - 1) : 0ULL;
-            } else if (slot_w >= C::Tc && slot_w < C::Tc + NN) {
-                const int c = slot_w - C::Tc;
-                if (c < tmask_words) v = tmask[r * tmask_words + c];
-            }
-            cx.S[slot_w] = v;
-        }
-        const int k = K.k;
-        // activation 0 is the read; 1 and 2 are the one-level recursion on a long unfixed prefix /
-        // suffix (readutils.cc:547-563).  One call site keeps a single inlined copy of the walk.
-        int pre_n = 0, suf_lo = 0, suf_n = 0;
-#pragma unroll 1
-        for (int act = 0; act < 3; ++act) {
-            int lo = 0, nn = len;
-            if (act == 1) { if (!pre_n) continue; nn = pre_n; }
-            if (act == 2) { if (!suf_n) continue; lo = suf_lo; nn = suf_n; }
-            const typename C::CallOut out = cx.run_call(lo, nn, 6);
-            if (act == 0) {
-                if (out.patch_pos >= 0 && lane == 0)
-                    patch[r] = 0x80000000u | ((uint32_t)out.patch_pos << 8) | (uint32_t)out.patch_base;
-                if (out.bad_prefix > 0 && (out.bad_prefix >= len / 2 || out.bad_prefix >= 2 * k)) pre_n = out.bad_prefix + 1;
-                if (out.bad_suffix >= 0 && out.bad_suffix < len &&
-                    (len - out.bad_suffix > len / 2 || len - out.bad_suffix > 2 * k)) {
-                    suf_lo = out.bad_suffix;
-                    suf_n = len - out.bad_suffix;
-                }
-            }
-        }
-        // publish the flags: lane l owns the 32-bit piece l of the read's flag words
-        if (lane < 2 * NN && lane * 32 < len) {
-            const uint32_t v = (uint32_t)(cx.ldw(C::E, lane >> 1) >> (32 * (lane & 1)));
-            if (v) {
-                const uint64_t g = off + (uint64_t)lane * 32;
-                atomicOr(&err_bits[g >> 5], v << (g & 31));
-                if (g & 31) atomicOr(&err_bits[(g >> 5) + 1], v >> (32 - (g & 31)));
-            }
-        }
-        q_total += cx.queries;
-    }
-    if (lane == 0 && q_total) atomicAdd(&stats[1], q_total);
-}
-
-// ---- pass 3c: covariate tally ---------------------------------------------------
-// CCovariateData::consume_read (covariateutils.cc:193-202).  Only the cycle and
-// dinucleotide tables are tallied: qcov[rg][q] and rgcov[rg] are exact sums of
-// the cycle table (every base is counted in all three, :30-42, :65-76, :102-116)
-// and are formed once at the end.  Totals go through an LDS-private table
-// (16-bit counters, packed two per word, flushed before they can wrap) for the
-// read group of the block's first read; error counts and anything outside the
-// LDS table go straight to 64-bit global atomics (rare).
-struct HistDev {
-    unsigned long long *cycle;   // [n_rg][94][2][n_cycle][2]
-    unsigned long long *dinuc;   // [n_rg][94][16][2]
-    int n_rg, n_cycle;
-};
-
-__device__ __forceinline__ uint64_t cyc_index(const HistDev &H, int rg, int q, int s, int c) {
-    return ((((uint64_t)rg * KBBQ_NQ + q) * 2 + s) * H.n_cycle + c) * 2;
-}
-
-// One lane per 16 consecutive bases of the batch (16-byte quality load, 4-byte base load), a block of
-// 1024 lanes per 16 Ki bases; the block's LDS table is flushed before any 16-bit counter could wrap
-// (a read adds at most 1 to a counter, so the block counts the reads it has touched).
-__global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uint32_t *err_bits, const uint32_t *patch,
-                                                 int ccap, int minscore, int vec_ok) {
-    extern __shared__ uint32_t lds[];
-    // layout: cycle totals [2][94][ccap] u16 (packed, cycle slots permuted), dinuc totals [94][16] u32,
-    // dinuc errors [94][16] u32 (few, hot addresses: global atomics on them serialise at the memory side),
-    // reads-touched counter
-    const int cyc_words = (2 * ccap * KBBQ_NQ + 1) / 2;
-    uint32_t *l_cyc = lds;
-    uint32_t *l_cye = lds + cyc_words;          // cycle error counts, same layout as the totals
-    uint32_t *l_di = l_cye + cyc_words;
-    uint32_t *l_die = l_di + KBBQ_NQ * 16;
-    uint32_t *l_reads = l_die + KBBQ_NQ * 16;
-    const int lds_words = 2 * cyc_words + 2 * KBBQ_NQ * 16 + 1;
-    for (int i = threadIdx.x; i < lds_words; i += blockDim.x) lds[i] = 0;
-    __syncthreads();
-    const int lds_rg = R.rg ? (int)R.rg[0] : 0;
-    const uint64_t n_groups = (R.n_bases + 15) / 16;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t iters = (n_groups + stride - 1) / stride;
-    for (uint64_t it = 0; it < iters; ++it) {
-        const uint64_t grp = it * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        const uint64_t g0 = grp * 16;
-        int starts = 0;
-        if (g0 < R.n_bases) {
-            uint64_t r, start, end;
-            if (R.offsets) {
-                uint64_t lo = 0, hi = R.n_reads;   // last r with offsets[r] <= g0
-                while (hi - lo > 1) {
-                    const uint64_t mid = (lo + hi) >> 1;
-                    if (R.offsets[mid] <= g0) lo = mid; else hi = mid;
-                }
-                r = lo;
-                start = R.offsets[r];
-                end = R.offsets[r + 1];
-                while (end <= g0) { ++r; start = end; end = R.offsets[r + 1]; }
-            } else {
-                r = g0 / R.read_len;
-                start = r * R.read_len;
-                end = start + R.read_len;
-            }
-            const int n = (int)min((uint64_t)16, R.n_bases - g0);
-            uint8_t qv[16];
-            if (n == 16 && vec_ok) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(R.qual + g0);
-                memcpy(qv, &v, 16);
-            } else {
-                for (int i = 0; i < 16; ++i) qv[i] = i < n ? R.qual[g0 + i] : 0;
-            }
-            const uint32_t bw = (uint32_t)(R.bases[g0 >> 5] >> ((g0 & 31) * 2));
-            const uint32_t nw = (uint32_t)(R.nmask[g0 >> 6] >> (g0 & 63)) & 0xFFFFu;
-            const uint32_t ew = (err_bits[g0 >> 5] >> (g0 & 31)) & 0xFFFFu;
-            int prev_b = 0, prev_n = 1;
-            if (g0 > 0) {
-                const uint64_t gp = g0 - 1;
-                prev_b = (int)((R.bases[gp >> 5] >> ((gp & 31) * 2)) & 3);
-                prev_n = (int)((R.nmask[gp >> 6] >> (gp & 63)) & 1);
-            }
-            int rg = R.rg ? (int)R.rg[r] : 0;
-            int second = R.flags ? (R.flags[r] & 1) : 0;
-            uint32_t pt = patch ? patch[r] : 0u;
-            starts = g0 == start ? 1 : 0;
-            // the read this group starts in may carry a patch on the base just before the group
-            if ((pt >> 31) && g0 > start && (int)((pt >> 8) & 0xFFFF) == (int)(g0 - 1 - start)) { prev_b = (int)(pt & 3); prev_n = 0; }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const uint64_t g = g0 + i;
-                if (i < n) {
-                    while (g >= end) {
-                        ++r; start = end;
-                        end = R.offsets ? R.offsets[r + 1] : end + R.read_len;
-                        rg = R.rg ? (int)R.rg[r] : 0;
-                        second = R.flags ? (R.flags[r] & 1) : 0;
-                        pt = patch ? patch[r] : 0u;
-                        if (end > start) ++starts;
-                    }
-                    const int cyc = (int)(g - start);
-                    int b = (int)((bw >> (2 * i)) & 3), nn = (int)((nw >> i) & 1);
-                    if ((pt >> 31) && (int)((pt >> 8) & 0xFFFF) == cyc) { b = (int)(pt & 3); nn = 0; }
-                    const int q = qv[i];
-                    const int er = (int)((ew >> i) & 1);
-                    if (rg < H.n_rg && cyc < H.n_cycle && q < KBBQ_NQ) {
-                        if (rg == lds_rg && cyc < ccap) {
-                            // lanes of one instruction are 16 cycles apart: store cycle c at slot
-                            // (c%16)*(ccap/16) + c/16 so that they land in neighbouring words, not in two banks
-                            const int slot = (cyc & 15) * (ccap >> 4) + (cyc >> 4);
-                            const int idx = (second * KBBQ_NQ + q) * ccap + slot;
-                            atomicAdd(&l_cyc[idx >> 1], 1u << (16 * (idx & 1)));
-                            if (er) atomicAdd(&l_cye[idx >> 1], 1u << (16 * (idx & 1)));
-                        } else {
-                            atomicAdd(&H.cycle[cyc_index(H, rg, q, second, cyc) + 1], 1ULL);
-                            if (er) atomicAdd(&H.cycle[cyc_index(H, rg, q, second, cyc)], 1ULL);
-                        }
-                        if (cyc >= 1 && q >= minscore && !nn && !prev_n) {
-                            const int d = (prev_b << 2) | b;
-                            if (rg == lds_rg) {
-                                atomicAdd(&l_di[q * 16 + d], 1u);
-                                if (er) atomicAdd(&l_die[q * 16 + d], 1u);
-                            } else {
-                                atomicAdd(&H.dinuc[(((uint64_t)rg * KBBQ_NQ + q) * 16 + d) * 2 + 1], 1ULL);
-                                if (er) atomicAdd(&H.dinuc[(((uint64_t)rg * KBBQ_NQ + q) * 16 + d) * 2], 1ULL);
-                            }
-                        }
-                    }
-                    prev_b = b;
-                    prev_n = nn;
-                }
-            }
-            // a read that began before this group and continues into it also counts once for this block
-            starts += g0 != start ? 1 : 0;
-        }
-        {
-            // reads touched by this wavefront (a lane touches at most 17): bit-sliced ballot sum, one LDS add per wave
-            const int s = g0 < R.n_bases ? starts : 0;
-            unsigned int tot = 0;
-#pragma unroll
-            for (int b = 0; b < 5; ++b) tot += (unsigned int)__popcll(__ballot((s >> b) & 1)) << b;
-            if ((threadIdx.x & 63) == 0 && tot) atomicAdd(l_reads, tot);
-        }
-        __syncthreads();
-        if (*l_reads >= 40000u || it + 1 == iters) {
-            __syncthreads();
-            for (int w = threadIdx.x; w < cyc_words; w += blockDim.x) {
-                const uint32_t v = l_cyc[w], ve = l_cye[w];
-                if (!v) continue;      // no total, no error
-                l_cyc[w] = 0;
-                l_cye[w] = 0;
-                for (int h = 0; h < 2; ++h) {
-                    const uint32_t cnt = (v >> (16 * h)) & 0xFFFFu, cne = (ve >> (16 * h)) & 0xFFFFu;
-                    if (!cnt) continue;
-                    const int idx = 2 * w + h;
-                    const int slot = idx % ccap, rest = idx / ccap;
-                    const int q = rest % KBBQ_NQ, s = rest / KBBQ_NQ;
-                    const int c = (slot % (ccap >> 4)) * 16 + slot / (ccap >> 4);
-                    if (c < H.n_cycle) {
-                        atomicAdd(&H.cycle[cyc_index(H, lds_rg, q, s, c) + 1], (unsigned long long)cnt);
-                        if (cne) atomicAdd(&H.cycle[cyc_index(H, lds_rg, q, s, c)], (unsigned long long)cne);
-                    }
-                }
-            }
-            for (int w = threadIdx.x; w < KBBQ_NQ * 16; w += blockDim.x) {
-                const uint32_t v = l_di[w], ve = l_die[w];
-                if (v) { l_di[w] = 0; atomicAdd(&H.dinuc[((uint64_t)lds_rg * KBBQ_NQ * 16 + w) * 2 + 1], (unsigned long long)v); }
-                if (ve) { l_die[w] = 0; atomicAdd(&H.dinuc[((uint64_t)lds_rg * KBBQ_NQ * 16 + w) * 2], (unsigned long long)ve); }
-            }
-            if (threadIdx.x == 0) *l_reads = 0;
-            __syncthreads();
-        }
-    }
-}
-
-// ---- pass 4: delta-Q apply -------------------------------------------------------
-// CReadData::recalibrate (readutils.cc:572-595).  One lane per 16 consecutive
-// bases of the batch: 16-byte quality load and store, 4-byte base load.
-struct DqDev {
-    const int16_t *base;   // [n_rg][94]  meanq + rgdq + qscoredq
-    const int8_t *cycle;   // [n_rg][94][2][n_cycle]
-    const int8_t *dinuc;   // [n_rg][94][16]
-    int n_rg, n_cycle;
-};
-
-__global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8_t *out, int minqual, int vec_ok, int lds_rgs) {
-    // the delta-Q tables of the first `lds_rgs` read groups sit in LDS: per read group one int16 per
-    // (q, second, cycle) holding meanq + rg + q delta-Q + cycle delta-Q already summed, and the int8
-    // dinucleotide delta-Q -- two dependent LDS reads per base instead of three global ones
-    extern __shared__ uint8_t l_tab[];
-    const int cyc_cells = KBBQ_NQ * 2 * D.n_cycle, di_bytes = KBBQ_NQ * 16;
-    const int cyc_bytes = 2 * cyc_cells;
-    const int per_rg = (cyc_bytes + di_bytes + 3) & ~3;
-    for (int i = threadIdx.x; i < lds_rgs * (cyc_cells + di_bytes); i += blockDim.x) {
-        const int rg = i / (cyc_cells + di_bytes), o = i % (cyc_cells + di_bytes);
-        if (o < cyc_cells) {
-            const int q = o / (2 * D.n_cycle);
-            reinterpret_cast<int16_t *>(l_tab + (size_t)rg * per_rg)[o] =
-                (int16_t)(D.base[rg * KBBQ_NQ + q] + D.cycle[(size_t)rg * cyc_cells + o]);
-        } else {
-            l_tab[(size_t)rg * per_rg + cyc_bytes + (o - cyc_cells)] = (uint8_t)D.dinuc[(size_t)rg * di_bytes + (o - cyc_cells)];
-        }
-    }
-    __syncthreads();
-    // persistent blocks: the table load above is paid once per block, not once per 4 KB of qualities
-    for (uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; g0 < R.n_bases;
-         g0 += (uint64_t)gridDim.x * blockDim.x * 16) {
-    // read containing g0
-    uint64_t r, start, end;
-    if (R.offsets) {
-        uint64_t lo = 0, hi = R.n_reads;   // last r with offsets[r] <= g0
-        while (hi - lo > 1) {
-            const uint64_t mid = (lo + hi) >> 1;
-            if (R.offsets[mid] <= g0) lo = mid; else hi = mid;
-        }
-        r = lo;
-        start = R.offsets[r];
-        end = R.offsets[r + 1];
-        while (end <= g0) { ++r; start = end; end = R.offsets[r + 1]; }   // skip empty reads
-    } else {
-        r = g0 / R.read_len;
-        start = r * R.read_len;
-        end = start + R.read_len;
-    }
-    const int n = (int)min((uint64_t)16, R.n_bases - g0);
-    uint8_t qv[16];
-    if (n == 16 && vec_ok) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(R.qual + g0);
-        memcpy(qv, &v, 16);
-    } else {
-        for (int i = 0; i < 16; ++i) qv[i] = i < n ? R.qual[g0 + i] : 0;
-    }
-    const uint32_t bw = (uint32_t)(R.bases[g0 >> 5] >> ((g0 & 31) * 2));
-    const uint32_t nw = (uint32_t)(R.nmask[g0 >> 6] >> (g0 & 63)) & 0xFFFFu;
-    int prev_b = 0, prev_n = 1;
-    if (g0 > 0) {
-        const uint64_t gp = g0 - 1;
-        prev_b = (int)((R.bases[gp >> 5] >> ((gp & 31) * 2)) & 3);
-        prev_n = (int)((R.nmask[gp >> 6] >> (gp & 63)) & 1);
-    }
-    int rg = R.rg ? (int)R.rg[r] : 0;
-    int second = R.flags ? (R.flags[r] & 1) : 0;
-    uint8_t res[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const uint64_t g = g0 + i;
-        if (i < n) {
-            while (g >= end) {
-                ++r; start = end;
-                end = R.offsets ? R.offsets[r + 1] : end + R.read_len;
-                rg = R.rg ? (int)R.rg[r] : 0;
-                second = R.flags ? (R.flags[r] & 1) : 0;
-            }
-        }
-        const int cyc = (int)(g - start);
-        const int b = (int)((bw >> (2 * i)) & 3), nn = (int)((nw >> i) & 1);
-        const int q = qv[i];
-        int v = q;
-        if (i < n && q >= minqual && q < KBBQ_NQ && rg < D.n_rg && cyc < D.n_cycle) {
-            const int cell = rg * KBBQ_NQ + q;
-            const bool use_di = cyc > 0 && !nn && !prev_n;
-            if (rg < lds_rgs) {
-                const uint8_t *t = l_tab + rg * per_rg;
-                v = reinterpret_cast<const int16_t *>(t)[(q * 2 + second) * D.n_cycle + cyc];
-                if (use_di) v += (int8_t)t[cyc_bytes + q * 16 + ((prev_b << 2) | b)];
-            } else {
-                v = D.base[cell] + D.cycle[((uint64_t)cell * 2 + second) * D.n_cycle + cyc];
-                if (use_di) v += D.dinuc[cell * 16 + ((prev_b << 2) | b)];
-            }
-        }
-        res[i] = (uint8_t)(v < 0 ? 0 : (v > KBBQ_MAXQ ? KBBQ_MAXQ : v));
-        prev_b = b;
-        prev_n = nn;
-    }
-    if (n == 16 && vec_ok) {
-        uint4 v;
-        memcpy(&v, res, 16);
-        *reinterpret_cast<uint4 *>(out + g0) = v;
-    } else {
-        for (int i = 0; i < n; ++i) out[g0 + i] = res[i];
-    }
-    }
-}
-
-// ---- helpers ----------------------------------------------------------------------
-__global__ void k_or_words(uint64_t *dst, const uint64_t *src, uint64_t n) {
-    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
-    if (i + 1 < n) {
-        ulonglong2 a = *reinterpret_cast<ulonglong2 *>(dst + i);
-        const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(src + i);
-        a.x |= b.x; a.y |= b.y;
-        *reinterpret_cast<ulonglong2 *>(dst + i) = a;
-    } else if (i < n) {
-        dst[i] |= src[i];
-    }
-}
-
-// dst |= OR of n_pieces consecutive pieces of `src` (each piece_words long), skipping piece `skip`:
-// the reduce step of the OR all-reduce in one launch
-__global__ void k_or_pieces(uint64_t *dst, const uint64_t *src, uint64_t piece_words, int n_pieces, int skip) {
-    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
-    if (i >= piece_words) return;
-    if (i + 1 < piece_words) {
-        ulonglong2 a = *reinterpret_cast<ulonglong2 *>(dst + i);
-        for (int p = 0; p < n_pieces; ++p) {
-            if (p == skip) continue;
-            const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(src + (uint64_t)p * piece_words + i);
-            a.x |= b.x; a.y |= b.y;
-        }
-        *reinterpret_cast<ulonglong2 *>(dst + i) = a;
-    } else {
-        uint64_t a = dst[i];
-        for (int p = 0; p < n_pieces; ++p)
-            if (p != skip) a |= src[(uint64_t)p * piece_words + i];
-        dst[i] = a;
-    }
-}
-
-// synthetic data set (kbbq_amd/synth.py is the host twin, bit for bit)
-struct SynthDev {
-    uint64_t seed, genome_len, first_read, n_reads;
-    uint32_t read_len, n_rg, paired, n_thr;   // n_thr: N threshold on 20 bits
-    const uint32_t *qcum;     // [read_len][4] cumulative 32-bit thresholds for Q2,Q12,Q22,Q32 (else Q37)
-    const uint32_t *errthr;   // [94] 32-bit error thresholds
-};
-__device__ __host__ __forceinline__ uint64_t synth_hash(uint64_t seed, uint64_t stream, uint64_t idx) {
-    return mix64(mix64(seed + stream * 0x9e3779b97f4a7c15ULL) + idx * 0xD1342543DE82EF95ULL);
-}
-__device__ __forceinline__ int synth_genome(uint64_t seed, uint64_t pos) { return (int)(synth_hash(seed, 0, pos) >> 62); }
-
-__global__ void __launch_bounds__(256) k_synth(SynthDev S, uint64_t *bases, uint64_t *nmask, uint8_t *qual,
-                                                uint8_t *flags, uint16_t *rg) {
-    // one lane per 32 consecutive bases of the batch (one 2-bit word)
-    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t total = S.n_reads * S.read_len;
-    const uint64_t g0 = w * 32;
-    if (g0 >= total) return;
-    uint64_t bword = 0;
-    uint32_t nbits = 0;
-    for (int i = 0; i < 32; ++i) {
-        const uint64_t g = g0 + i;
-        if (g >= total) break;
-        const uint64_t lr = g / S.read_len;
-        const uint32_t c = (uint32_t)(g - lr * S.read_len);
-        const uint64_t r = S.first_read + lr;
-        const uint64_t h1 = synth_hash(S.seed, 1, r);
-        const uint64_t start = (h1 >> 1) % (S.genome_len - S.read_len + 1);
-        const int strand = (int)(h1 & 1);
-        int b = strand ? 3 - synth_genome(S.seed, start + S.read_len - 1 - c) : synth_genome(S.seed, start + c);
-        const uint64_t hb = synth_hash(S.seed, 3, r * S.read_len + c);
-        const uint32_t uq = (uint32_t)hb, ue = (uint32_t)(hb >> 32);
-        const uint32_t *qc = S.qcum + 4 * c;
-        int q = uq < qc[0] ? 2 : uq < qc[1] ? 12 : uq < qc[2] ? 22 : uq < qc[3] ? 32 : 37;
-        if (ue < S.errthr[q]) b = (b + 1 + (int)(synth_hash(S.seed, 4, r * S.read_len + c) % 3)) & 3;
-        const bool isn = (synth_hash(S.seed, 5, r * S.read_len + c) & 0xFFFFF) < S.n_thr;
-        if (isn) { b = 0; q = 2; nbits |= 1u << i; }
-        bword |= (uint64_t)b << (2 * i);
-        qual[g] = (uint8_t)q;
-        if (c == 0) {
-            flags[lr] = S.paired ? (uint8_t)(r & 1) : 0;
-            rg[lr] = (uint16_t)((synth_hash(S.seed, 6, r) >> 32) % S.n_rg);
-        }
-    }
-    bases[w] = bword;
-    // two lanes share one mask word
-    uint32_t *nm32 = reinterpret_cast<uint32_t *>(nmask);
-    nm32[w] = nbits;
-}
+#include "kernels.h"
 
 // ============================================================ engine object
 
