@@ -39,7 +39,7 @@ K = 32
 READ_LEN = 150
 SEED_DATA = 12345
 SEED_SAMPLER = 777
-BATCH_READS = 1 << 22          # reads per engine call (multiple of 32)
+BATCH_READS = int(os.environ.get("KBBQ_BENCH_BATCH", 1 << 22))   # reads per engine call
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -295,7 +295,7 @@ def main():
             pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_latest.json")))
             k = pmc["kernels"].get(dom)
             launches_per_step = kernels[dom]["launches"] // args.steps
-            full_launches = (n_local // BATCH_READS) >= 1 and READ_LEN == 150
+            full_launches = (n_local // BATCH_READS) >= 1 and READ_LEN == 150 and BATCH_READS == 1 << 22
             if k and full_launches:
                 traffic = round((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0)
                 traffic_note = ("FETCH_SIZE + WRITE_SIZE per launch of %d reads, %s (%d launches per step here, the last one partial)"
