@@ -154,6 +154,73 @@ private:
     bool stop_ = false, eof_ = false, failed_ = false;
 };
 
+// A plain gzip stream cannot be inflated in parallel, but it can be inflated AHEAD: one thread runs zlib and
+// fills a short queue of 4 MiB pieces while the caller parses the previous ones.
+class AheadSource : public ByteSource {
+public:
+    explicit AheadSource(std::unique_ptr<ByteSource> inner) : inner_(std::move(inner)), th_(&AheadSource::run, this) {}
+    ~AheadSource() override {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_space_.notify_all();
+        th_.join();
+    }
+    int read(void *dst, unsigned n) override {
+        unsigned char *out = (unsigned char *)dst;
+        unsigned done = 0;
+        while (done < n) {
+            if (pos_ < cur_.size()) {
+                const size_t take = std::min<size_t>(n - done, cur_.size() - pos_);
+                memcpy(out + done, cur_.data() + pos_, take);
+                pos_ += take;
+                done += (unsigned)take;
+                continue;
+            }
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_data_.wait(lk, [&] { return !ready_.empty() || finished_; });
+            if (ready_.empty()) return error_ && !done ? -1 : (int)done;
+            cur_.swap(ready_.front());
+            ready_.pop_front();
+            pos_ = 0;
+            lk.unlock();
+            cv_space_.notify_one();
+        }
+        return (int)done;
+    }
+
+private:
+    void run() {
+        for (;;) {
+            std::vector<unsigned char> piece(4 << 20);
+            const int got = inner_->read(piece.data(), (unsigned)piece.size());
+            std::unique_lock<std::mutex> lk(mu_);
+            if (got <= 0) {
+                error_ = got < 0;
+                finished_ = true;
+                lk.unlock();
+                cv_data_.notify_all();
+                return;
+            }
+            piece.resize((size_t)got);
+            cv_space_.wait(lk, [&] { return stop_ || ready_.size() < 4; });
+            if (stop_) return;
+            ready_.push_back(std::move(piece));
+            lk.unlock();
+            cv_data_.notify_one();
+        }
+    }
+    std::unique_ptr<ByteSource> inner_;
+    std::deque<std::vector<unsigned char>> ready_;
+    std::vector<unsigned char> cur_;
+    size_t pos_ = 0;
+    std::mutex mu_;
+    std::condition_variable cv_data_, cv_space_;
+    bool stop_ = false, finished_ = false, error_ = false;
+    std::thread th_;      // last member: starts when everything above exists
+};
+
 }  // namespace
 
 std::unique_ptr<ByteSource> open_bytes(const std::string &path, int threads) {
@@ -170,7 +237,9 @@ std::unique_ptr<ByteSource> open_bytes(const std::string &path, int threads) {
     }
     gzFile g = path == "-" ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");
     if (!g) return nullptr;
-    return std::unique_ptr<ByteSource>(new GzSource(g));
+    std::unique_ptr<ByteSource> src(new GzSource(g));
+    if (threads > 1) return std::unique_ptr<ByteSource>(new AheadSource(std::move(src)));
+    return src;
 }
 
 // ------------------------------------------------------------------ reader ----

@@ -36,8 +36,9 @@ def ref_name_rules(fullname):
     return rg, second, first
 
 
-def parse(path):
-    out = subprocess.run([CLI, "--io-test", "parse", str(path)], capture_output=True, text=True, check=True).stdout
+def parse(path, threads=1):
+    out = subprocess.run([CLI, "--io-test", "parse", str(path)], capture_output=True, text=True, check=True,
+                         env=dict(os.environ, KBBQ_IO_THREADS=str(threads))).stdout
     lines = out.rstrip("\n").split("\n")
     assert lines[-1].startswith("#end")
     return [ln.split("\t") for ln in lines[:-1]], int(lines[-1].split()[1])
@@ -58,8 +59,8 @@ def test_reader_plain_gzip_multiline_and_comments(tmp_path):
     g = tmp_path / "a.fq.gz"
     with gzip.open(g, "wt") as fh:
         fh.write(text)
-    for path in (p, g):
-        recs, rc = parse(path)
+    for path, threads in ((p, 1), (g, 1), (p, 3), (g, 3)):      # 3: inflate-ahead thread in front of the parser
+        recs, rc = parse(path, threads)
         assert rc == -1
         assert [(r[0], r[1], r[6], r[7]) for r in recs] == [
             ("r1", "first comment", "ACGTNNAC", "IIII!!#I"), ("r2/2", "comment after a tab", "AC", "I+"),
