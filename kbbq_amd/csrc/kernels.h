@@ -952,6 +952,43 @@ __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8
     int rg = R.rg ? (int)R.rg[r] : 0;
     int second = R.flags ? (R.flags[r] & 1) : 0;
     uint8_t res[16];
+    // A group of 16 bases lies in one read or straddles one boundary (reads of 16 bases or more): handled
+    // without a branch per base -- the read a base belongs to is a select on its index.  Everything else (a
+    // second boundary inside the group, a read group whose tables are not in LDS, the batch's last group)
+    // takes the general loop below.
+    const int bpos = end - g0 < 16 ? (int)(end - g0) : 16;      // first base of the next read inside the group
+    int rg2 = rg, second2 = second;
+    uint64_t end2 = end;
+    if (bpos < 16 && r + 1 < R.n_reads) {
+        rg2 = R.rg ? (int)R.rg[r + 1] : 0;
+        second2 = R.flags ? (R.flags[r + 1] & 1) : 0;
+        end2 = R.offsets ? R.offsets[r + 2] : end + R.read_len;
+    }
+    const int c0 = (int)(g0 - start);
+    const bool plain = n == 16 && rg < lds_rgs && rg2 < lds_rgs && (bpos == 16 || (r + 1 < R.n_reads && end2 >= g0 + 16)) &&
+                       c0 + bpos <= D.n_cycle && 16 - bpos <= D.n_cycle;
+    if (plain) {
+        const int16_t *ta = reinterpret_cast<const int16_t *>(l_tab + rg * per_rg) + second * D.n_cycle + c0;
+        const int16_t *tb = reinterpret_cast<const int16_t *>(l_tab + rg2 * per_rg) + second2 * D.n_cycle - bpos;
+        const int8_t *da = reinterpret_cast<const int8_t *>(l_tab + rg * per_rg + cyc_bytes);
+        const int8_t *db = reinterpret_cast<const int8_t *>(l_tab + rg2 * per_rg + cyc_bytes);
+        const int qstride = 2 * D.n_cycle;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool in2 = i >= bpos;
+            const int b = (int)((bw >> (2 * i)) & 3), nn = (int)((nw >> i) & 1);
+            const int q = qv[i];
+            int v = q;
+            if (q >= minqual && q < KBBQ_NQ) {
+                v = (in2 ? tb : ta)[q * qstride + i];
+                const bool first = in2 ? i == bpos : c0 + i == 0;        // cycle 0 has no dinucleotide context
+                if (!first && !(nn | prev_n)) v += (in2 ? db : da)[q * 16 + ((prev_b << 2) | b)];
+            }
+            res[i] = (uint8_t)(v < 0 ? 0 : (v > KBBQ_MAXQ ? KBBQ_MAXQ : v));
+            prev_b = b;
+            prev_n = nn;
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const uint64_t g = g0 + i;
@@ -982,6 +1019,7 @@ __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8
         res[i] = (uint8_t)(v < 0 ? 0 : (v > KBBQ_MAXQ ? KBBQ_MAXQ : v));
         prev_b = b;
         prev_n = nn;
+    }
     }
     if (n == 16 && vec_ok) {
         uint4 v;
