@@ -795,6 +795,52 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
             int second = R.flags ? (R.flags[r] & 1) : 0;
             uint32_t pt = patch ? patch[r] : 0u;
             starts = g0 == start ? 1 : 0;
+            // Same shape as the apply kernel: a group lies in one read or straddles one boundary, and which read a
+            // base belongs to is a select on its index (also for the read's patch, if it has one).  Anything else
+            // -- a second boundary, a read group other than the one whose tables are in LDS -- takes the general loop.
+            const int bpos = end - g0 < 16 ? (int)(end - g0) : 16;
+            int rg2 = rg, second2 = second;
+            uint32_t pt2 = 0;
+            uint64_t end2 = end;
+            if (bpos < 16 && r + 1 < R.n_reads) {
+                rg2 = R.rg ? (int)R.rg[r + 1] : 0;
+                second2 = R.flags ? (R.flags[r + 1] & 1) : 0;
+                pt2 = patch ? patch[r + 1] : 0u;
+                end2 = R.offsets ? R.offsets[r + 2] : end + R.read_len;
+            }
+            const int c0 = (int)(g0 - start);
+            const bool plain = n == 16 && rg == lds_rg && rg2 == lds_rg && rg < H.n_rg &&
+                               (bpos == 16 || (r + 1 < R.n_reads && end2 >= g0 + 16)) &&
+                               c0 + bpos <= ccap && c0 + bpos <= H.n_cycle && 16 - bpos <= ccap && 16 - bpos <= H.n_cycle;
+            if (plain) {
+                const int pp1 = (pt >> 31) ? (int)((pt >> 8) & 0xFFFF) : -2, pp2 = (pt2 >> 31) ? (int)((pt2 >> 8) & 0xFFFF) : -2;
+                if (pp1 >= 0 && pp1 == c0 - 1) { prev_b = (int)(pt & 3); prev_n = 0; }
+                const int qa = second * KBBQ_NQ * ccap, qb = second2 * KBBQ_NQ * ccap;
+                starts += bpos < 16 ? 1 : 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const bool in2 = i >= bpos;
+                    const int cyc = in2 ? i - bpos : c0 + i;
+                    int b = (int)((bw >> (2 * i)) & 3), nn = (int)((nw >> i) & 1);
+                    if (cyc == (in2 ? pp2 : pp1)) { b = (int)((in2 ? pt2 : pt) & 3); nn = 0; }
+                    const int q = qv[i];
+                    const uint32_t er = (ew >> i) & 1u;
+                    if (q < KBBQ_NQ) {
+                        const int slot = (cyc & 15) * (ccap >> 4) + (cyc >> 4);
+                        const int idx = (in2 ? qb : qa) + q * ccap + slot;
+                        const uint32_t one = 1u << (16 * (idx & 1));
+                        atomicAdd(&l_cyc[idx >> 1], one);
+                        if (er) atomicAdd(&l_cye[idx >> 1], one);
+                        if (cyc >= 1 && q >= minscore && !(nn | prev_n)) {
+                            const int d = q * 16 + ((prev_b << 2) | b);
+                            atomicAdd(&l_di[d], 1u);
+                            if (er) atomicAdd(&l_die[d], 1u);
+                        }
+                    }
+                    prev_b = b;
+                    prev_n = nn;
+                }
+            } else {
             // the read this group starts in may carry a patch on the base just before the group
             if ((pt >> 31) && g0 > start && (int)((pt >> 8) & 0xFFFF) == (int)(g0 - 1 - start)) { prev_b = (int)(pt & 3); prev_n = 0; }
 #pragma unroll
@@ -840,6 +886,7 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
                     prev_b = b;
                     prev_n = nn;
                 }
+            }
             }
             // a read that began before this group and continues into it also counts once for this block
             starts += g0 != start ? 1 : 0;
