@@ -276,6 +276,8 @@ int kbbq_stats_get(kbbq_engine *e, uint64_t *out, int32_t n);
 /* Filter sizing, salts and pattern table (bloom_filter.hpp:108-160,467-549; bloom.hh:36-56,189-231). */
 int kbbq_host_filter_spec(uint64_t approx_kmers, double fpr, uint64_t bloom_seed, kbbq_filter_info *info,
                           uint64_t *patterns_out /* 65536*8 words or NULL */);
+/* hash % n_blocks exactly as the kernels compute it (get_block, bloom.hh:99-105; kbbq_amd/csrc/modmath.h). */
+uint32_t kbbq_host_block_index(uint32_t hash, uint64_t n_blocks);
 /* Between the reference's 512-bit blocks (8 words) and the engine's 128-bit ones (2 words), see
  * kbbq_filter_device_table.  Squeezing fails with KBBQ_ERANGE on a bit no pattern can set. */
 int kbbq_host_blocks_squeeze(const uint64_t *reference_words, uint64_t n_blocks, uint64_t *engine_words);

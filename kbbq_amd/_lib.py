@@ -109,6 +109,7 @@ SYMBOLS = {
     "kbbq_profile_reset": (ctypes.c_int, [c_vp]),
     "kbbq_stats_get": (ctypes.c_int, [c_vp, c_u64p, ctypes.c_int32]),
     "kbbq_host_filter_spec": (ctypes.c_int, [c_u64, ctypes.c_double, c_u64, ctypes.POINTER(FilterInfo), c_u64p]),
+    "kbbq_host_block_index": (ctypes.c_uint32, [ctypes.c_uint32, c_u64]),
     "kbbq_host_blocks_squeeze": (ctypes.c_int, [c_u64p, c_u64, c_u64p]),
     "kbbq_host_blocks_expand": (ctypes.c_int, [c_u64p, c_u64, c_u64p]),
     "kbbq_host_thresholds": (ctypes.c_int, [ctypes.c_int32, c_u64, c_u64, ctypes.c_uint32, ctypes.c_char_p, c_i32p,

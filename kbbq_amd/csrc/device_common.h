@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "modmath.h"
+
 namespace kbbq {
 
 constexpr int WAVE = 64;
@@ -93,16 +95,14 @@ struct FiltDev {
     ulonglong2 *table;           // n_blocks x 16 bytes
     const ulonglong2 *patterns;  // 65536 x 16 bytes
     uint64_t n_blocks;
-    uint64_t mod_magic;          // 2^64 / n_blocks + 1 (fastmod), 0 when n_blocks >= 2^32
+    uint64_t mod_magic;          // modmath.h: ModMagic.m64
+    uint32_t mod_m32;            //            ModMagic.m32
     uint32_t salt0, salt1;
 };
 
-// get_block (bloom.hh:99-105): hash % num_blocks, exact via Lemire's fastmod
+// get_block (bloom.hh:99-105): hash % num_blocks, exact (modmath.h)
 __device__ __forceinline__ uint32_t block_of(const FiltDev &f, uint64_t key) {
-    const uint32_t h = hash_ap8(key, f.salt0);
-    if (f.n_blocks > 0xFFFFFFFFULL) return h;
-    const uint64_t low = f.mod_magic * h;
-    return (uint32_t)__umul64hi(low, f.n_blocks);
+    return mod_hash(hash_ap8(key, f.salt0), f.n_blocks, f.mod_magic, f.mod_m32);
 }
 // get_pattern (bloom.hh:250-253)
 __device__ __forceinline__ uint32_t pattern_of(const FiltDev &f, uint64_t key) {

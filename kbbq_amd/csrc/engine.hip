@@ -51,7 +51,9 @@ struct FilterHost {
         f.table = reinterpret_cast<ulonglong2 *>(d_table);
         f.patterns = reinterpret_cast<const ulonglong2 *>(d_patterns);
         f.n_blocks = spec.n_blocks;
-        f.mod_magic = spec.n_blocks > 0xFFFFFFFFULL ? 0 : (~0ULL / spec.n_blocks + 1);
+        const ModMagic mm = make_mod_magic(spec.n_blocks);
+        f.mod_magic = mm.m64;
+        f.mod_m32 = mm.m32;
         f.salt0 = spec.salt[0];
         f.salt1 = spec.salt[1];
         return f;
@@ -1196,6 +1198,12 @@ int kbbq_host_filter_spec(uint64_t approx_kmers, double fpr, uint64_t bloom_seed
     for (uint32_t i = 0; i < s.n_salt; ++i) info->salt[i] = s.salt[i];
     if (patterns_out) memcpy(patterns_out, s.patterns.data(), kNumPatterns * 64);
     return KBBQ_OK;
+}
+
+uint32_t kbbq_host_block_index(uint32_t hash, uint64_t n_blocks) {
+    if (!n_blocks) return 0;
+    const ModMagic mm = make_mod_magic(n_blocks);
+    return mod_hash(hash, mm.d, mm.m64, mm.m32);
 }
 
 int kbbq_host_blocks_squeeze(const uint64_t *reference_words, uint64_t n_blocks, uint64_t *engine_words) {

@@ -286,3 +286,19 @@ def test_engine_block_layout_holds_everything_the_reference_can_set():
         back = np.zeros_like(t)
         L.kbbq_host_blocks_expand(small.ctypes.data_as(_lib.c_u64p), len(t) // 8, back.ctypes.data_as(_lib.c_u64p))
         assert np.array_equal(back, t) and t.any()
+
+
+def test_block_index_is_the_exact_remainder():
+    """hash % n_blocks (get_block, bloom.hh:99-105) through the two-multiply Barrett form the kernels use for
+    n_blocks <= 2^31 and the 64-bit fastmod above that: every divisor class, hashes at the edges."""
+    L = _lib.lib()
+    rng = np.random.RandomState(7)
+    divisors = [1, 2, 3, 4, 5, 7, 255, 256, 257, 13116, 21630, 131154, 216294, 393216000, 649000000, 2 ** 31 - 1, 2 ** 31, 2 ** 31 + 1,
+                3 * 2 ** 30 + 12345, 2 ** 32 - 1, 2 ** 32, 2 ** 32 + 1, 2 ** 40]
+    divisors += [int(x) for x in rng.randint(1, 2 ** 31, size=200, dtype=np.int64)] + [int(x) for x in rng.randint(2 ** 31, 2 ** 33, size=50, dtype=np.int64)]
+    for d in divisors:
+        hs = [0, 1, d - 1 if d <= 2 ** 32 else 5, d % 2 ** 32, (d + 1) % 2 ** 32, (2 * d - 1) % 2 ** 32, 2 ** 32 - 1, 2 ** 32 - 2, 2 ** 31, 2 ** 31 - 1]
+        hs += [int(x) for x in rng.randint(0, 2 ** 32, size=300, dtype=np.int64)]
+        hs += [(2 ** 32 // d) * d % 2 ** 32, ((2 ** 32 // d) * d - 1) % 2 ** 32] if d <= 2 ** 32 else []
+        for h in hs:
+            assert L.kbbq_host_block_index(h, d) == h % d, (h, d)
