@@ -12,9 +12,9 @@
 //     lives in wave-uniform 64-bit words; control flow is wave-uniform;
 //   * "which alternative base at position m makes its k covering k-mers
 //     trusted" -- the question behind adjust_right_anchor, find_longest_fix and
-//     correct_one -- is answered by a PROBE: one lane per (candidate, k-mer), all
-//     Bloom blocks fetched together with the 8-lanes-per-block cooperative load,
-//     the answer returned as one bit mask per candidate;
+//     correct_one -- is answered by a PROBE: one lane per (candidate, k-mer), every
+//     lane fetching its own 128-bit Bloom block, the answer returned as one bit mask
+//     per candidate;
 //   * k-mers that do not cover the modified base are never re-queried: their
 //     status is a bit of the trusted mask the scan kernel already produced
 //     (recomputed in parallel only after correct_one changed a base);
@@ -52,7 +52,7 @@ struct WaveCorrector {
     // Everything below that steers control flow is wave-uniform by construction (it derives from
     // ballots and from data every lane loaded identically).  The compiler cannot always prove that,
     // so such values go through readfirstlane: they then live in SGPRs, branches on them are scalar
-    // branches, and no lane ever sits out an `ask` (whose shuffles need all 64 lanes).
+    // branches, and the ballots that collect the answers of an `ask` see every lane.
     template <typename T>
     static __device__ __forceinline__ T uni(T v) {
         if constexpr (sizeof(T) == 8) {

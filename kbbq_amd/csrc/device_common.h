@@ -1,6 +1,6 @@
 // device_common.h -- device-side building blocks shared by the kernels in
-// engine.hip: packed-read access, k-mer extraction, hash_ap, the blocked Bloom
-// filter (8-lane cooperative form and single-lane form).  gfx950 only:
+// kernels.h: packed-read access, k-mer extraction, hash_ap, the blocked Bloom
+// filter (128-bit blocks, one lane per lookup), per-wave LDS staging of reads.  gfx950 only:
 // wavefront = 64 lanes everywhere.
 #pragma once
 #include <hip/hip_runtime.h>

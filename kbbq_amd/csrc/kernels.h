@@ -402,7 +402,7 @@ __global__ void __launch_bounds__(1024) k_compact(const uint8_t *dirty, uint64_t
 // p makes every k-mer covering p trusted, that alternative alone has the longest walk, it is
 // applied, and the walk continues through the trusted k-mers to the next run (or the read end).  At
 // most four flags are set, so the over-correction window cannot fire and nothing is left for the
-// recursion: errors = {p1..pm}.  This kernel decides that with two small cooperative lookups per
+// recursion: errors = {p1..pm}.  This kernel decides that with two small rounds of lookups per
 // read and marks the read done (dirty = 2); if any run has no or several full alternatives, or the
 // mask has any other shape, the read stays untouched for k_correct_wave.
 template <int NW>
