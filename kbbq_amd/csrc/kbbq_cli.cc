@@ -235,6 +235,30 @@ struct Batch {
     }
 };
 
+// What the output pass needs of one batch besides the new qualities, kept from the first scan when it fits in
+// host memory, so that the input is decoded once instead of twice: FASTQ name / comment / sequence text, or
+// the BAM alignment blocks.
+struct RecordStore {
+    std::string blob;
+    std::vector<uint32_t> lens;     // FASTQ: name, comment, sequence length per record; BAM: block length
+    size_t bytes() const { return blob.capacity() + lens.capacity() * 4; }
+    void add(const FastqRecord &r) {
+        blob += r.name; blob += r.comment; blob += r.seq;
+        lens.push_back((uint32_t)r.name.size()); lens.push_back((uint32_t)r.comment.size()); lens.push_back((uint32_t)r.seq.size());
+    }
+    void add(const BamRecord &r) {
+        blob.append((const char *)r.data.data(), r.data.size());
+        lens.push_back((uint32_t)r.data.size());
+    }
+};
+
+static uint64_t host_cache_budget() {
+    if (const char *s = getenv("KBBQ_HOST_CACHE_MB")) return strtoull(s, nullptr, 10) << 20;
+    const long pages = sysconf(_SC_PHYS_PAGES), psize = sysconf(_SC_PAGE_SIZE);
+    const uint64_t ram = pages > 0 && psize > 0 ? (uint64_t)pages * (uint64_t)psize : 0;
+    return std::min<uint64_t>(ram / 4, 64ULL << 30);
+}
+
 static int fail_engine(const char *what) {
     std::cerr << put_now << " Error: " << what << ": " << kbbq_last_error() << std::endl;
     return 1;
@@ -381,11 +405,17 @@ int main(int argc, char *argv[]) {
     Batch batch;
     struct Resident {
         std::vector<kbbq_reads> dev;
-        bool on = true;
-        uint64_t bytes = 0, budget = 0;
+        std::vector<RecordStore> recs;      // the records of the same batches, when they fit in host memory
+        bool on = true, keep_recs = true;
+        uint64_t bytes = 0, budget = 0, rec_bytes = 0, rec_budget = 0;
+        void drop_recs() {
+            std::vector<RecordStore>().swap(recs);
+            keep_recs = false;
+        }
         void drop() {
             for (auto &d : dev) { kbbq_reads_free_hints(&d); kbbq_reads_free(nullptr, &d); }
             dev.clear();
+            drop_recs();
             on = false;
         }
     } resident;
@@ -395,6 +425,8 @@ int main(int argc, char *argv[]) {
         uint64_t free_b = 0, total_b = 0;
         if ((env && !strcmp(env, "0")) || fixed_mode || kbbq_device_memory(-1, &free_b, &total_b) < 0) resident.on = false;
         resident.budget = (uint64_t)(0.6 * (double)free_b);
+        resident.rec_budget = host_cache_budget();
+        if (!resident.on || !resident.rec_budget) resident.keep_recs = false;
     }
     {
         std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
@@ -404,7 +436,7 @@ int main(int argc, char *argv[]) {
         }
         if (is_bam) bam_header = static_cast<BamSource *>(in.get())->header();
         bool counting = true;    // the coverage pass stops at the first empty read; the other passes do not
-        while (batch.fill(*in, groups, batch_reads, false)) {
+        while (batch.fill(*in, groups, batch_reads, resident.on && resident.keep_recs, is_bam)) {
             for (size_t r = 0; r < batch.c.n_reads && counting; ++r) {
                 const uint64_t l = batch.off[r + 1] - batch.off[r];
                 if (l == 0) counting = false; else seqlen += l;
@@ -426,6 +458,15 @@ int main(int argc, char *argv[]) {
                     resident.bytes += need;
                 }
             }
+            if (resident.on && resident.keep_recs) {
+                RecordStore st;
+                st.lens.reserve(batch.c.n_reads * (is_bam ? 1 : 3));
+                if (is_bam) for (auto &b : batch.bam_recs) st.add(b);
+                else for (auto &f : batch.fq_recs) st.add(f);
+                resident.rec_bytes += st.bytes();
+                if (resident.rec_bytes > resident.rec_budget) resident.drop_recs();
+                else resident.recs.push_back(std::move(st));
+            }
         }
         if (batch.fatal) return 1;
     }
@@ -435,7 +476,9 @@ int main(int argc, char *argv[]) {
     }
 
     kbbq_engine *e = nullptr;
-    if (resident.on) std::cerr << put_now << " Reads are resident on the GPU: " << resident.dev.size() << " batches." << std::endl;
+    if (resident.on)
+        std::cerr << put_now << " Reads are resident on the GPU: " << resident.dev.size() << " batches"
+                  << (resident.keep_recs ? ", their records in host memory." : ".") << std::endl;
 
     if (!fixed_mode) {
         if (genomelen == 0) {
@@ -609,50 +652,90 @@ int main(int argc, char *argv[]) {
     // pass 4, kbbq.cc:455-457: recalibrate_and_write(file, dqs, "-")
     std::cerr << put_now << " Recalibrating file" << std::endl;
     {
-        std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
         BgzfWriter out(stdout, out_threads);
         BamWriter bam_out(out);
         if (is_bam && !bam_out.write_header(bam_header)) return 1;      // BamFile::open_out, htsiter.cc:35-42
         std::vector<uint8_t> newq;
-        std::string qtext;
-        size_t bi = 0;
-        while (batch.fill(*in, groups, batch_reads, true, is_bam)) {
-            newq.assign(batch.c.n_bases + 16, 0);
-            if (resident.on) {
-                if (bi >= resident.dev.size() || resident.dev[bi].n_bases != batch.c.n_bases || resident.dev[bi].n_reads != batch.c.n_reads) {
-                    std::cerr << put_now << " Error: the input changed between the passes." << std::endl;
-                    return 1;
+        std::string qtext, line;
+        // FastqFile::write, htsiter.cc:75-86 (the comment goes on the '+' line); qualities as text, htsiter.cc:61-65
+        auto emit_fastq = [&](const char *name, size_t nl, const char *comment, size_t cl, const char *seq, size_t sl, const uint8_t *q) {
+            line.clear();
+            line += '@'; line.append(name, nl); line += '\n'; line.append(seq, sl); line += "\n+"; line.append(comment, cl); line += '\n';
+            const size_t at = line.size();
+            line.resize(at + sl);
+            for (size_t i = 0; i < sl; ++i) line[at + i] = (char)(q[i] + 33);
+            line += '\n';
+            return out.write(line.data(), line.size());
+        };
+        // BamFile::recalibrate + write, htsiter.cc:11-45
+        auto emit_bam = [&](BamRecord &b, const uint8_t *q) -> int {
+            const size_t len = b.l_seq();
+            if (set_oq) {
+                qtext.resize(len);
+                for (size_t i = 0; i < len; ++i) qtext[i] = (char)(b.qual()[i] + 33);
+                int status = 0;
+                if (!b.aux_update_string("OQ", qtext, status)) {
+                    std::cerr << "Tag data is corrupt. Repair the tags and try again." << std::endl;
+                    return -1;   // std::invalid_argument("Unable to update OQ tag.") in the reference
                 }
-                if (kbbq_recalibrate_batch_host(e, &resident.dev[bi], newq.data()) < 0) return fail_engine("recalibrating");
-                ++bi;
-            } else if (kbbq_recalibrate_batch(e, &batch.c, newq.data()) < 0) {
-                return fail_engine("recalibrating");
             }
-            for (size_t r = 0; r < batch.c.n_reads; ++r) {
-                const uint64_t a = batch.off[r], len = batch.off[r + 1] - a;
-                if (!is_bam) {
-                    qtext.resize(len);
-                    for (uint64_t i = 0; i < len; ++i) qtext[i] = (char)(newq[a + i] + 33);   // htsiter.cc:61-65
-                    if (!write_fastq_record(out, batch.fq_recs[r], qtext)) return 1;
-                    continue;
-                }
-                BamRecord &b = batch.bam_recs[r];                       // BamFile::recalibrate, htsiter.cc:11-34
-                if (set_oq) {
-                    qtext.resize(len);
-                    for (uint64_t i = 0; i < len; ++i) qtext[i] = (char)(b.qual()[i] + 33);
-                    int status = 0;
-                    if (!b.aux_update_string("OQ", qtext, status)) {
-                        std::cerr << "Tag data is corrupt. Repair the tags and try again." << std::endl;
-                        return 1;   // std::invalid_argument("Unable to update OQ tag.") in the reference
+            if (b.reverse()) std::reverse_copy(q, q + len, b.qual());
+            else std::copy(q, q + len, b.qual());
+            return bam_out.write(b) ? 0 : -1;
+        };
+        if (resident.on && resident.keep_recs) {
+            // every batch is in HBM and its records are in host memory: nothing is decoded again
+            BamRecord b;
+            for (size_t bi = 0; bi < resident.dev.size(); ++bi) {
+                const kbbq_reads &d = resident.dev[bi];
+                const RecordStore &st = resident.recs[bi];
+                newq.assign(d.n_bases + 16, 0);
+                if (kbbq_recalibrate_batch_host(e, &d, newq.data()) < 0) return fail_engine("recalibrating");
+                size_t at = 0, qa = 0;
+                for (size_t r = 0; r < d.n_reads; ++r) {
+                    if (is_bam) {
+                        const uint32_t n = st.lens[r];
+                        b.data.assign((const uint8_t *)st.blob.data() + at, (const uint8_t *)st.blob.data() + at + n);
+                        at += n;
+                        const size_t len = b.l_seq();
+                        if (emit_bam(b, newq.data() + qa) < 0) return 1;
+                        qa += len;
+                    } else {
+                        const uint32_t nl = st.lens[3 * r], cl = st.lens[3 * r + 1], sl = st.lens[3 * r + 2];
+                        const char *p = st.blob.data() + at;
+                        if (!emit_fastq(p, nl, p + nl, cl, p + nl + cl, sl, newq.data() + qa)) return 1;
+                        at += (size_t)nl + cl + sl;
+                        qa += sl;
                     }
                 }
-                uint8_t *q = b.qual();
-                if (b.reverse()) std::reverse_copy(newq.begin() + a, newq.begin() + a + len, q);
-                else std::copy(newq.begin() + a, newq.begin() + a + len, q);
-                if (!bam_out.write(b)) return 1;
             }
+        } else {
+            std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
+            size_t bi = 0;
+            while (batch.fill(*in, groups, batch_reads, true, is_bam)) {
+                newq.assign(batch.c.n_bases + 16, 0);
+                if (resident.on) {
+                    if (bi >= resident.dev.size() || resident.dev[bi].n_bases != batch.c.n_bases || resident.dev[bi].n_reads != batch.c.n_reads) {
+                        std::cerr << put_now << " Error: the input changed between the passes." << std::endl;
+                        return 1;
+                    }
+                    if (kbbq_recalibrate_batch_host(e, &resident.dev[bi], newq.data()) < 0) return fail_engine("recalibrating");
+                    ++bi;
+                } else if (kbbq_recalibrate_batch(e, &batch.c, newq.data()) < 0) {
+                    return fail_engine("recalibrating");
+                }
+                for (size_t r = 0; r < batch.c.n_reads; ++r) {
+                    const uint8_t *q = newq.data() + batch.off[r];
+                    if (is_bam) {
+                        if (emit_bam(batch.bam_recs[r], q) < 0) return 1;
+                    } else {
+                        const FastqRecord &f = batch.fq_recs[r];
+                        if (!emit_fastq(f.name.data(), f.name.size(), f.comment.data(), f.comment.size(), f.seq.data(), f.seq.size(), q)) return 1;
+                    }
+                }
+            }
+            if (batch.fatal) return 1;
         }
-        if (batch.fatal) return 1;
         if (!out.close()) return 1;
     }
     resident.drop();

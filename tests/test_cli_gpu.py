@@ -89,9 +89,12 @@ def test_cli_streaming_and_resident_modes_agree(tmp_path):
     write_fastq(fq, d, names)
     rc, out_res, err_res = run_cli(["-g", d["genome_len"], fq], {"KBBQ_SEED": "5"})
     assert rc == 0 and "Reads are resident on the GPU" in err_res
+    assert "their records in host memory" in err_res          # nothing is decoded twice
+    rc, out_nocache, err_nocache = run_cli(["-g", d["genome_len"], fq], {"KBBQ_SEED": "5", "KBBQ_HOST_CACHE_MB": "0"})
+    assert rc == 0 and "resident on the GPU" in err_nocache and "host memory" not in err_nocache     # second decode for the output
     rc, out_str, err_str = run_cli(["-g", d["genome_len"], "-t", 1, fq], {"KBBQ_SEED": "5", "KBBQ_RESIDENT": "0"})
     assert rc == 0 and "resident" not in err_str
-    assert out_res == out_str
+    assert out_res == out_str == out_nocache
     ora = common.run_oracle(dict(d, coverage=int(d["off"][-1]) // d["genome_len"]), seed=5, n_rg=n_rg)
     got = "".join(q for _, _, _, q in read_fastq_text(gzip.decompress(out_res)))
     assert got == (ora["recal"] + 33).astype(np.uint8).tobytes().decode()
