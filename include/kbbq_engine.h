@@ -200,7 +200,11 @@ int kbbq_trusted_finish(kbbq_engine *e, uint64_t *inserted);
 /* ---- pass 3: recalibrateutils::get_covariatedata (recalibrateutils.cc:42-89) */
 
 /* get_errors(trusted, k, 6) then CCovariateData::consume_read for every read.
- * errors_out (optional): 1 bit per base, CReadData::errors. */
+ * errors_out (optional): 1 bit per base, CReadData::errors.
+ * Asynchronous for device-resident batches without errors_out: the call returns once the batch is queued (its
+ * correction walk and tally run on a side stream beside the next batch's Bloom scan) and the batch's arrays
+ * must stay valid until the next synchronising call -- kbbq_engine_sync, kbbq_train, kbbq_covariates_get,
+ * kbbq_stats_get or kbbq_engine_reset.  Host batches and calls with errors_out complete before returning. */
 int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_out);
 /* --fixed mode (kbbq.cc:367-378): tally with caller-supplied error bits. */
 int kbbq_tally_batch(kbbq_engine *e, const kbbq_reads *reads, const uint64_t *errors);
@@ -215,7 +219,8 @@ typedef struct kbbq_covariates {
 } kbbq_covariates;
 int kbbq_covariates_get(kbbq_engine *e, kbbq_covariates *out);
 /* Device addresses + word counts of the two tallied histograms (cycle, dinuc),
- * contiguous, for the multi-GPU sum all-reduce. */
+ * contiguous, for the multi-GPU sum all-reduce.  Call kbbq_engine_sync first: tallies of the last batches may
+ * still be running (see kbbq_errors_batch). */
 void *kbbq_covariates_device(kbbq_engine *e, uint64_t *n_words);
 
 /* ---- CCovariateData::get_dqs (covariateutils.cc:204-230) ------------------ */
