@@ -47,7 +47,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-PASS3_KERNELS = ("k_scan_trusted", "k_compact", "k_fix_single", "k_correct_wave", "k_correct", "k_tally")
+PASS3_KERNELS = ("k_scan_trusted", "k_compact", "k_correct_wave", "k_correct", "k_tally")
 
 
 def run_step(e, xch, batches, ordinals, out_buf, hints):

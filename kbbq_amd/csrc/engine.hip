@@ -792,20 +792,11 @@ int kbbq_trusted_finish(kbbq_engine *e, uint64_t *inserted) {
 
 // ---- pass 3
 }  // extern "C"
-template <int NW> struct LaunchFixSingle {
-    static int go(kbbq_engine *e, ReadsDev R, const uint32_t *list, const uint64_t *tmask, uint32_t *err_bits, uint8_t *dirty) {
-        Timed t(e, "k_fix_single", e->cur);
-        hipLaunchKernelGGL(k_fix_single<NW>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->cur, R, e->K, e->filt[1].dev(),
-                           list, (const unsigned long long *)e->cur_cnt, tmask, err_bits, dirty, e->cur_cnt);
-        HIP_TRY(hipGetLastError());
-        return KBBQ_OK;
-    }
-};
 template <int NW> struct LaunchScan {
-    static int go(kbbq_engine *e, ReadsDev R, uint64_t *tmask, uint8_t *dirty) {
+    static int go(kbbq_engine *e, ReadsDev R, uint64_t *tmask, uint8_t *dirty, uint32_t *err_bits, int fast) {
         Timed t(e, "k_scan_trusted", e->cur);
         hipLaunchKernelGGL(k_scan_trusted<NW>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->cur, R, e->K,
-                           e->filt[1].dev(), tmask, dirty);
+                           e->filt[1].dev(), tmask, dirty, err_bits, e->cur_cnt, fast);
         HIP_TRY(hipGetLastError());
         return KBBQ_OK;
     }
@@ -916,17 +907,10 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
     uint8_t *dirty = (uint8_t *)e->scratch[s_dirty];
     uint32_t *list = (uint32_t *)e->scratch[s_list];
     uint32_t *patch = (uint32_t *)e->scratch[s_patch];
-    if ((rc = dispatch_nw<LaunchScan>(max_len, e, R, tmask, dirty))) return rc;
-    {
-        Timed t(e, "k_compact", e->cur);
-        hipLaunchKernelGGL(k_compact, dim3((unsigned)((R.n_reads + 1023) / 1024)), dim3(1024), 0, e->cur, dirty, R.n_reads, list, e->cur_cnt, 0);
-        HIP_TRY(hipGetLastError());
-    }
-    // isolated single errors are settled by the fast path; the walk gets what is left
+    // isolated single errors are settled inside the scan (fast_path); the walk gets what is left (dirty == 1)
     static const bool no_fast = getenv("KBBQ_NO_FASTPATH") != nullptr;
-    if (!no_fast && e->p.k >= 3) {
-        if ((rc = dispatch_nw<LaunchFixSingle>(max_len, e, R, (const uint32_t *)list, (const uint64_t *)tmask, d_err, dirty))) return rc;
-        HIP_TRY(hipMemsetAsync(e->cur_cnt, 0, 8, e->cur));
+    if ((rc = dispatch_nw<LaunchScan>(max_len, e, R, tmask, dirty, d_err, (!no_fast && e->p.k >= 3) ? 1 : 0))) return rc;
+    {
         Timed t(e, "k_compact", e->cur);
         hipLaunchKernelGGL(k_compact, dim3((unsigned)((R.n_reads + 1023) / 1024)), dim3(1024), 0, e->cur, dirty, R.n_reads, list, e->cur_cnt, 1);
         HIP_TRY(hipGetLastError());

@@ -4,9 +4,9 @@
 //           k_insert_marked    sampled & valid k-mers -> sampled filter   (recalibrateutils.cc:7-13)
 //   pass 2  k_infer            infer_read_errors, which k-mers are trusted (recalibrateutils.cc:15-40)
 //           k_insert_marked    those k-mers -> trusted filter
-//   pass 3  k_scan_trusted     trusted mask of every k-mer; clean reads finish here
+//   pass 3  k_scan_trusted     trusted mask of every k-mer; clean reads finish here, reads with up to four isolated
+//                              errors in its fast path (fast_path)
 //           k_compact          work list of reads that need more
-//           k_fix_single       reads with up to four isolated errors (fast path of get_errors)
 //           k_correct_wave     get_errors, one read per wavefront (correct_wave.h); k_correct: one read per lane (correct.h)
 //           k_tally            covariate histograms                      (covariateutils.cc:30-164,193-202)
 //   pass 4  k_recalibrate      delta-Q apply                             (readutils.cc:572-595)
@@ -306,13 +306,130 @@ __global__ void __launch_bounds__(256) k_infer(ReadsDev R, KParams K, FiltDev S,
     if (lane == 0 && mine) atomicAdd(inserted, mine);
 }
 
+// ---- pass 3a': the isolated-error fast path (inside k_scan_trusted) -------------------
+// Most reads that need work carry a few ISOLATED errors: their trusted mask has up to four separate
+// runs of untrusted k-mers, each run being exactly the k-mers that cover one base p.  For such a
+// read get_errors (readutils.cc:238-570) reduces to: the anchor is the longest trusted run; walking
+// away from it, find_longest_fix meets the errors one at a time; if exactly one alternative base at
+// p makes every k-mer covering p trusted, that alternative alone has the longest walk, it is
+// applied, and the walk continues through the trusted k-mers to the next run (or the read end).  At
+// most four flags are set, so the over-correction window cannot fire and nothing is left for the
+// recursion: errors = {p1..pm}.  The scan kernel decides that with two small rounds of lookups per
+// read, while the read is still staged in its LDS slice, and marks the read done (dirty = 2); if any
+// run has no or several full alternatives, or the mask has any other shape, the read goes to k_correct_wave.
+// Z = the read's untrusted k-mer starts (complement of the trusted mask inside [0, nk)), `zeros` their number;
+// the read's words are staged in the wave's LDS slice L32 (Stage<NW>).  Returns true when the read is
+// settled (its flags are then OR-ed into err_bits); q_total counts the lookups.
+template <int NW>
+__device__ __forceinline__ bool fast_path(const uint32_t *L32, const KParams &K, const FiltDev &T, const uint64_t (&Z)[NW], int zeros,
+                                          uint64_t off, int nk, int o31, int o63, uint32_t *err_bits, int lane,
+                                          unsigned long long &q_total) {
+    using S = Stage<NW>;
+    constexpr int MAXRUN = 4;
+    const int k = K.k;
+    auto next_bit = [&](int from, bool one) -> int {      // first index >= from with Z bit == one, nk if none
+        while (from < nk) {
+            uint64_t x = sel_word<NW>(Z, from >> 6);
+            if (!one) x = ~x;
+            x >>= (from & 63);
+            if (x) { const int q = from + __ffsll((unsigned long long)x) - 1; return q < nk ? q : nk; }
+            from = ((from >> 6) + 1) << 6;
+        }
+        return nk;
+    };
+    int m = 0, z0s[MAXRUN], z1s[MAXRUN], ps[MAXRUN];
+    bool eligible = zeros > 0 && zeros < nk;
+    for (int pos = next_bit(0, true); eligible && pos < nk;) {
+        const int z0 = pos, z1 = next_bit(pos, false) - 1;
+        if (m == MAXRUN || z1 - z0 + 1 > k) { eligible = false; break; }
+        const int p = z0 > 0 ? z0 + k - 1 : z1;
+        // the run must be exactly the in-range starts that cover p
+        if (!(z0 == max(0, p - k + 1) && z1 == min(p, nk - 1))) { eligible = false; break; }
+#pragma unroll
+        for (int q = 0; q < MAXRUN; ++q) if (q == m) { z0s[q] = z0; z1s[q] = z1; ps[q] = p; }
+        ++m;
+        pos = next_bit(z1 + 1, true);
+    }
+    int singles = 0;   // runs with exactly one full alternative
+    if (eligible) {
+        auto pick = [&](const int (&a)[MAXRUN], int idx) -> int {
+            int v = a[0];
+#pragma unroll
+            for (int q = 1; q < MAXRUN; ++q) v = (idx == q) ? a[q] : v;
+            return v;
+        };
+        // k-mer starting at st with base p := y
+        auto key_of = [&](int st, int p, int y, bool &valid) -> uint64_t {
+            uint64_t w = lds_window64(L32 + 2 * S::B, 2 * (o31 + st));
+            uint32_t nm = lds_window32(L32 + 2 * S::M, o63 + st) & K.nmask_bits;
+            const int j = p - st;
+            w = (w & ~(3ULL << (2 * j))) | ((uint64_t)y << (2 * j));
+            nm &= ~(1u << j);
+            valid = nm == 0;
+            return canon_key(w, K);
+        };
+        // round 1: one covering k-mer per (run, alternative): lane 4*run + y
+        int alive;
+        {
+            const int run = lane >> 2, y = lane & 3;
+            bool act = lane < 4 * m;
+            int p = 0, st = 0;
+            if (act) {
+                p = pick(ps, run);
+                st = pick(z0s, run);
+                const int cur = lds_bit(L32 + 2 * S::M, o63 + p) ? 4 : (int)((L32[2 * S::B + ((o31 + p) >> 4)] >> (((o31 + p) & 15) * 2)) & 3);
+                act = y != cur;
+            }
+            bool valid = false;
+            const uint64_t key = key_of(st, p, y, valid);
+            const bool go = act && valid;
+            q_total += __popcll(__ballot(go));
+            const bool t = go && bloom_has(T, key);
+            alive = (int)(__ballot(t) & 0xFFFF);
+        }
+        // round 2: every covering k-mer of the survivors, two (run, alternative) pairs per lookup
+        int full = 0;   // 3 bits per run: number of alternatives whose covering k-mers are all trusted
+        while (alive) {
+            const int a = __ffs(alive) - 1;
+            alive &= alive - 1;
+            int b = -1;
+            if (alive) { b = __ffs(alive) - 1; alive &= alive - 1; }
+            const int mine = (lane >> 5) ? b : a;
+            const int run = mine >= 0 ? mine >> 2 : 0, y = mine >= 0 ? (mine & 3) : 0;
+            const int z0 = pick(z0s, run), z1 = pick(z1s, run), p = pick(ps, run);
+            const int st = z0 + (lane & 31);
+            const bool act = mine >= 0 && st <= z1;
+            bool valid = false;
+            const uint64_t key = key_of(act ? st : z0, p, y, valid);
+            const bool go = act && valid;
+            q_total += __popcll(__ballot(go));
+            const bool t = go && bloom_has(T, key);
+            const unsigned long long bal = __ballot(t);
+            const int ra = a >> 2;
+            if (__popcll(bal & 0xFFFFFFFFULL) == pick(z1s, ra) - pick(z0s, ra) + 1) full += 1 << (3 * ra);
+            if (b >= 0) {
+                const int rb = b >> 2;
+                if (__popcll(bal >> 32) == pick(z1s, rb) - pick(z0s, rb) + 1) full += 1 << (3 * rb);
+            }
+        }
+        for (int q = 0; q < m; ++q) singles += ((full >> (3 * q)) & 7) == 1 ? 1 : 0;
+    }
+    const bool fixed = eligible && singles == m;
+    if (fixed && lane < m) {
+        const uint64_t g = off + (lane == 0 ? ps[0] : lane == 1 ? ps[1] : lane == 2 ? ps[2] : ps[3]);
+        atomicOr(&err_bits[g >> 5], 1u << (g & 31));
+    }
+    return fixed;
+}
+
 // ---- pass 3a: trusted mask of every k-mer ------------------------------------
 // Wave per read.  A read whose k-mers are all trusted has no errors
 // (readutils.cc:263-265) and needs nothing more than the tally; the others get
 // their mask stored and a flag for the correction kernel.
 template <int NW>
 __global__ void __launch_bounds__(256) k_scan_trusted(ReadsDev R, KParams K, FiltDev T, uint64_t *tmask,
-                                                       uint8_t *dirty) {
+                                                       uint8_t *dirty, uint32_t *err_bits, unsigned long long *stats,
+                                                       int fast) {
     using S = Stage<NW>;
     __shared__ uint32_t lds[4][2 * S::WORDS];
     const int lane = threadIdx.x & 63;
@@ -321,6 +438,7 @@ __global__ void __launch_bounds__(256) k_scan_trusted(ReadsDev R, KParams K, Fil
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t *hint = reinterpret_cast<const uint64_t *>(R.hint_trusted);
     const int k = K.k;
+    unsigned long long q_total = 0;
     uint64_t off = 0, word = 0;
     uint32_t len = 0;
     if (wave < R.n_reads) {
@@ -331,6 +449,7 @@ __global__ void __launch_bounds__(256) k_scan_trusted(ReadsDev R, KParams K, Fil
         __builtin_amdgcn_wave_barrier();
         if (lane < S::WORDS) stage_store(L32, lane, word);
         __builtin_amdgcn_wave_barrier();
+        const uint64_t cur = off;
         const int o31 = (int)(off & 31), o63 = (int)(off & 63);
         const int nk = (int)len - k + 1;
         if (r + n_waves < R.n_reads) {   // the next read's words travel while this one is processed
@@ -368,10 +487,22 @@ __global__ void __launch_bounds__(256) k_scan_trusted(ReadsDev R, KParams K, Fil
                 trusted += __popcll(M[c]);
             }
         }
-        const bool is_dirty = trusted != nk;
-        if (lane == 0) dirty[r] = is_dirty ? 1 : 0;
-        if (is_dirty && lane < NW) tmask[r * NW + lane] = sel_word<NW>(M, lane);
+        // 0 = every k-mer trusted, nothing to do; 2 = settled by the fast path right here (the read is still staged:
+        // waves in their lookup rounds and waves streaming through clean reads share the CU); 1 = needs the walk
+        int state = trusted != nk ? 1 : 0;
+        if (state && fast) {
+            uint64_t Z[NW];
+#pragma unroll
+            for (int c = 0; c < NW; ++c) {
+                const int rem = nk - c * 64;
+                Z[c] = rem <= 0 ? 0ULL : (~M[c] & (rem >= 64 ? ~0ULL : ((1ULL << rem) - 1)));
+            }
+            if (fast_path<NW>(L32, K, T, Z, nk - trusted, cur, nk, o31, o63, err_bits, lane, q_total)) state = 2;
+        }
+        if (lane == 0) dirty[r] = (uint8_t)state;
+        if (state == 1 && lane < NW) tmask[r * NW + lane] = sel_word<NW>(M, lane);
     }
+    if (lane == 0 && q_total) atomicAdd(&stats[1], q_total);
 }
 
 __global__ void __launch_bounds__(1024) k_compact(const uint8_t *dirty, uint64_t n, uint32_t *list,
@@ -392,183 +523,6 @@ __global__ void __launch_bounds__(1024) k_compact(const uint8_t *dirty, uint64_t
     }
     __syncthreads();
     if (d) list[block_base + wave_cnt[w] + __popcll(bal & ((1ULL << lane) - 1))] = (uint32_t)i;
-}
-
-// ---- pass 3a': the isolated-error fast path ------------------------------------------
-// Most reads that need work carry a few ISOLATED errors: their trusted mask has up to four separate
-// runs of untrusted k-mers, each run being exactly the k-mers that cover one base p.  For such a
-// read get_errors (readutils.cc:238-570) reduces to: the anchor is the longest trusted run; walking
-// away from it, find_longest_fix meets the errors one at a time; if exactly one alternative base at
-// p makes every k-mer covering p trusted, that alternative alone has the longest walk, it is
-// applied, and the walk continues through the trusted k-mers to the next run (or the read end).  At
-// most four flags are set, so the over-correction window cannot fire and nothing is left for the
-// recursion: errors = {p1..pm}.  This kernel decides that with two small rounds of lookups per
-// read and marks the read done (dirty = 2); if any run has no or several full alternatives, or the
-// mask has any other shape, the read stays untouched for k_correct_wave.
-template <int NW>
-__global__ void __launch_bounds__(256) k_fix_single(ReadsDev R, KParams K, FiltDev T, const uint32_t *list,
-                                                     const unsigned long long *n_list, const uint64_t *tmask,
-                                                     uint32_t *err_bits, uint8_t *dirty, unsigned long long *stats) {
-    using S = Stage<NW>;
-    constexpr int MAXRUN = 4;
-    __shared__ uint32_t lds[4][2 * S::WORDS];
-    const int lane = threadIdx.x & 63;
-    uint32_t *L32 = lds[threadIdx.x >> 6];
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    const uint64_t n = *n_list;
-    const int k = K.k;
-    unsigned long long q_total = 0;
-    // Three reads are in flight per wave: A is being decided, B's words are travelling, C's list entry
-    // and span are travelling -- the dependent chain list -> offsets -> words never sits in front of
-    // the two lookup rounds.
-    uint64_t rA = 0, offA = 0, wordA = 0, rB = 0, offB = 0, rC = 0, slotC = wave + 2 * n_waves;
-    uint64_t tmA[NW], tmB[NW];                        // trusted masks: wave-uniform, scalar loads
-#pragma unroll
-    for (int c = 0; c < NW; ++c) { tmA[c] = 0; tmB[c] = 0; }
-    uint32_t lenA = 0, lenB = 0;
-    bool hasA = wave < n, hasB = wave + n_waves < n, hasC = slotC < n;
-    if (hasA) {
-        rA = list[wave];
-        read_span(R, rA, offA, lenA);
-        wordA = stage_fetch<NW>(R, nullptr, nullptr, 0, 0, offA, lane);
-#pragma unroll
-        for (int c = 0; c < NW; ++c) tmA[c] = tmask[rA * NW + c];
-    }
-    if (hasB) {
-        rB = list[wave + n_waves];
-        read_span(R, rB, offB, lenB);
-#pragma unroll
-        for (int c = 0; c < NW; ++c) tmB[c] = tmask[rB * NW + c];
-    }
-    if (hasC) rC = list[slotC];
-    while (hasA) {
-        __builtin_amdgcn_wave_barrier();
-        if (lane < S::WORDS) stage_store(L32, lane, wordA);
-        __builtin_amdgcn_wave_barrier();
-        const uint64_t r = rA, off = offA;
-        const int len = (int)lenA, nk = len - k + 1;
-        const int o31 = (int)(off & 31), o63 = (int)(off & 63);
-        // runs of untrusted k-mer starts: z = complement of the trusted mask inside [0, nk)
-        uint64_t Z[NW];
-        int zeros = 0;
-#pragma unroll
-        for (int c = 0; c < NW; ++c) {
-            Z[c] = 0;
-            if (c * 64 < nk) {
-                const int rem = nk - c * 64;
-                Z[c] = ~tmA[c] & (rem >= 64 ? ~0ULL : ((1ULL << rem) - 1));
-                zeros += __popcll(Z[c]);
-            }
-        }
-        if (hasB) wordA = stage_fetch<NW>(R, nullptr, nullptr, 0, 0, offB, lane);
-        auto next_bit = [&](int from, bool one) -> int {      // first index >= from with Z bit == one, nk if none
-            while (from < nk) {
-                uint64_t x = sel_word<NW>(Z, from >> 6);
-                if (!one) x = ~x;
-                x >>= (from & 63);
-                if (x) { const int q = from + __ffsll((unsigned long long)x) - 1; return q < nk ? q : nk; }
-                from = ((from >> 6) + 1) << 6;
-            }
-            return nk;
-        };
-        int m = 0, z0s[MAXRUN], z1s[MAXRUN], ps[MAXRUN];
-        bool eligible = zeros > 0 && zeros < nk;
-        for (int pos = next_bit(0, true); eligible && pos < nk;) {
-            const int z0 = pos, z1 = next_bit(pos, false) - 1;
-            if (m == MAXRUN || z1 - z0 + 1 > k) { eligible = false; break; }
-            const int p = z0 > 0 ? z0 + k - 1 : z1;
-            // the run must be exactly the in-range starts that cover p
-            if (!(z0 == max(0, p - k + 1) && z1 == min(p, nk - 1))) { eligible = false; break; }
-#pragma unroll
-            for (int q = 0; q < MAXRUN; ++q) if (q == m) { z0s[q] = z0; z1s[q] = z1; ps[q] = p; }
-            ++m;
-            pos = next_bit(z1 + 1, true);
-        }
-        int singles = 0;   // runs with exactly one full alternative
-        uint64_t offC = 0;
-        uint32_t lenC = 0;
-        bool spanC_done = false;
-        if (eligible) {
-            auto pick = [&](const int (&a)[MAXRUN], int idx) -> int {
-                int v = a[0];
-#pragma unroll
-                for (int q = 1; q < MAXRUN; ++q) v = (idx == q) ? a[q] : v;
-                return v;
-            };
-            // k-mer starting at st with base p := y
-            auto key_of = [&](int st, int p, int y, bool &valid) -> uint64_t {
-                uint64_t w = lds_window64(L32 + 2 * S::B, 2 * (o31 + st));
-                uint32_t nm = lds_window32(L32 + 2 * S::M, o63 + st) & K.nmask_bits;
-                const int j = p - st;
-                w = (w & ~(3ULL << (2 * j))) | ((uint64_t)y << (2 * j));
-                nm &= ~(1u << j);
-                valid = nm == 0;
-                return canon_key(w, K);
-            };
-            // round 1: one covering k-mer per (run, alternative): lane 4*run + y
-            int alive;
-            {
-                const int run = lane >> 2, y = lane & 3;
-                bool act = lane < 4 * m;
-                int p = 0, st = 0;
-                if (act) {
-                    p = pick(ps, run);
-                    st = pick(z0s, run);
-                    const int cur = lds_bit(L32 + 2 * S::M, o63 + p) ? 4 : (int)((L32[2 * S::B + ((o31 + p) >> 4)] >> (((o31 + p) & 15) * 2)) & 3);
-                    act = y != cur;
-                }
-                bool valid = false;
-                const uint64_t key = key_of(st, p, y, valid);
-                const bool go = act && valid;
-                q_total += __popcll(__ballot(go));
-                const bool t = go && bloom_has(T, key);
-                if (hasC) { read_span(R, rC, offC, lenC); spanC_done = true; }
-                alive = (int)(__ballot(t) & 0xFFFF);
-            }
-            // round 2: every covering k-mer of the survivors, two (run, alternative) pairs per lookup
-            int full = 0;   // 3 bits per run: number of alternatives whose covering k-mers are all trusted
-            while (alive) {
-                const int a = __ffs(alive) - 1;
-                alive &= alive - 1;
-                int b = -1;
-                if (alive) { b = __ffs(alive) - 1; alive &= alive - 1; }
-                const int mine = (lane >> 5) ? b : a;
-                const int run = mine >= 0 ? mine >> 2 : 0, y = mine >= 0 ? (mine & 3) : 0;
-                const int z0 = pick(z0s, run), z1 = pick(z1s, run), p = pick(ps, run);
-                const int st = z0 + (lane & 31);
-                const bool act = mine >= 0 && st <= z1;
-                bool valid = false;
-                const uint64_t key = key_of(act ? st : z0, p, y, valid);
-                const bool go = act && valid;
-                q_total += __popcll(__ballot(go));
-                const bool t = go && bloom_has(T, key);
-                const unsigned long long bal = __ballot(t);
-                const int ra = a >> 2;
-                if (__popcll(bal & 0xFFFFFFFFULL) == pick(z1s, ra) - pick(z0s, ra) + 1) full += 1 << (3 * ra);
-                if (b >= 0) {
-                    const int rb = b >> 2;
-                    if (__popcll(bal >> 32) == pick(z1s, rb) - pick(z0s, rb) + 1) full += 1 << (3 * rb);
-                }
-            }
-            for (int q = 0; q < m; ++q) singles += ((full >> (3 * q)) & 7) == 1 ? 1 : 0;
-        }
-        if (eligible && singles == m && lane < m) {
-            const uint64_t g = off + (lane == 0 ? ps[0] : lane == 1 ? ps[1] : lane == 2 ? ps[2] : ps[3]);
-            atomicOr(&err_bits[g >> 5], 1u << (g & 31));
-            if (lane == 0) dirty[r] = 2;
-        }
-        // rotate the pipeline
-        if (hasC && !spanC_done) read_span(R, rC, offC, lenC);
-        hasA = hasB; rA = rB; offA = offB; lenA = lenB;
-        hasB = hasC; rB = rC; offB = offC; lenB = lenC;
-#pragma unroll
-        for (int c = 0; c < NW; ++c) { tmA[c] = tmB[c]; tmB[c] = hasC ? tmask[rC * NW + c] : 0; }
-        slotC += n_waves;
-        hasC = slotC < n;
-        if (hasC) rC = list[slotC];
-    }
-    if (lane == 0 && q_total) atomicAdd(&stats[1], q_total);
 }
 
 // ---- pass 3b: the correction walk, one read per lane ---------------------------
