@@ -1,0 +1,36 @@
+"""bench.py keeps the driver's contract: one JSON line with the agreed keys, the roofline object for a kernel
+that runs alone, the CPU baseline leg -- checked on a small configuration."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_prints_one_contract_line():
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--genome-len", "30000000",
+                          "--cpu-genome-len", "300000"], cwd=common.ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["metric"] == "recalibrated Gbases/sec" and d["unit"] == "Gbases/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    assert "model" not in d["config"]
+    bases = d["config"]["bases"]
+    assert abs(d["value"] - bases / (d["ms_per_step"] / 1e3) / 1e9) < 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert not d["kernels"][r["kernel"]].get("overlapped")          # an exclusive duration
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] / 1e3) / 1e9) < 0.01 * r["achieved"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Gbases/s" and c["value"] > 0 and "sample" in c
+    assert d["result"]["recal_qual_sum"] > 0 and d["result"]["trusted_inserted"] > d["result"]["sampled_inserted"] > 0
