@@ -97,13 +97,26 @@ class Exchange:
     aliasing the tallied histograms, train() -> dict of int32 arrays, set_dq(dict), quiesce().
     """
 
-    def __init__(self, peer, group=None, slab_words=1 << 27, device=None, force=False):
+    def __init__(self, peer, group=None, slab_words=1 << 27, device=None, force=False, stage_host=False):
         self.peer = peer
         self.group = group
         self.slab_words = slab_words
         self.rank, self.n = world(group)
         self.device = device
         self.force = force and dist.is_initialized()   # run the collectives even with one rank
+        # stage_host: the peer's tensors live on a GPU but the process group cannot move device memory (gloo):
+        # copy to the host, reduce there, copy back.  Lets several ranks share one GPU in the tests.
+        self.stage_host = stage_host
+
+    def _reduce(self, t, fn):
+        if not self.stage_host:
+            return fn(t)
+        c = t.cpu()
+        fn(c)
+        t.copy_(c)
+        if t.is_cuda:
+            torch.cuda.synchronize()
+        return t
 
     def filter_done(self, which):
         """After pass 1 (which=0) or pass 2 (which=1): make filter and counter global."""
@@ -111,8 +124,12 @@ class Exchange:
         if self.n == 1 and not self.force:
             return local
         self.peer.quiesce()
-        or_allreduce_(self.peer.table_tensor(which), self.peer.or_into, self.slab_words, self.group,
-                      getattr(self.peer, "or_pieces", None), force=self.force)
+        if self.stage_host:
+            self._reduce(self.peer.table_tensor(which),
+                         lambda c: or_allreduce_(c, lambda dst, src: dst.bitwise_or_(src), self.slab_words, self.group, None, force=self.force))
+        else:
+            or_allreduce_(self.peer.table_tensor(which), self.peer.or_into, self.slab_words, self.group,
+                          getattr(self.peer, "or_pieces", None), force=self.force)
         cnt = torch.tensor([local], dtype=torch.int64, device=self.device)
         sum_allreduce_(cnt, self.group)
         total = int(cnt.item())
@@ -124,7 +141,7 @@ class Exchange:
         if self.n == 1 and not self.force:
             return
         self.peer.quiesce()
-        sum_allreduce_(self.peer.hist_tensor(), self.group)
+        self._reduce(self.peer.hist_tensor(), lambda c: sum_allreduce_(c, self.group))
         self.peer.quiesce()
 
     def train_and_share(self):
