@@ -197,10 +197,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    # KBBQ_BENCH_BACKEND=gloo with KBBQ_BENCH_ONE_GPU=1 runs every rank on device 0 and stages the collectives
+    # through the host: a functional check of the N > 1 path on a one-GPU box (tests/test_bench_contract_gpu.py),
+    # not a measurement.  The driver's runs use the default: one rank per GPU over RCCL.
+    backend = os.environ.get("KBBQ_BENCH_BACKEND", "nccl")
+    if os.environ.get("KBBQ_BENCH_ONE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     G, cov = args.genome_len, args.coverage
     n_reads_total = G * cov // READ_LEN
@@ -225,7 +234,8 @@ def main():
         batches.append(shard.view(s, n))
         ordinals.append((a + s) * nk_per_read)
     out_buf = torch.empty(min(BATCH_READS, n_local) * READ_LEN + 16, dtype=torch.uint8, device="cuda")
-    xch = Exchange(EnginePeer(e), device=torch.device("cuda", local_rank))
+    xch = Exchange(EnginePeer(e), device=torch.device("cuda", local_rank) if backend == "nccl" else None,
+                   stage_host=backend != "nccl")
 
     def barrier():
         e.sync()
@@ -244,8 +254,9 @@ def main():
         info = run_step(e, xch, batches, ordinals, out_buf, hints)
     barrier()
     dt = time.perf_counter() - t0
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -258,7 +269,7 @@ def main():
         e.sync()
         digest += int(out_buf[:bt.n_bases].to(torch.int64).sum().item())
     if world > 1:
-        dg = torch.tensor([digest], dtype=torch.int64, device="cuda")
+        dg = torch.tensor([digest], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(dg)
         digest = int(dg.item())
 
