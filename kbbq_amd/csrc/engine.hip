@@ -82,6 +82,7 @@ struct kbbq_engine {
     bool side_busy[2] = {false, false};     // counters of that side not yet added to stats
     uint64_t side_reads[2] = {0, 0};
     int side_turn = 0;
+    uint32_t *d_rg_present[2] = {nullptr, nullptr};     // which read groups a batch contains (run_tally), per stream
     hipStream_t cur = nullptr;              // stream and counter pair the pass-3 launch helpers use
     unsigned long long *cur_cnt = nullptr;
     FilterHost filt[2];
@@ -349,6 +350,7 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
     CREATE_TRY(hipMalloc(&e->d_counters, 64));
     CREATE_TRY(hipMemset(e->d_counters, 0, 64));
     e->cur_cnt = e->d_counters;
+    for (int i = 0; i < 2; ++i) CREATE_TRY(hipMalloc(&e->d_rg_present[i], (((size_t)params->n_rg + 31) / 32) * 4 + 4));
     for (int w = 0; w < 2; ++w) {
         FilterHost &f = e->filt[w];
         CREATE_TRY(hipMalloc(&f.d_table, f.table_bytes()));
@@ -394,6 +396,8 @@ void kbbq_engine_destroy(kbbq_engine *e) {
     hipFree(e->d_dq_cycle);
     hipFree(e->d_dq_dinuc);
     hipFree(e->d_counters);
+    hipFree(e->d_rg_present[0]);
+    hipFree(e->d_rg_present[1]);
     hipFree(e->d_qcum);
     hipFree(e->d_errthr);
     for (int i = 0; i < 16; ++i) hipFree(e->scratch[i]);
@@ -855,12 +859,25 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
         HIP_TRY(hipFuncSetAttribute((const void *)k_tally, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
-    Timed t(e, "k_tally", stream);
-    // 16 wavefronts share one LDS table: two blocks (32 waves) per CU at 150-base reads
+    // 16 wavefronts share one LDS table: one 1024-lane block per CU at 150-base reads
     const uint64_t groups = (R.n_bases + 15) / 16;
     const int blocks = (int)std::min<uint64_t>((groups + 1023) / 1024, 256);
     const int vec_ok = ((uintptr_t)R.qual & 15) == 0;
-    hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, vec_ok);
+    if (!R.rg || e->p.n_rg == 1) {
+        Timed t(e, "k_tally", stream);
+        hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, vec_ok, 0, (const uint32_t *)nullptr);
+        HIP_TRY(hipGetLastError());
+        return KBBQ_OK;
+    }
+    // several read groups: which of them occur in this batch (bitmap on the device), then one launch per group;
+    // launches for absent groups return immediately
+    uint32_t *present = e->d_rg_present[stream == e->stream2 ? 1 : 0];
+    const size_t words = ((size_t)e->p.n_rg + 31) / 32;
+    HIP_TRY(hipMemsetAsync(present, 0, words * 4, stream));
+    hipLaunchKernelGGL(k_rg_presence, dim3((unsigned)((R.n_reads + 255) / 256)), dim3(256), 0, stream, R.rg, R.n_reads, (uint32_t)e->p.n_rg, present);
+    Timed t(e, "k_tally", stream);
+    for (int g = 0; g < e->p.n_rg; ++g)
+        hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, vec_ok, g, (const uint32_t *)present);
     HIP_TRY(hipGetLastError());
     return KBBQ_OK;
 }

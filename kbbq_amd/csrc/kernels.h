@@ -688,9 +688,24 @@ __device__ __forceinline__ uint64_t cyc_index(const HistDev &H, int rg, int q, i
 // One lane per 16 consecutive bases of the batch (16-byte quality load, 4-byte base load), a block of
 // 1024 lanes per 16 Ki bases; the block's LDS table is flushed before any 16-bit counter could wrap
 // (a read adds at most 1 to a counter, so the block counts the reads it has touched).
+// One launch tallies the reads of ONE read group (lds_rg; its tables are the ones in LDS) and ignores the rest: a
+// batch with several read groups gets one launch per group that occurs in it (`present`, a bit per group from
+// k_rg_presence; a launch for an absent group returns at once).  Counting the other groups through global atomics
+// in the same launch serialises on a few hundred hot addresses -- 400 ms instead of 1 ms for four groups.
+__global__ void k_rg_presence(const uint16_t *rg, uint64_t n_reads, uint32_t n_rg, uint32_t *present) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_reads) {
+        const uint32_t g = rg[i] < n_rg ? rg[i] : 0;      // reads of an undeclared group are not tallied anyway
+        // most lanes of a wave carry the same few groups: one atomic per distinct group of the wave's first lanes
+        const uint32_t first = __shfl(g, 0);
+        if (g != first || (threadIdx.x & 63) == 0) atomicOr(&present[g >> 5], 1u << (g & 31));
+    }
+}
+
 __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uint32_t *err_bits, const uint32_t *patch,
-                                                 int ccap, int minscore, int vec_ok) {
+                                                 int ccap, int minscore, int vec_ok, int lds_rg, const uint32_t *present) {
     extern __shared__ uint32_t lds[];
+    if (present && !((present[lds_rg >> 5] >> (lds_rg & 31)) & 1)) return;
     // layout: cycle totals [2][94][ccap] u16 (packed, cycle slots permuted), dinuc totals [94][16] u32,
     // dinuc errors [94][16] u32 (few, hot addresses: global atomics on them serialise at the memory side),
     // reads-touched counter
@@ -703,7 +718,6 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
     const int lds_words = 2 * cyc_words + 2 * KBBQ_NQ * 16 + 1;
     for (int i = threadIdx.x; i < lds_words; i += blockDim.x) lds[i] = 0;
     __syncthreads();
-    const int lds_rg = R.rg ? (int)R.rg[0] : 0;
     const uint64_t n_groups = (R.n_bases + 15) / 16;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t iters = (n_groups + stride - 1) / stride;
@@ -814,8 +828,8 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
                     if ((pt >> 31) && (int)((pt >> 8) & 0xFFFF) == cyc) { b = (int)(pt & 3); nn = 0; }
                     const int q = qv[i];
                     const int er = (int)((ew >> i) & 1);
-                    if (rg < H.n_rg && cyc < H.n_cycle && q < KBBQ_NQ) {
-                        if (rg == lds_rg && cyc < ccap) {
+                    if (rg == lds_rg && rg < H.n_rg && cyc < H.n_cycle && q < KBBQ_NQ) {
+                        if (cyc < ccap) {
                             // lanes of one instruction are 16 cycles apart: store cycle c at slot
                             // (c%16)*(ccap/16) + c/16 so that they land in neighbouring words, not in two banks
                             const int slot = (cyc & 15) * (ccap >> 4) + (cyc >> 4);
@@ -828,13 +842,8 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
                         }
                         if (cyc >= 1 && q >= minscore && !nn && !prev_n) {
                             const int d = (prev_b << 2) | b;
-                            if (rg == lds_rg) {
-                                atomicAdd(&l_di[q * 16 + d], 1u);
-                                if (er) atomicAdd(&l_die[q * 16 + d], 1u);
-                            } else {
-                                atomicAdd(&H.dinuc[(((uint64_t)rg * KBBQ_NQ + q) * 16 + d) * 2 + 1], 1ULL);
-                                if (er) atomicAdd(&H.dinuc[(((uint64_t)rg * KBBQ_NQ + q) * 16 + d) * 2], 1ULL);
-                            }
+                            atomicAdd(&l_di[q * 16 + d], 1u);
+                            if (er) atomicAdd(&l_die[q * 16 + d], 1u);
                         }
                     }
                     prev_b = b;

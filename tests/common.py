@@ -103,6 +103,17 @@ def make_repeat_dataset(seed=77, genome_len=12000, coverage=30, read_len=100, n_
                 coverage=coverage)
 
 
+def make_sparse_rg_dataset(**kw):
+    """Five declared read groups of which one never occurs and one occurs in a single read."""
+    d = make_dataset(n_rg=5, **kw)
+    rg = d["rg"].copy()
+    rg[rg == 3] = 1
+    rg[rg == 4] = 0
+    rg[len(rg) // 2] = 4
+    d["rg"] = rg
+    return d
+
+
 # The seeded inputs of the GPU parity suite: name -> (dataset builder, dataset kwargs, run kwargs, engine kwargs).
 # tests/test_coverage_cpu.py proves on the CPU that together they reach every branch of get_errors.
 PARITY_CASES = {
@@ -127,6 +138,8 @@ PARITY_CASES = {
     # -c 60 -a 0.05) at oracle-friendly genome sizes
     "config0_1Mbp_20x": (make_dataset, dict(seed=2020, genome_len=1_000_000, coverage=20), dict(), dict(uniform=True, n_batches=2)),
     "config4_60x_k21": (make_dataset, dict(seed=6021, genome_len=40_000, coverage=60), dict(k=21, alpha=0.05), dict(uniform=True)),
+    "sparse_read_groups": (make_sparse_rg_dataset, dict(seed=55, genome_len=20000, coverage=20, paired=True, extra_errors=60), dict(n_rg=5),
+                           dict(uniform=True, n_batches=3)),
     "reads_400": (make_dataset, dict(seed=400, genome_len=20000, coverage=20, read_len=400, n_per_million=500,
                                      extra_errors=60), dict(), dict(uniform=True)),
 }
