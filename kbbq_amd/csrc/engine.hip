@@ -269,11 +269,14 @@ int kmer_prefix(kbbq_engine *e, const ReadsDev &R, const uint64_t **kofs, uint64
         *total = nk * R.n_reads;
         return KBBQ_OK;
     }
-    int rc = ensure_scratch(e, 1, (R.n_reads + 1) * 8);
+    const uint64_t n_tiles = (R.n_reads + SCAN_TILE - 1) / SCAN_TILE;
+    int rc = ensure_scratch(e, 1, (R.n_reads + 1 + n_tiles) * 8);
     if (rc) return rc;
-    uint64_t *d = (uint64_t *)e->scratch[1];
+    uint64_t *d = (uint64_t *)e->scratch[1], *tiles = d + R.n_reads + 1;
     hipLaunchKernelGGL(k_kmer_counts, dim3((unsigned)((R.n_reads + 255) / 256)), dim3(256), 0, e->stream, R, e->p.k, d);
-    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, e->stream, d, R.n_reads, (uint64_t *)&e->d_counters[2]);
+    hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)n_tiles), dim3(256), 0, e->stream, d, R.n_reads, tiles);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(1024), 0, e->stream, tiles, n_tiles, (uint64_t *)&e->d_counters[2]);
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)((R.n_reads + 255) / 256)), dim3(256), 0, e->stream, d, R.n_reads, (const uint64_t *)tiles);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(total, &e->d_counters[2], 8, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -844,6 +847,19 @@ static int launch_correct_wave(kbbq_engine *e, ReadsDev R, const uint32_t *list,
 }
 extern "C" {
 
+// coarse base -> read index of a ragged batch (kernels.h: k_read_index), in scratch slot `slot`; null for uniform batches
+static int build_read_index(kbbq_engine *e, const ReadsDev &R, int slot, hipStream_t stream, const uint32_t **index) {
+    *index = nullptr;
+    if (!R.offsets || !R.n_reads) return KBBQ_OK;
+    const size_t entries = R.n_bases / READ_INDEX_STEP + 2;
+    int rc = ensure_scratch(e, slot, entries * 4);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_read_index, dim3((unsigned)((R.n_reads + 255) / 256)), dim3(256), 0, stream, R.offsets, R.n_reads, (uint32_t *)e->scratch[slot]);
+    HIP_TRY(hipGetLastError());
+    *index = (const uint32_t *)e->scratch[slot];
+    return KBBQ_OK;
+}
+
 static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits, const uint32_t *patch, int max_len,
                      hipStream_t stream = nullptr) {
     if (!stream) stream = e->cur;
@@ -863,9 +879,12 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
     const uint64_t groups = (R.n_bases + 15) / 16;
     const int blocks = (int)std::min<uint64_t>((groups + 1023) / 1024, 256);
     const int vec_ok = ((uintptr_t)R.qual & 15) == 0;
+    const uint32_t *read_index;
+    int rc = build_read_index(e, R, stream == e->stream2 ? 15 : 14, stream, &read_index);
+    if (rc) return rc;
     if (!R.rg || e->p.n_rg == 1) {
         Timed t(e, "k_tally", stream);
-        hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, vec_ok, 0, (const uint32_t *)nullptr);
+        hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, vec_ok, 0, (const uint32_t *)nullptr, read_index);
         HIP_TRY(hipGetLastError());
         return KBBQ_OK;
     }
@@ -877,7 +896,7 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
     hipLaunchKernelGGL(k_rg_presence, dim3((unsigned)((R.n_reads + 255) / 256)), dim3(256), 0, stream, R.rg, R.n_reads, (uint32_t)e->p.n_rg, present);
     Timed t(e, "k_tally", stream);
     for (int g = 0; g < e->p.n_rg; ++g)
-        hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, vec_ok, g, (const uint32_t *)present);
+        hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, vec_ok, g, (const uint32_t *)present, read_index);
     HIP_TRY(hipGetLastError());
     return KBBQ_OK;
 }
@@ -1074,6 +1093,8 @@ static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qu
     DqDev D;
     D.base = e->d_dq_base; D.cycle = e->d_dq_cycle; D.dinuc = e->d_dq_dinuc;
     D.n_rg = e->p.n_rg; D.n_cycle = e->p.max_read_len;
+    const uint32_t *read_index;
+    if ((rc = build_read_index(e, R, 14, e->stream, &read_index))) return rc;
     {
         Timed t(e, "k_recalibrate");
         const uint64_t lanes = (R.n_bases + 15) / 16;
@@ -1082,7 +1103,7 @@ static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qu
         const int lds_rgs = std::max(0, std::min(D.n_rg, (64 * 1024) / per_rg));   // two 1024-lane blocks per CU share 160 KB
         const unsigned blocks = (unsigned)std::min<uint64_t>((lanes + 1023) / 1024, 256 * 2);
         hipLaunchKernelGGL(k_recalibrate, dim3(blocks), dim3(1024), (size_t)lds_rgs * per_rg, e->stream,
-                           R, D, d_out, 6, vec_ok, lds_rgs);
+                           R, D, d_out, 6, vec_ok, lds_rgs, read_index);
         HIP_TRY(hipGetLastError());
     }
     if (out_on_host) {

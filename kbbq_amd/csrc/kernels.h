@@ -90,14 +90,35 @@ __global__ void k_kmer_counts(ReadsDev R, int k, uint64_t *counts) {
     read_span(R, r, off, len);
     counts[r] = len >= (uint32_t)k ? len - k + 1 : 0;
 }
-// single-block exclusive scan, in place, `n` up to a few tens of millions (test/ragged path)
-__global__ void __launch_bounds__(1024) k_exclusive_scan(uint64_t *data, uint64_t n, uint64_t *total) {
+// Exclusive scan in three launches (ragged batches: every command-line batch has offsets): tiles of 2048 counts
+// are scanned in LDS and leave their total; one block scans the tile totals; the tile offsets are added back.
+constexpr int SCAN_TILE = 2048;
+__global__ void __launch_bounds__(256) k_scan_tiles(uint64_t *data, uint64_t n, uint64_t *tile_sums) {
+    __shared__ uint64_t wave_tot[4];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * 8;
+    uint64_t v[8], run = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = base + j < n ? data[base + j] : 0; const uint64_t x = v[j]; v[j] = run; run += x; }
+    // exclusive scan of the 256 thread totals: inside the wave by shuffles, across the four waves through LDS
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint64_t inc = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint64_t y = __shfl_up(inc, o); if (lane >= o) inc += y; }
+    if (lane == 63) wave_tot[w] = inc;
+    __syncthreads();
+    uint64_t before = inc - run;
+    for (int i = 0; i < w; ++i) before += wave_tot[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (base + j < n) data[base + j] = v[j] + before;
+    if (threadIdx.x == 255) tile_sums[blockIdx.x] = before + run;
+}
+__global__ void __launch_bounds__(1024) k_scan_tile_sums(uint64_t *tile_sums, uint64_t n_tiles, uint64_t *total) {
     __shared__ uint64_t part[1024];
     const int tid = threadIdx.x;
-    const uint64_t per = (n + 1023) / 1024;
-    const uint64_t b = min(n, per * tid), e = min(n, b + per);
+    const uint64_t per = (n_tiles + 1023) / 1024;
+    const uint64_t b = min(n_tiles, per * tid), e = min(n_tiles, b + per);
     uint64_t s = 0;
-    for (uint64_t i = b; i < e; ++i) s += data[i];
+    for (uint64_t i = b; i < e; ++i) s += tile_sums[i];
     part[tid] = s;
     __syncthreads();
     if (tid == 0) {
@@ -107,7 +128,37 @@ __global__ void __launch_bounds__(1024) k_exclusive_scan(uint64_t *data, uint64_
     }
     __syncthreads();
     uint64_t run = part[tid];
-    for (uint64_t i = b; i < e; ++i) { const uint64_t v = data[i]; data[i] = run; run += v; }
+    for (uint64_t i = b; i < e; ++i) { const uint64_t v = tile_sums[i]; tile_sums[i] = run; run += v; }
+}
+__global__ void __launch_bounds__(256) k_scan_add(uint64_t *data, uint64_t n, const uint64_t *tile_sums) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) data[i] += tile_sums[i / SCAN_TILE];
+}
+
+// Which read holds base m*1024 (ragged batches): entry m of a coarse index, so that the kernels that walk the
+// batch by base (tally, apply) start their search one load away from the answer instead of bisecting n_reads offsets.
+constexpr int READ_INDEX_STEP = 1024;
+__global__ void k_read_index(const uint64_t *offsets, uint64_t n_reads, uint32_t *index) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint64_t a = offsets[r], b = offsets[r + 1];
+    for (uint64_t m = (a + READ_INDEX_STEP - 1) / READ_INDEX_STEP; m * READ_INDEX_STEP < b; ++m) index[m] = (uint32_t)r;
+}
+// the read that contains base g0 (skipping empty reads), from the coarse index
+__device__ __forceinline__ void find_read(const ReadsDev &R, const uint32_t *index, uint64_t g0, uint64_t &r, uint64_t &start, uint64_t &end) {
+    if (index) {
+        r = index[g0 / READ_INDEX_STEP];
+    } else {
+        uint64_t lo = 0, hi = R.n_reads;   // last r with offsets[r] <= g0
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (R.offsets[mid] <= g0) lo = mid; else hi = mid;
+        }
+        r = lo;
+    }
+    start = R.offsets[r];
+    end = R.offsets[r + 1];
+    while (end <= g0) { ++r; start = end; end = R.offsets[r + 1]; }
 }
 
 __device__ __forceinline__ uint64_t kmer_base(const uint64_t *kofs, uint64_t r, uint32_t read_len, int k) {
@@ -703,7 +754,8 @@ __global__ void k_rg_presence(const uint16_t *rg, uint64_t n_reads, uint32_t n_r
 }
 
 __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uint32_t *err_bits, const uint32_t *patch,
-                                                 int ccap, int minscore, int vec_ok, int lds_rg, const uint32_t *present) {
+                                                 int ccap, int minscore, int vec_ok, int lds_rg, const uint32_t *present,
+                                                 const uint32_t *read_index) {
     extern __shared__ uint32_t lds[];
     if (present && !((present[lds_rg >> 5] >> (lds_rg & 31)) & 1)) return;
     // layout: cycle totals [2][94][ccap] u16 (packed, cycle slots permuted), dinuc totals [94][16] u32,
@@ -728,15 +780,7 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
         if (g0 < R.n_bases) {
             uint64_t r, start, end;
             if (R.offsets) {
-                uint64_t lo = 0, hi = R.n_reads;   // last r with offsets[r] <= g0
-                while (hi - lo > 1) {
-                    const uint64_t mid = (lo + hi) >> 1;
-                    if (R.offsets[mid] <= g0) lo = mid; else hi = mid;
-                }
-                r = lo;
-                start = R.offsets[r];
-                end = R.offsets[r + 1];
-                while (end <= g0) { ++r; start = end; end = R.offsets[r + 1]; }
+                find_read(R, read_index, g0, r, start, end);
             } else {
                 r = g0 / R.read_len;
                 start = r * R.read_len;
@@ -904,7 +948,8 @@ struct DqDev {
     int n_rg, n_cycle;
 };
 
-__global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8_t *out, int minqual, int vec_ok, int lds_rgs) {
+__global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8_t *out, int minqual, int vec_ok, int lds_rgs,
+                                                       const uint32_t *read_index) {
     // the delta-Q tables of the first `lds_rgs` read groups sit in LDS: per read group one int16 per
     // (q, second, cycle) holding meanq + rg + q delta-Q + cycle delta-Q already summed, and the int8
     // dinucleotide delta-Q -- two dependent LDS reads per base instead of three global ones
@@ -929,15 +974,7 @@ __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8
     // read containing g0
     uint64_t r, start, end;
     if (R.offsets) {
-        uint64_t lo = 0, hi = R.n_reads;   // last r with offsets[r] <= g0
-        while (hi - lo > 1) {
-            const uint64_t mid = (lo + hi) >> 1;
-            if (R.offsets[mid] <= g0) lo = mid; else hi = mid;
-        }
-        r = lo;
-        start = R.offsets[r];
-        end = R.offsets[r + 1];
-        while (end <= g0) { ++r; start = end; end = R.offsets[r + 1]; }   // skip empty reads
+        find_read(R, read_index, g0, r, start, end);
     } else {
         r = g0 / R.read_len;
         start = r * R.read_len;
