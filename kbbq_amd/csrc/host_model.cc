@@ -10,6 +10,7 @@
 #include <cstring>
 #include <limits>
 #include <mutex>
+#include <thread>
 
 namespace kbbq {
 
@@ -347,12 +348,31 @@ long double normal_log_prior(size_t j) {   // NormalPrior::get_normal_prior, cov
 inline long double q_to_p(int q) { return std::pow(10.0l, -((long double)q / 10.0l)); }   // recalibrateutils.hh:36
 inline int p_to_q(long double p) { return p > 0 ? (int)(-10 * std::log10(p)) : 42; }         // recalibrateutils.hh:37
 
-// the argmax shared by the four delta_q members (covariateutils.cc:44-63 etc.)
+// log(p) and log1p(-p) of the 94 candidate qualities: the same long double values binom_logpmf would compute for
+// every cell, computed once
+struct CandidateLogs {
+    long double logp[94], log1mp[94];
+    CandidateLogs() {
+        for (int c = 0; c <= 93; ++c) { const long double p = q_to_p(c); logp[c] = std::log(p); log1mp[c] = std::log1p(-p); }
+    }
+};
+const CandidateLogs &candidate_logs() {
+    static const CandidateLogs t;
+    return t;
+}
+
+// the argmax shared by the four delta_q members (covariateutils.cc:44-63 etc.): the binomial coefficient of
+// log_binom_pmf (covariateutils.hh:54-59) does not depend on the candidate and is taken out of the loop; every
+// term keeps the value and the order of additions it has in binom_logpmf
 int delta_for(unsigned long long err, unsigned long long tot, int prior) {
+    const CandidateLogs &L = candidate_logs();
+    const unsigned long long k = err + 1, n = tot + 2;
+    const double comb = ::lgamma((double)(n + 1)) - (::lgamma((double)(k + 1)) + ::lgamma((double)(n - k + 1)));
     int arg = 0;
     long double top = std::numeric_limits<long double>::lowest();
     for (int cand = 0; cand <= 93; ++cand) {
-        const long double score = normal_log_prior((size_t)std::abs(prior - cand)) + binom_logpmf(err + 1, tot + 2, q_to_p(cand));
+        const long double pmf = (long double)comb + (long double)k * L.logp[cand] + (long double)(n - k) * L.log1mp[cand];
+        const long double score = normal_log_prior((size_t)std::abs(prior - cand)) + pmf;
         if (score > top) { top = score; arg = cand; }
     }
     return arg - prior;
@@ -388,7 +408,9 @@ DqTables train_model(uint64_t n_rg, uint64_t n_cycle, const uint64_t *rg, const 
     d.qdq.assign(n_rg * kNQ, 0);
     d.cycledq.assign(n_rg * kNQ * 2 * n_cycle, 0);
     d.dinucdq.assign(n_rg * kNQ * 16, 0);
-    for (uint64_t r = 0; r < n_rg; ++r) {
+    normal_log_prior(1024);     // fill the memo before the threads read it
+    candidate_logs();
+    auto one_group = [&](uint64_t r) {
         const uint64_t *qr = q + r * kNQ * 2;
         int q_extent = 0;
         for (int i = 0; i < kNQ; ++i)
@@ -420,6 +442,16 @@ DqTables train_model(uint64_t n_rg, uint64_t n_cycle, const uint64_t *rg, const 
             for (int x = 0; x < 16; ++x)
                 d.dinucdq[cell0 + x] = delta_for(dinuc[(cell0 + x) * 2], dinuc[(cell0 + x) * 2 + 1], prior_q[i]);
         }
+    };
+    // read groups are independent (covariateutils.cc:204-230 loops over them): one thread each, up to 16 at a time
+    const uint64_t n_threads = std::min<uint64_t>(n_rg, 16);
+    if (n_threads <= 1) {
+        for (uint64_t r = 0; r < n_rg; ++r) one_group(r);
+    } else {
+        std::vector<std::thread> pool;
+        for (uint64_t t = 0; t < n_threads; ++t)
+            pool.emplace_back([&, t] { for (uint64_t r = t; r < n_rg; r += n_threads) one_group(r); });
+        for (auto &th : pool) th.join();
     }
     return d;
 }
