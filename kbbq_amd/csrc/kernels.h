@@ -747,9 +747,10 @@ __global__ void k_rg_presence(const uint16_t *rg, uint64_t n_reads, uint32_t n_r
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_reads) {
         const uint32_t g = rg[i] < n_rg ? rg[i] : 0;      // reads of an undeclared group are not tallied anyway
-        // most lanes of a wave carry the same few groups: one atomic per distinct group of the wave's first lanes
-        const uint32_t first = __shfl(g, 0);
-        if (g != first || (threadIdx.x & 63) == 0) atomicOr(&present[g >> 5], 1u << (g & 31));
+        // a few bits, millions of reads: look before the atomic (the words sit in cache), or every read of the
+        // batch queues up on the same address
+        const uint32_t bit = 1u << (g & 31);
+        if (!(__builtin_nontemporal_load(&present[g >> 5]) & bit)) atomicOr(&present[g >> 5], bit);
     }
 }
 
@@ -824,7 +825,11 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
             const bool plain = n == 16 && rg == lds_rg && rg2 == lds_rg && rg < H.n_rg &&
                                (bpos == 16 || (r + 1 < R.n_reads && end2 >= g0 + 16)) &&
                                c0 + bpos <= ccap && c0 + bpos <= H.n_cycle && 16 - bpos <= ccap && 16 - bpos <= H.n_cycle;
-            if (plain) {
+            // a group that lies in one read (or two) of other read groups has nothing for this launch
+            const bool foreign = n == 16 && rg != lds_rg && (bpos == 16 || (r + 1 < R.n_reads && end2 >= g0 + 16 && rg2 != lds_rg));
+            if (foreign) {
+                starts += bpos < 16 ? 1 : 0;
+            } else if (plain) {
                 const int pp1 = (pt >> 31) ? (int)((pt >> 8) & 0xFFFF) : -2, pp2 = (pt2 >> 31) ? (int)((pt2 >> 8) & 0xFFFF) : -2;
                 if (pp1 >= 0 && pp1 == c0 - 1) { prev_b = (int)(pt & 3); prev_n = 0; }
                 const int qa = second * KBBQ_NQ * ccap, qb = second2 * KBBQ_NQ * ccap;
