@@ -882,9 +882,13 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
     const uint32_t *read_index;
     int rc = build_read_index(e, R, stream == e->stream2 ? 15 : 14, stream, &read_index);
     if (rc) return rc;
+    // reads longer than the LDS tables' cycle capacity take one launch per window of ccap cycles
+    const int n_windows = (max_len + ccap - 1) / ccap;
     if (!R.rg || e->p.n_rg == 1) {
         Timed t(e, "k_tally", stream);
-        hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, vec_ok, 0, (const uint32_t *)nullptr, read_index);
+        for (int w = 0; w < n_windows; ++w)
+            hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, vec_ok, 0, (const uint32_t *)nullptr,
+                               read_index, w * ccap);
         HIP_TRY(hipGetLastError());
         return KBBQ_OK;
     }
@@ -896,7 +900,9 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
     hipLaunchKernelGGL(k_rg_presence, dim3((unsigned)((R.n_reads + 255) / 256)), dim3(256), 0, stream, R.rg, R.n_reads, (uint32_t)e->p.n_rg, present);
     Timed t(e, "k_tally", stream);
     for (int g = 0; g < e->p.n_rg; ++g)
-        hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, vec_ok, g, (const uint32_t *)present, read_index);
+        for (int w = 0; w < n_windows; ++w)
+            hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, vec_ok, g, (const uint32_t *)present,
+                               read_index, w * ccap);
     HIP_TRY(hipGetLastError());
     return KBBQ_OK;
 }
@@ -1100,9 +1106,18 @@ static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qu
         const uint64_t lanes = (R.n_bases + 15) / 16;
         const int vec_ok = (((uintptr_t)R.qual | (uintptr_t)d_out) & 15) == 0;
         const int per_rg = (2 * KBBQ_NQ * 2 * D.n_cycle + KBBQ_NQ * 16 + 3) & ~3;
-        const int lds_rgs = std::max(0, std::min(D.n_rg, (64 * 1024) / per_rg));   // two 1024-lane blocks per CU share 160 KB
-        const unsigned blocks = (unsigned)std::min<uint64_t>((lanes + 1023) / 1024, 256 * 2);
-        hipLaunchKernelGGL(k_recalibrate, dim3(blocks), dim3(1024), (size_t)lds_rgs * per_rg, e->stream,
+        // tables of as many read groups as fit: two 1024-lane blocks per CU share the 160 KB of LDS when one group
+        // takes at most 64 KB (reads up to 170 bases); longer reads get one block per CU and up to 152 KB
+        const int budget = per_rg <= 64 * 1024 ? 64 * 1024 : 152 * 1024;
+        const int lds_rgs = std::max(0, std::min(D.n_rg, budget / per_rg));
+        const size_t lds = (size_t)lds_rgs * per_rg;
+        static size_t attr_lds = 0;
+        if (lds > attr_lds) {
+            HIP_TRY(hipFuncSetAttribute((const void *)k_recalibrate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_lds = lds;
+        }
+        const unsigned blocks = (unsigned)std::min<uint64_t>((lanes + 1023) / 1024, lds > 76 * 1024 ? 256 : 256 * 2);
+        hipLaunchKernelGGL(k_recalibrate, dim3(blocks), dim3(1024), lds, e->stream,
                            R, D, d_out, 6, vec_ok, lds_rgs, read_index);
         HIP_TRY(hipGetLastError());
     }

@@ -739,7 +739,9 @@ __device__ __forceinline__ uint64_t cyc_index(const HistDev &H, int rg, int q, i
 // One lane per 16 consecutive bases of the batch (16-byte quality load, 4-byte base load), a block of
 // 1024 lanes per 16 Ki bases; the block's LDS table is flushed before any 16-bit counter could wrap
 // (a read adds at most 1 to a counter, so the block counts the reads it has touched).
-// One launch tallies the reads of ONE read group (lds_rg; its tables are the ones in LDS) and ignores the rest: a
+// One launch tallies the cycles [cbase, cbase + ccap) (reads longer than the LDS tables' 192 cycles take several
+// launches; cycles beyond the tables used to go through global atomics: 100 ms per launch for 250-base reads) of
+// the reads of ONE read group (lds_rg; its tables are the ones in LDS) and ignores the rest: a
 // batch with several read groups gets one launch per group that occurs in it (`present`, a bit per group from
 // k_rg_presence; a launch for an absent group returns at once).  Counting the other groups through global atomics
 // in the same launch serialises on a few hundred hot addresses -- 400 ms instead of 1 ms for four groups.
@@ -756,7 +758,7 @@ __global__ void k_rg_presence(const uint16_t *rg, uint64_t n_reads, uint32_t n_r
 
 __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uint32_t *err_bits, const uint32_t *patch,
                                                  int ccap, int minscore, int vec_ok, int lds_rg, const uint32_t *present,
-                                                 const uint32_t *read_index) {
+                                                 const uint32_t *read_index, int cbase) {
     extern __shared__ uint32_t lds[];
     if (present && !((present[lds_rg >> 5] >> (lds_rg & 31)) & 1)) return;
     // layout: cycle totals [2][94][ccap] u16 (packed, cycle slots permuted), dinuc totals [94][16] u32,
@@ -824,7 +826,7 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
             const int c0 = (int)(g0 - start);
             const bool plain = n == 16 && rg == lds_rg && rg2 == lds_rg && rg < H.n_rg &&
                                (bpos == 16 || (r + 1 < R.n_reads && end2 >= g0 + 16)) &&
-                               c0 + bpos <= ccap && c0 + bpos <= H.n_cycle && 16 - bpos <= ccap && 16 - bpos <= H.n_cycle;
+                               c0 + bpos <= H.n_cycle && 16 - bpos <= H.n_cycle;
             // a group that lies in one read (or two) of other read groups has nothing for this launch
             const bool foreign = n == 16 && rg != lds_rg && (bpos == 16 || (r + 1 < R.n_reads && end2 >= g0 + 16 && rg2 != lds_rg));
             if (foreign) {
@@ -842,8 +844,9 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
                     if (cyc == (in2 ? pp2 : pp1)) { b = (int)((in2 ? pt2 : pt) & 3); nn = 0; }
                     const int q = qv[i];
                     const uint32_t er = (ew >> i) & 1u;
-                    if (q < KBBQ_NQ) {
-                        const int slot = (cyc & 15) * (ccap >> 4) + (cyc >> 4);
+                    const int cr = cyc - cbase;      // inside this launch's cycle window?
+                    if (q < KBBQ_NQ && (unsigned)cr < (unsigned)ccap) {
+                        const int slot = (cr & 15) * (ccap >> 4) + (cr >> 4);
                         const int idx = (in2 ? qb : qa) + q * ccap + slot;
                         const uint32_t one = 1u << (16 * (idx & 1));
                         atomicAdd(&l_cyc[idx >> 1], one);
@@ -877,17 +880,15 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
                     if ((pt >> 31) && (int)((pt >> 8) & 0xFFFF) == cyc) { b = (int)(pt & 3); nn = 0; }
                     const int q = qv[i];
                     const int er = (int)((ew >> i) & 1);
-                    if (rg == lds_rg && rg < H.n_rg && cyc < H.n_cycle && q < KBBQ_NQ) {
-                        if (cyc < ccap) {
+                    const int cr = cyc - cbase;      // inside this launch's cycle window?
+                    if (rg == lds_rg && rg < H.n_rg && cyc < H.n_cycle && q < KBBQ_NQ && (unsigned)cr < (unsigned)ccap) {
+                        {
                             // lanes of one instruction are 16 cycles apart: store cycle c at slot
                             // (c%16)*(ccap/16) + c/16 so that they land in neighbouring words, not in two banks
-                            const int slot = (cyc & 15) * (ccap >> 4) + (cyc >> 4);
+                            const int slot = (cr & 15) * (ccap >> 4) + (cr >> 4);
                             const int idx = (second * KBBQ_NQ + q) * ccap + slot;
                             atomicAdd(&l_cyc[idx >> 1], 1u << (16 * (idx & 1)));
                             if (er) atomicAdd(&l_cye[idx >> 1], 1u << (16 * (idx & 1)));
-                        } else {
-                            atomicAdd(&H.cycle[cyc_index(H, rg, q, second, cyc) + 1], 1ULL);
-                            if (er) atomicAdd(&H.cycle[cyc_index(H, rg, q, second, cyc)], 1ULL);
                         }
                         if (cyc >= 1 && q >= minscore && !nn && !prev_n) {
                             const int d = (prev_b << 2) | b;
@@ -925,7 +926,7 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
                     const int idx = 2 * w + h;
                     const int slot = idx % ccap, rest = idx / ccap;
                     const int q = rest % KBBQ_NQ, s = rest / KBBQ_NQ;
-                    const int c = (slot % (ccap >> 4)) * 16 + slot / (ccap >> 4);
+                    const int c = cbase + (slot % (ccap >> 4)) * 16 + slot / (ccap >> 4);
                     if (c < H.n_cycle) {
                         atomicAdd(&H.cycle[cyc_index(H, lds_rg, q, s, c) + 1], (unsigned long long)cnt);
                         if (cne) atomicAdd(&H.cycle[cyc_index(H, lds_rg, q, s, c)], (unsigned long long)cne);
