@@ -82,6 +82,8 @@ struct kbbq_engine {
     bool side_busy[2] = {false, false};     // counters of that side not yet added to stats
     uint64_t side_reads[2] = {0, 0};
     int side_turn = 0;
+    uint8_t *d_dq_qslot = nullptr;      // apply kernel: quality -> LDS table slot (upload_dq)
+    int dq_slots = 0;
     uint32_t *d_rg_present[2] = {nullptr, nullptr};     // which read groups a batch contains (run_tally), per stream
     hipStream_t cur = nullptr;              // stream and counter pair the pass-3 launch helpers use
     unsigned long long *cur_cnt = nullptr;
@@ -296,6 +298,22 @@ int upload_dq(kbbq_engine *e) {
     HIP_TRY(hipMemcpyAsync(e->d_dq_base, base.data(), nb * 2, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->d_dq_cycle, cyc.data(), nc, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->d_dq_dinuc, di.data(), nd, hipMemcpyHostToDevice, e->stream));
+    // quality values that carry a cycle or dinucleotide delta in some read group get a slot in the apply
+    // kernel's LDS tables; the others only need their base value
+    uint8_t slot[96];
+    memset(slot, 255, sizeof slot);
+    int n_slots = 0;
+    for (int q = 0; q < kNQ; ++q) {
+        bool any = false;
+        for (uint64_t r = 0; r < d.n_rg && !any; ++r) {
+            const size_t c0 = (r * kNQ + q) * 2 * d.n_cycle, d0 = (r * kNQ + q) * 16;
+            for (size_t i = 0; i < 2 * d.n_cycle && !any; ++i) any = cyc[c0 + i] != 0;
+            for (size_t i = 0; i < 16 && !any; ++i) any = di[d0 + i] != 0;
+        }
+        if (any) slot[q] = (uint8_t)n_slots++;
+    }
+    e->dq_slots = n_slots;
+    HIP_TRY(hipMemcpyAsync(e->d_dq_qslot, slot, 96, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->dq_set = true;
     return KBBQ_OK;
@@ -353,6 +371,7 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
     CREATE_TRY(hipMalloc(&e->d_counters, 64));
     CREATE_TRY(hipMemset(e->d_counters, 0, 64));
     e->cur_cnt = e->d_counters;
+    CREATE_TRY(hipMalloc(&e->d_dq_qslot, 96));
     for (int i = 0; i < 2; ++i) CREATE_TRY(hipMalloc(&e->d_rg_present[i], (((size_t)params->n_rg + 31) / 32) * 4 + 4));
     for (int w = 0; w < 2; ++w) {
         FilterHost &f = e->filt[w];
@@ -399,6 +418,7 @@ void kbbq_engine_destroy(kbbq_engine *e) {
     hipFree(e->d_dq_cycle);
     hipFree(e->d_dq_dinuc);
     hipFree(e->d_counters);
+    hipFree(e->d_dq_qslot);
     hipFree(e->d_rg_present[0]);
     hipFree(e->d_rg_present[1]);
     hipFree(e->d_qcum);
@@ -1098,19 +1118,20 @@ static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qu
     }
     DqDev D;
     D.base = e->d_dq_base; D.cycle = e->d_dq_cycle; D.dinuc = e->d_dq_dinuc;
-    D.n_rg = e->p.n_rg; D.n_cycle = e->p.max_read_len;
+    D.qslot = e->d_dq_qslot;
+    D.n_rg = e->p.n_rg; D.n_cycle = e->p.max_read_len; D.n_slots = e->dq_slots;
     const uint32_t *read_index;
     if ((rc = build_read_index(e, R, 14, e->stream, &read_index))) return rc;
     {
         Timed t(e, "k_recalibrate");
         const uint64_t lanes = (R.n_bases + 15) / 16;
         const int vec_ok = (((uintptr_t)R.qual | (uintptr_t)d_out) & 15) == 0;
-        const int per_rg = (2 * KBBQ_NQ * 2 * D.n_cycle + KBBQ_NQ * 16 + 3) & ~3;
-        // tables of as many read groups as fit: two 1024-lane blocks per CU share the 160 KB of LDS when one group
-        // takes at most 64 KB (reads up to 170 bases); longer reads get one block per CU and up to 152 KB
-        const int budget = per_rg <= 64 * 1024 ? 64 * 1024 : 152 * 1024;
+        const int per_rg = (D.n_slots * (4 * D.n_cycle + 16) + KBBQ_NQ * 2 + 3) & ~3;
+        // tables of as many read groups as fit (kernels.h: compacted over the quality axis): two 1024-lane blocks
+        // per CU share the 160 KB of LDS when one group takes at most 64 KB; otherwise one block per CU and up to 152 KB
+        const int budget = per_rg + 96 <= 64 * 1024 ? 64 * 1024 - 96 : 152 * 1024 - 96;
         const int lds_rgs = std::max(0, std::min(D.n_rg, budget / per_rg));
-        const size_t lds = (size_t)lds_rgs * per_rg;
+        const size_t lds = 96 + (size_t)lds_rgs * per_rg;
         static size_t attr_lds = 0;
         if (lds > attr_lds) {
             HIP_TRY(hipFuncSetAttribute((const void *)k_recalibrate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -951,26 +951,35 @@ struct DqDev {
     const int16_t *base;   // [n_rg][94]  meanq + rgdq + qscoredq
     const int8_t *cycle;   // [n_rg][94][2][n_cycle]
     const int8_t *dinuc;   // [n_rg][94][16]
-    int n_rg, n_cycle;
+    const uint8_t *qslot;  // [94] slot of a quality in the LDS tables (255 = it has no cycle / dinucleotide delta anywhere)
+    int n_rg, n_cycle, n_slots;
 };
 
 __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8_t *out, int minqual, int vec_ok, int lds_rgs,
                                                        const uint32_t *read_index) {
-    // the delta-Q tables of the first `lds_rgs` read groups sit in LDS: per read group one int16 per
-    // (q, second, cycle) holding meanq + rg + q delta-Q + cycle delta-Q already summed, and the int8
-    // dinucleotide delta-Q -- two dependent LDS reads per base instead of three global ones
+    // The delta-Q tables of the first `lds_rgs` read groups sit in LDS, compacted over the quality axis: only the
+    // D.n_slots quality values that have a non-zero cycle or dinucleotide delta anywhere get a slot (D.qslot; a
+    // handful for binned qualities, so a dozen read groups fit), holding per (slot, second, cycle) one int16 with
+    // meanq + rg + q delta-Q + cycle delta-Q already summed and the int8 dinucleotide delta-Q; every other
+    // quality only needs its base value.  Two or three dependent LDS reads per base instead of three global ones.
     extern __shared__ uint8_t l_tab[];
-    const int cyc_cells = KBBQ_NQ * 2 * D.n_cycle, di_bytes = KBBQ_NQ * 16;
+    uint8_t *l_qslot = l_tab;                                   // [96]: slot of a quality, 255 = none
+    const int ns = D.n_slots;
+    const int cyc_cells = ns * 2 * D.n_cycle, di_bytes = ns * 16, base_bytes = KBBQ_NQ * 2;
     const int cyc_bytes = 2 * cyc_cells;
-    const int per_rg = (cyc_bytes + di_bytes + 3) & ~3;
-    for (int i = threadIdx.x; i < lds_rgs * (cyc_cells + di_bytes); i += blockDim.x) {
-        const int rg = i / (cyc_cells + di_bytes), o = i % (cyc_cells + di_bytes);
-        if (o < cyc_cells) {
-            const int q = o / (2 * D.n_cycle);
-            reinterpret_cast<int16_t *>(l_tab + (size_t)rg * per_rg)[o] =
-                (int16_t)(D.base[rg * KBBQ_NQ + q] + D.cycle[(size_t)rg * cyc_cells + o]);
-        } else {
-            l_tab[(size_t)rg * per_rg + cyc_bytes + (o - cyc_cells)] = (uint8_t)D.dinuc[(size_t)rg * di_bytes + (o - cyc_cells)];
+    const int per_rg = (cyc_bytes + di_bytes + base_bytes + 3) & ~3;
+    uint8_t *l_rg = l_tab + 96;
+    if (threadIdx.x < 96) l_qslot[threadIdx.x] = threadIdx.x < KBBQ_NQ ? D.qslot[threadIdx.x] : 255;
+    __syncthreads();
+    for (int i = threadIdx.x; i < lds_rgs * KBBQ_NQ; i += blockDim.x) {
+        const int rg = i / KBBQ_NQ, q = i % KBBQ_NQ;
+        reinterpret_cast<int16_t *>(l_rg + (size_t)rg * per_rg + cyc_bytes + di_bytes)[q] = D.base[rg * KBBQ_NQ + q];
+        const int sl = l_qslot[q];
+        if (sl != 255) {
+            int16_t *tc = reinterpret_cast<int16_t *>(l_rg + (size_t)rg * per_rg) + sl * 2 * D.n_cycle;
+            const int8_t *src = D.cycle + ((size_t)rg * KBBQ_NQ + q) * 2 * D.n_cycle;
+            for (int c = 0; c < 2 * D.n_cycle; ++c) tc[c] = (int16_t)(D.base[rg * KBBQ_NQ + q] + src[c]);
+            for (int x = 0; x < 16; ++x) l_rg[(size_t)rg * per_rg + cyc_bytes + sl * 16 + x] = (uint8_t)D.dinuc[((size_t)rg * KBBQ_NQ + q) * 16 + x];
         }
     }
     __syncthreads();
@@ -1021,10 +1030,12 @@ __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8
     const bool plain = n == 16 && rg < lds_rgs && rg2 < lds_rgs && (bpos == 16 || (r + 1 < R.n_reads && end2 >= g0 + 16)) &&
                        c0 + bpos <= D.n_cycle && 16 - bpos <= D.n_cycle;
     if (plain) {
-        const int16_t *ta = reinterpret_cast<const int16_t *>(l_tab + rg * per_rg) + second * D.n_cycle + c0;
-        const int16_t *tb = reinterpret_cast<const int16_t *>(l_tab + rg2 * per_rg) + second2 * D.n_cycle - bpos;
-        const int8_t *da = reinterpret_cast<const int8_t *>(l_tab + rg * per_rg + cyc_bytes);
-        const int8_t *db = reinterpret_cast<const int8_t *>(l_tab + rg2 * per_rg + cyc_bytes);
+        const int16_t *ta = reinterpret_cast<const int16_t *>(l_rg + rg * per_rg) + second * D.n_cycle + c0;
+        const int16_t *tb = reinterpret_cast<const int16_t *>(l_rg + rg2 * per_rg) + second2 * D.n_cycle - bpos;
+        const int8_t *da = reinterpret_cast<const int8_t *>(l_rg + rg * per_rg + cyc_bytes);
+        const int8_t *db = reinterpret_cast<const int8_t *>(l_rg + rg2 * per_rg + cyc_bytes);
+        const int16_t *ba = reinterpret_cast<const int16_t *>(l_rg + rg * per_rg + cyc_bytes + di_bytes);
+        const int16_t *bb = reinterpret_cast<const int16_t *>(l_rg + rg2 * per_rg + cyc_bytes + di_bytes);
         const int qstride = 2 * D.n_cycle;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -1033,9 +1044,14 @@ __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8
             const int q = qv[i];
             int v = q;
             if (q >= minqual && q < KBBQ_NQ) {
-                v = (in2 ? tb : ta)[q * qstride + i];
-                const bool first = in2 ? i == bpos : c0 + i == 0;        // cycle 0 has no dinucleotide context
-                if (!first && !(nn | prev_n)) v += (in2 ? db : da)[q * 16 + ((prev_b << 2) | b)];
+                const int sl = l_qslot[q];
+                if (sl != 255) {
+                    v = (in2 ? tb : ta)[sl * qstride + i];
+                    const bool first = in2 ? i == bpos : c0 + i == 0;        // cycle 0 has no dinucleotide context
+                    if (!first && !(nn | prev_n)) v += (in2 ? db : da)[sl * 16 + ((prev_b << 2) | b)];
+                } else {
+                    v = (in2 ? bb : ba)[q];      // no cycle or dinucleotide delta anywhere for this quality
+                }
             }
             res[i] = (uint8_t)(v < 0 ? 0 : (v > KBBQ_MAXQ ? KBBQ_MAXQ : v));
             prev_b = b;
@@ -1061,9 +1077,14 @@ __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8
             const int cell = rg * KBBQ_NQ + q;
             const bool use_di = cyc > 0 && !nn && !prev_n;
             if (rg < lds_rgs) {
-                const uint8_t *t = l_tab + rg * per_rg;
-                v = reinterpret_cast<const int16_t *>(t)[(q * 2 + second) * D.n_cycle + cyc];
-                if (use_di) v += (int8_t)t[cyc_bytes + q * 16 + ((prev_b << 2) | b)];
+                const uint8_t *t = l_rg + rg * per_rg;
+                const int sl = l_qslot[q];
+                if (sl != 255) {
+                    v = reinterpret_cast<const int16_t *>(t)[(sl * 2 + second) * D.n_cycle + cyc];
+                    if (use_di) v += (int8_t)t[cyc_bytes + sl * 16 + ((prev_b << 2) | b)];
+                } else {
+                    v = reinterpret_cast<const int16_t *>(t + cyc_bytes + di_bytes)[q];
+                }
             } else {
                 v = D.base[cell] + D.cycle[((uint64_t)cell * 2 + second) * D.n_cycle + cyc];
                 if (use_di) v += D.dinuc[cell * 16 + ((prev_b << 2) | b)];
