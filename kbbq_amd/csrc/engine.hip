@@ -82,6 +82,8 @@ struct kbbq_engine {
     bool side_busy[2] = {false, false};     // counters of that side not yet added to stats
     uint64_t side_reads[2] = {0, 0};
     int side_turn = 0;
+    uint32_t *d_qpresent = nullptr;     // quality values seen by pass 2 (3 words of bits), read at kbbq_trusted_finish
+    TallyPlan tally_plan;               // quality -> LDS table slot of the tally (identity until pass 2 has spoken)
     uint8_t *d_dq_qslot = nullptr;      // apply kernel: quality -> LDS table slot (upload_dq)
     int dq_slots = 0;
     uint32_t *d_rg_present[2] = {nullptr, nullptr};     // which read groups a batch contains (run_tally), per stream
@@ -129,6 +131,17 @@ int ensure_scratch(kbbq_engine *e, int idx, size_t bytes) {
     HIP_TRY(hipMalloc(&e->scratch[idx], want));
     e->scratch_bytes[idx] = want;
     return KBBQ_OK;
+}
+
+// quality -> slot map of the tally from the presence bits of pass 2; no bits (pass 3 used on its own) = every quality its own slot
+static void plan_tally_slots(TallyPlan &P, const uint32_t mask[3]) {
+    memset(P.qslot, 255, sizeof P.qslot);
+    memset(P.qof, 0, sizeof P.qof);
+    P.n_slots = 0;
+    const bool none = !(mask[0] | mask[1] | mask[2]);
+    for (int q = 0; q < KBBQ_NQ; ++q)
+        if (none || ((mask[q >> 5] >> (q & 31)) & 1)) { P.qof[P.n_slots] = (uint8_t)q; P.qslot[q] = (uint8_t)P.n_slots++; }
+    P.rg_base = 0; P.n_rgs = 1; P.cbase = 0;
 }
 
 struct Timed {
@@ -372,6 +385,7 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
     CREATE_TRY(hipMemset(e->d_counters, 0, 64));
     e->cur_cnt = e->d_counters;
     CREATE_TRY(hipMalloc(&e->d_dq_qslot, 96));
+    CREATE_TRY(hipMalloc(&e->d_qpresent, 16));
     for (int i = 0; i < 2; ++i) CREATE_TRY(hipMalloc(&e->d_rg_present[i], (((size_t)params->n_rg + 31) / 32) * 4 + 4));
     for (int w = 0; w < 2; ++w) {
         FilterHost &f = e->filt[w];
@@ -419,6 +433,7 @@ void kbbq_engine_destroy(kbbq_engine *e) {
     hipFree(e->d_dq_dinuc);
     hipFree(e->d_counters);
     hipFree(e->d_dq_qslot);
+    hipFree(e->d_qpresent);
     hipFree(e->d_rg_present[0]);
     hipFree(e->d_rg_present[1]);
     hipFree(e->d_qcum);
@@ -441,6 +456,11 @@ int kbbq_engine_reset(kbbq_engine *e) {
     }
     HIP_TRY(hipMemsetAsync(e->d_hist, 0, (e->hist_cycle_words + e->hist_dinuc_words) * 8, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_counters, 0, 64, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_qpresent, 0, 16, e->stream));
+    {
+        const uint32_t none[3] = {0, 0, 0};
+        plan_tally_slots(e->tally_plan, none);
+    }
     e->thresholds_set = false;
     e->dq_set = false;
     memset(e->stats, 0, sizeof e->stats);
@@ -753,7 +773,7 @@ template <int NW> struct LaunchTrusted {
         {
             Timed t(e, "k_infer");
             hipLaunchKernelGGL(k_infer<NW>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
-                               e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out);
+                               e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent);
             HIP_TRY(hipGetLastError());
         }
         {
@@ -813,6 +833,11 @@ int kbbq_trusted_finish(kbbq_engine *e, uint64_t *inserted) {
     if (!e) return fail(KBBQ_EINVAL, "null engine");
     int rc = sync_engine(e);
     if (rc) return rc;
+    {
+        uint32_t mask[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpy(mask, e->d_qpresent, 16, hipMemcpyDeviceToHost));
+        plan_tally_slots(e->tally_plan, mask);
+    }
     if (inserted) HIP_TRY(hipMemcpy(inserted, e->filt[1].d_inserted, 8, hipMemcpyDeviceToHost));
     return KBBQ_OK;
 }
@@ -888,41 +913,52 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
     H.dinuc = e->d_hist + e->hist_cycle_words;
     H.n_rg = e->p.n_rg;
     H.n_cycle = e->p.max_read_len;
-    int ccap = std::min(((max_len + 31) / 32) * 32, 192);   // LDS: 2 tables x 2 x 94 x ccap x 2 B <= 141 KB
-    const size_t lds = (2 * ((size_t)(2 * ccap * KBBQ_NQ + 1) / 2) + 2 * KBBQ_NQ * 16 + 1) * 4;
+    // LDS tables: ccap cycles x the quality values pass 2 saw x as many read groups as fit (one launch per set of
+    // read groups and per window of ccap cycles; a launch whose read groups do not occur in the batch returns at once)
+    TallyPlan P = e->tally_plan;
+    const int n_rg = R.rg ? e->p.n_rg : 1;
+    const bool compact = n_rg > 1;      // one read group: full-width tables fit and save the slot lookup
+    if (!compact) {
+        const uint32_t none[3] = {0, 0, 0};
+        plan_tally_slots(P, none);
+    }
+    const int ccap = std::min(((max_len + 31) / 32) * 32, 192);
+    const size_t cyc_words = ((size_t)2 * ccap * P.n_slots + 1) / 2;
+    const size_t per_rg = (2 * cyc_words + 2 * (size_t)P.n_slots * 16) * 4;
+    // (half of the LDS if everything fits in it: two blocks per CU)
+    const size_t budget = (size_t)n_rg * per_rg <= 70 * 1024 ? 70 * 1024 : 140 * 1024;
+    const int per_launch = compact ? (int)std::max<size_t>(1, std::min<size_t>((size_t)n_rg, budget / per_rg)) : 1;
+    const size_t lds = (size_t)per_launch * per_rg + 4 + 96 + 4;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
-        HIP_TRY(hipFuncSetAttribute((const void *)k_tally, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_tally<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_tally<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
-    // 16 wavefronts share one LDS table: one 1024-lane block per CU at 150-base reads
+    // 16 wavefronts share one set of LDS tables: one 1024-lane block per CU, two when the tables leave room
     const uint64_t groups = (R.n_bases + 15) / 16;
-    const int blocks = (int)std::min<uint64_t>((groups + 1023) / 1024, 256);
+    const int blocks = (int)std::min<uint64_t>((groups + 1023) / 1024, lds <= 76 * 1024 ? 512 : 256);
     const int vec_ok = ((uintptr_t)R.qual & 15) == 0;
     const uint32_t *read_index;
     int rc = build_read_index(e, R, stream == e->stream2 ? 15 : 14, stream, &read_index);
     if (rc) return rc;
-    // reads longer than the LDS tables' cycle capacity take one launch per window of ccap cycles
-    const int n_windows = (max_len + ccap - 1) / ccap;
-    if (!R.rg || e->p.n_rg == 1) {
-        Timed t(e, "k_tally", stream);
-        for (int w = 0; w < n_windows; ++w)
-            hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, vec_ok, 0, (const uint32_t *)nullptr,
-                               read_index, w * ccap);
-        HIP_TRY(hipGetLastError());
-        return KBBQ_OK;
+    const uint32_t *present = nullptr;
+    if (n_rg > per_launch) {     // several launches: mark the read groups that occur, so that the others cost nothing
+        uint32_t *pr = e->d_rg_present[stream == e->stream2 ? 1 : 0];
+        HIP_TRY(hipMemsetAsync(pr, 0, (((size_t)e->p.n_rg + 31) / 32) * 4, stream));
+        hipLaunchKernelGGL(k_rg_presence, dim3((unsigned)((R.n_reads + 255) / 256)), dim3(256), 0, stream, R.rg, R.n_reads, (uint32_t)e->p.n_rg, pr);
+        present = pr;
     }
-    // several read groups: which of them occur in this batch (bitmap on the device), then one launch per group;
-    // launches for absent groups return immediately
-    uint32_t *present = e->d_rg_present[stream == e->stream2 ? 1 : 0];
-    const size_t words = ((size_t)e->p.n_rg + 31) / 32;
-    HIP_TRY(hipMemsetAsync(present, 0, words * 4, stream));
-    hipLaunchKernelGGL(k_rg_presence, dim3((unsigned)((R.n_reads + 255) / 256)), dim3(256), 0, stream, R.rg, R.n_reads, (uint32_t)e->p.n_rg, present);
+    const int n_windows = (max_len + ccap - 1) / ccap;
     Timed t(e, "k_tally", stream);
-    for (int g = 0; g < e->p.n_rg; ++g)
-        for (int w = 0; w < n_windows; ++w)
-            hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, vec_ok, g, (const uint32_t *)present,
-                               read_index, w * ccap);
+    for (int g = 0; g < n_rg; g += per_launch)
+        for (int w = 0; w < n_windows; ++w) {
+            P.rg_base = g;
+            P.n_rgs = std::min(per_launch, n_rg - g);
+            P.cbase = w * ccap;
+            if (compact) hipLaunchKernelGGL(k_tally<true>, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, vec_ok, P, present, read_index);
+            else hipLaunchKernelGGL(k_tally<false>, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, vec_ok, P, present, read_index);
+        }
     HIP_TRY(hipGetLastError());
     return KBBQ_OK;
 }

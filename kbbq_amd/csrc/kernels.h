@@ -250,7 +250,7 @@ struct Thresholds { int v[KBBQ_MAX_KMER + 1]; };
 
 template <int NW>
 __global__ void __launch_bounds__(256) k_infer(ReadsDev R, KParams K, FiltDev S, Thresholds thr, uint32_t *take_bits,
-                                                unsigned long long *inserted, uint32_t *err_out) {
+                                                unsigned long long *inserted, uint32_t *err_out, uint32_t *qpresent) {
     using St = Stage<NW>;
     __shared__ uint32_t lds[4][St::LDS_U32];
     __shared__ int thr_lds[KBBQ_MAX_KMER + 1];
@@ -296,7 +296,13 @@ __global__ void __launch_bounds__(256) k_infer(ReadsDev R, KParams K, FiltDev S,
             p[c] = make_ulonglong2(0, 0);
             q[c] = 0;
             const int s = c * 64 + lane;
-            if (c * 64 < Lr && s < Lr) q[c] = R.qual[cur + s];
+            if (c * 64 < Lr && s < Lr) {
+                q[c] = R.qual[cur + s];
+                // which quality values occur at all (the tally of pass 3 sizes its LDS tables by them): a handful of
+                // bits, looked at before the atomic
+                const uint32_t bit = 1u << (q[c] & 31);
+                if (q[c] < 96 && !(qpresent[q[c] >> 5] & bit)) atomicOr(&qpresent[q[c] >> 5], bit);
+            }
             if (c * 64 < nk && s < nk) {
                 const uint64_t key = canon_key(lds_window64(L32 + 2 * St::B, 2 * (o31 + s)), K);
                 valid[c] = (lds_window32(L32 + 2 * St::M, o63 + s) & K.nmask_bits) == 0;
@@ -752,27 +758,67 @@ __global__ void k_rg_presence(const uint16_t *rg, uint64_t n_reads, uint32_t n_r
         // a few bits, millions of reads: look before the atomic (the words sit in cache), or every read of the
         // batch queues up on the same address
         const uint32_t bit = 1u << (g & 31);
-        if (!(__builtin_nontemporal_load(&present[g >> 5]) & bit)) atomicOr(&present[g >> 5], bit);
+        if (!(present[g >> 5] & bit)) atomicOr(&present[g >> 5], bit);
     }
 }
 
+struct TallyPlan {
+    uint8_t qslot[96];     // slot of a quality value in the LDS tables, 255 = none (counted through global atomics)
+    uint8_t qof[96];       // quality value of a slot
+    int n_slots;           // slots in use
+    int rg_base, n_rgs;    // this launch tallies the read groups [rg_base, rg_base + n_rgs)
+    int cbase;             // ... and the cycles [cbase, cbase + ccap)
+};
+
+// COMPACT = false: every quality value is its own slot (one read group per launch fits then): no slot lookup.
+template <bool COMPACT>
 __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uint32_t *err_bits, const uint32_t *patch,
-                                                 int ccap, int minscore, int vec_ok, int lds_rg, const uint32_t *present,
-                                                 const uint32_t *read_index, int cbase) {
+                                                 int ccap, int minscore, int vec_ok, TallyPlan P, const uint32_t *present,
+                                                 const uint32_t *read_index) {
     extern __shared__ uint32_t lds[];
-    if (present && !((present[lds_rg >> 5] >> (lds_rg & 31)) & 1)) return;
-    // layout: cycle totals [2][94][ccap] u16 (packed, cycle slots permuted), dinuc totals [94][16] u32,
-    // dinuc errors [94][16] u32 (few, hot addresses: global atomics on them serialise at the memory side),
-    // reads-touched counter
-    const int cyc_words = (2 * ccap * KBBQ_NQ + 1) / 2;
-    uint32_t *l_cyc = lds;
-    uint32_t *l_cye = lds + cyc_words;          // cycle error counts, same layout as the totals
-    uint32_t *l_di = l_cye + cyc_words;
-    uint32_t *l_die = l_di + KBBQ_NQ * 16;
-    uint32_t *l_reads = l_die + KBBQ_NQ * 16;
-    const int lds_words = 2 * cyc_words + 2 * KBBQ_NQ * 16 + 1;
+    const int ns = P.n_slots, cbase = P.cbase;
+    if (present) {      // none of this launch's read groups occurs in the batch
+        bool any = false;
+        for (int g = P.rg_base; g < P.rg_base + P.n_rgs; ++g) any = any || ((present[g >> 5] >> (g & 31)) & 1);
+        if (!any) return;
+    }
+    // layout per read group: cycle totals [2][ns][ccap] u16 (packed, cycle slots permuted), cycle errors likewise,
+    // dinuc totals [ns][16] u32, dinuc errors [ns][16] u32 (few, hot addresses: global atomics on them serialise
+    // at the memory side); then the quality -> slot map and the reads-touched counter
+    const int cyc_words = (2 * ccap * ns + 1) / 2;
+    const int per_rg = 2 * cyc_words + 2 * ns * 16;
+    uint32_t *l_reads = lds + P.n_rgs * per_rg;
+    uint8_t *l_qslot = reinterpret_cast<uint8_t *>(l_reads + 1);
+    const int lds_words = P.n_rgs * per_rg + 1;
     for (int i = threadIdx.x; i < lds_words; i += blockDim.x) lds[i] = 0;
+    if (threadIdx.x < 96) l_qslot[threadIdx.x] = P.qslot[threadIdx.x];
     __syncthreads();
+    // one base: cycle and dinucleotide counters of (read group slot lr, quality q, second, cycle cyc)
+    auto count = [&](int lr, int rg, int q, int second, int cyc, int er, bool dinuc_ok, int d) {
+        const int cr = cyc - cbase;      // inside this launch's cycle window?
+        if ((unsigned)cr >= (unsigned)ccap) return;
+        const int sl = COMPACT ? (int)l_qslot[q] : q;
+        if (!COMPACT || sl != 255) {
+            uint32_t *t = lds + lr * per_rg;
+            // lanes of one instruction are 16 cycles apart: store cycle c at slot (c%16)*(ccap/16) + c/16 so that
+            // they land in neighbouring words, not in two banks
+            const int idx = (second * ns + sl) * ccap + (cr & 15) * (ccap >> 4) + (cr >> 4);
+            const uint32_t one = 1u << (16 * (idx & 1));
+            atomicAdd(&t[idx >> 1], one);
+            if (er) atomicAdd(&t[cyc_words + (idx >> 1)], one);
+            if (dinuc_ok) {
+                atomicAdd(&t[2 * cyc_words + sl * 16 + d], 1u);
+                if (er) atomicAdd(&t[2 * cyc_words + ns * 16 + sl * 16 + d], 1u);
+            }
+        } else {      // a quality value pass 2 did not announce: straight to the histograms
+            atomicAdd(&H.cycle[cyc_index(H, rg, q, second, cyc) + 1], 1ULL);
+            if (er) atomicAdd(&H.cycle[cyc_index(H, rg, q, second, cyc)], 1ULL);
+            if (dinuc_ok) {
+                atomicAdd(&H.dinuc[(((uint64_t)rg * KBBQ_NQ + q) * 16 + d) * 2 + 1], 1ULL);
+                if (er) atomicAdd(&H.dinuc[(((uint64_t)rg * KBBQ_NQ + q) * 16 + d) * 2], 1ULL);
+            }
+        }
+    };
     const uint64_t n_groups = (R.n_bases + 15) / 16;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t iters = (n_groups + stride - 1) / stride;
@@ -812,7 +858,7 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
             starts = g0 == start ? 1 : 0;
             // Same shape as the apply kernel: a group lies in one read or straddles one boundary, and which read a
             // base belongs to is a select on its index (also for the read's patch, if it has one).  Anything else
-            // -- a second boundary, a read group other than the one whose tables are in LDS -- takes the general loop.
+            // -- a second boundary inside the group, the batch's last group -- takes the general loop.
             const int bpos = end - g0 < 16 ? (int)(end - g0) : 16;
             int rg2 = rg, second2 = second;
             uint32_t pt2 = 0;
@@ -824,17 +870,17 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
                 end2 = R.offsets ? R.offsets[r + 2] : end + R.read_len;
             }
             const int c0 = (int)(g0 - start);
-            const bool plain = n == 16 && rg == lds_rg && rg2 == lds_rg && rg < H.n_rg &&
-                               (bpos == 16 || (r + 1 < R.n_reads && end2 >= g0 + 16)) &&
-                               c0 + bpos <= H.n_cycle && 16 - bpos <= H.n_cycle;
-            // a group that lies in one read (or two) of other read groups has nothing for this launch
-            const bool foreign = n == 16 && rg != lds_rg && (bpos == 16 || (r + 1 < R.n_reads && end2 >= g0 + 16 && rg2 != lds_rg));
-            if (foreign) {
-                starts += bpos < 16 ? 1 : 0;
-            } else if (plain) {
+            // read groups of this launch are [rg_base, rg_base + n_rgs); everything else belongs to another launch
+            // (not COMPACT: exactly one read group per launch, at offset 0 of the LDS)
+            const int lr1 = COMPACT ? rg - P.rg_base : 0, lr2 = COMPACT ? rg2 - P.rg_base : 0;
+            const bool mine1 = (COMPACT ? (unsigned)lr1 < (unsigned)P.n_rgs : rg == P.rg_base) && rg < H.n_rg;
+            const bool mine2 = (COMPACT ? (unsigned)lr2 < (unsigned)P.n_rgs : rg2 == P.rg_base) && rg2 < H.n_rg;
+            const bool one_boundary = bpos == 16 || (r + 1 < R.n_reads && end2 >= g0 + 16);
+            if (n == 16 && one_boundary && !mine1 && (bpos == 16 || !mine2)) {
+                starts += bpos < 16 ? 1 : 0;       // a group of other launches' read groups
+            } else if (n == 16 && one_boundary && c0 + bpos <= H.n_cycle && 16 - bpos <= H.n_cycle) {
                 const int pp1 = (pt >> 31) ? (int)((pt >> 8) & 0xFFFF) : -2, pp2 = (pt2 >> 31) ? (int)((pt2 >> 8) & 0xFFFF) : -2;
                 if (pp1 >= 0 && pp1 == c0 - 1) { prev_b = (int)(pt & 3); prev_n = 0; }
-                const int qa = second * KBBQ_NQ * ccap, qb = second2 * KBBQ_NQ * ccap;
                 starts += bpos < 16 ? 1 : 0;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -843,20 +889,9 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
                     int b = (int)((bw >> (2 * i)) & 3), nn = (int)((nw >> i) & 1);
                     if (cyc == (in2 ? pp2 : pp1)) { b = (int)((in2 ? pt2 : pt) & 3); nn = 0; }
                     const int q = qv[i];
-                    const uint32_t er = (ew >> i) & 1u;
-                    const int cr = cyc - cbase;      // inside this launch's cycle window?
-                    if (q < KBBQ_NQ && (unsigned)cr < (unsigned)ccap) {
-                        const int slot = (cr & 15) * (ccap >> 4) + (cr >> 4);
-                        const int idx = (in2 ? qb : qa) + q * ccap + slot;
-                        const uint32_t one = 1u << (16 * (idx & 1));
-                        atomicAdd(&l_cyc[idx >> 1], one);
-                        if (er) atomicAdd(&l_cye[idx >> 1], one);
-                        if (cyc >= 1 && q >= minscore && !(nn | prev_n)) {
-                            const int d = q * 16 + ((prev_b << 2) | b);
-                            atomicAdd(&l_di[d], 1u);
-                            if (er) atomicAdd(&l_die[d], 1u);
-                        }
-                    }
+                    if (q < KBBQ_NQ && (in2 ? mine2 : mine1))
+                        count(in2 ? lr2 : lr1, in2 ? rg2 : rg, q, in2 ? second2 : second, cyc, (int)((ew >> i) & 1u),
+                              cyc >= 1 && q >= minscore && !(nn | prev_n), (prev_b << 2) | b);
                     prev_b = b;
                     prev_n = nn;
                 }
@@ -879,23 +914,9 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
                     int b = (int)((bw >> (2 * i)) & 3), nn = (int)((nw >> i) & 1);
                     if ((pt >> 31) && (int)((pt >> 8) & 0xFFFF) == cyc) { b = (int)(pt & 3); nn = 0; }
                     const int q = qv[i];
-                    const int er = (int)((ew >> i) & 1);
-                    const int cr = cyc - cbase;      // inside this launch's cycle window?
-                    if (rg == lds_rg && rg < H.n_rg && cyc < H.n_cycle && q < KBBQ_NQ && (unsigned)cr < (unsigned)ccap) {
-                        {
-                            // lanes of one instruction are 16 cycles apart: store cycle c at slot
-                            // (c%16)*(ccap/16) + c/16 so that they land in neighbouring words, not in two banks
-                            const int slot = (cr & 15) * (ccap >> 4) + (cr >> 4);
-                            const int idx = (second * KBBQ_NQ + q) * ccap + slot;
-                            atomicAdd(&l_cyc[idx >> 1], 1u << (16 * (idx & 1)));
-                            if (er) atomicAdd(&l_cye[idx >> 1], 1u << (16 * (idx & 1)));
-                        }
-                        if (cyc >= 1 && q >= minscore && !nn && !prev_n) {
-                            const int d = (prev_b << 2) | b;
-                            atomicAdd(&l_di[q * 16 + d], 1u);
-                            if (er) atomicAdd(&l_die[q * 16 + d], 1u);
-                        }
-                    }
+                    const int lr = COMPACT ? rg - P.rg_base : 0;
+                    if ((COMPACT ? (unsigned)lr < (unsigned)P.n_rgs : rg == P.rg_base) && rg < H.n_rg && cyc < H.n_cycle && q < KBBQ_NQ)
+                        count(lr, rg, q, second, cyc, (int)((ew >> i) & 1), cyc >= 1 && q >= minscore && !nn && !prev_n, (prev_b << 2) | b);
                     prev_b = b;
                     prev_n = nn;
                 }
@@ -915,28 +936,33 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
         __syncthreads();
         if (*l_reads >= 40000u || it + 1 == iters) {
             __syncthreads();
-            for (int w = threadIdx.x; w < cyc_words; w += blockDim.x) {
-                const uint32_t v = l_cyc[w], ve = l_cye[w];
-                if (!v) continue;      // no total, no error
-                l_cyc[w] = 0;
-                l_cye[w] = 0;
-                for (int h = 0; h < 2; ++h) {
-                    const uint32_t cnt = (v >> (16 * h)) & 0xFFFFu, cne = (ve >> (16 * h)) & 0xFFFFu;
-                    if (!cnt) continue;
-                    const int idx = 2 * w + h;
-                    const int slot = idx % ccap, rest = idx / ccap;
-                    const int q = rest % KBBQ_NQ, s = rest / KBBQ_NQ;
-                    const int c = cbase + (slot % (ccap >> 4)) * 16 + slot / (ccap >> 4);
-                    if (c < H.n_cycle) {
-                        atomicAdd(&H.cycle[cyc_index(H, lds_rg, q, s, c) + 1], (unsigned long long)cnt);
-                        if (cne) atomicAdd(&H.cycle[cyc_index(H, lds_rg, q, s, c)], (unsigned long long)cne);
+            for (int lr = 0; lr < P.n_rgs; ++lr) {
+                uint32_t *t = lds + lr * per_rg;
+                const int rg = P.rg_base + lr;
+                for (int w = threadIdx.x; w < cyc_words; w += blockDim.x) {
+                    const uint32_t v = t[w], ve = t[cyc_words + w];
+                    if (!v) continue;      // no total, no error
+                    t[w] = 0;
+                    t[cyc_words + w] = 0;
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t cnt = (v >> (16 * h)) & 0xFFFFu, cne = (ve >> (16 * h)) & 0xFFFFu;
+                        if (!cnt) continue;
+                        const int idx = 2 * w + h;
+                        const int slot = idx % ccap, rest = idx / ccap;
+                        const int q = P.qof[rest % ns], s = rest / ns;
+                        const int c = cbase + (slot % (ccap >> 4)) * 16 + slot / (ccap >> 4);
+                        if (c < H.n_cycle) {
+                            atomicAdd(&H.cycle[cyc_index(H, rg, q, s, c) + 1], (unsigned long long)cnt);
+                            if (cne) atomicAdd(&H.cycle[cyc_index(H, rg, q, s, c)], (unsigned long long)cne);
+                        }
                     }
                 }
-            }
-            for (int w = threadIdx.x; w < KBBQ_NQ * 16; w += blockDim.x) {
-                const uint32_t v = l_di[w], ve = l_die[w];
-                if (v) { l_di[w] = 0; atomicAdd(&H.dinuc[((uint64_t)lds_rg * KBBQ_NQ * 16 + w) * 2 + 1], (unsigned long long)v); }
-                if (ve) { l_die[w] = 0; atomicAdd(&H.dinuc[((uint64_t)lds_rg * KBBQ_NQ * 16 + w) * 2], (unsigned long long)ve); }
+                for (int w = threadIdx.x; w < ns * 16; w += blockDim.x) {
+                    const uint32_t v = t[2 * cyc_words + w], ve = t[2 * cyc_words + ns * 16 + w];
+                    const uint64_t cell = ((uint64_t)rg * KBBQ_NQ + P.qof[w >> 4]) * 16 + (w & 15);
+                    if (v) { t[2 * cyc_words + w] = 0; atomicAdd(&H.dinuc[cell * 2 + 1], (unsigned long long)v); }
+                    if (ve) { t[2 * cyc_words + ns * 16 + w] = 0; atomicAdd(&H.dinuc[cell * 2], (unsigned long long)ve); }
+                }
             }
             if (threadIdx.x == 0) *l_reads = 0;
             __syncthreads();
