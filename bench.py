@@ -148,10 +148,39 @@ def pcie_inclusive(genome_len, coverage, local_rank):
     e.sync()
     dt = time.perf_counter() - t0
     nb = n_reads * READ_LEN
+    # the other way over the same boundary, the one the command line takes: every batch is uploaded ONCE (while
+    # pass 1 of the batch before it runs), stays resident with its hint arrays, and only the new qualities come back
+    _lib.check(e.L.kbbq_engine_reset(e.h))
+    e.sync()
+    t0 = time.perf_counter()
+    resident = []
+    for b, o in zip(host, ordinals):
+        d = _lib.Reads()
+        _lib.check(e.L.kbbq_reads_upload(e.h, ctypes.byref(b.c), ctypes.byref(d)))
+        _lib.check(e.L.kbbq_reads_alloc_hints(ctypes.byref(d)))
+        _lib.check(e.L.kbbq_sample_batch(e.h, ctypes.byref(d), o))
+        resident.append(d)
+    e.sample_finish()
+    e.compute_thresholds()
+    for d in resident:
+        _lib.check(e.L.kbbq_trusted_batch(e.h, ctypes.byref(d), None))
+    e.trusted_finish()
+    for d in resident:
+        _lib.check(e.L.kbbq_errors_batch(e.h, ctypes.byref(d), None))
+    e.get_dqs()
+    for d in resident:
+        _lib.check(e.L.kbbq_recalibrate_batch_host(e.h, ctypes.byref(d), out.ctypes.data))
+    e.sync()
+    dt2 = time.perf_counter() - t0
+    for d in resident:
+        _lib.check(e.L.kbbq_reads_free_hints(ctypes.byref(d)))
+        _lib.check(e.L.kbbq_reads_free(e.h, ctypes.byref(d)))
     e.close()
     return dict(value=round(nb / dt / 1e9, 4), unit="Gbases/s", seconds=round(dt, 3),
                 sample="%d reads x %d bp = %.3g bases as host batches of %d reads, every pass re-submits them (5.5 B/base H2D, 1 B/base D2H)"
-                       % (n_reads, READ_LEN, nb, BATCH_READS))
+                       % (n_reads, READ_LEN, nb, BATCH_READS),
+                upload_once=dict(value=round(nb / dt2 / 1e9, 4), unit="Gbases/s", seconds=round(dt2, 3),
+                                 sample="same batches, uploaded once and kept resident (1.4 B/base H2D, 1 B/base D2H, pageable host memory)"))
 
 
 def cpu_baseline(e, genome_len, coverage):

@@ -611,7 +611,9 @@ int kbbq_reads_upload(kbbq_engine *e, const kbbq_reads *host, kbbq_reads *dev) {
     UP(flags, uint8_t, host->n_reads, 0)
     UP(rg, uint16_t, host->n_reads, 0)
 #undef UP
-    HIP_TRY(hipDeviceSynchronize());
+    // the copies above are blocking null-stream copies; the engine's streams are non-blocking, so kernels of
+    // earlier batches keep running underneath an upload (no device-wide wait here)
+    HIP_TRY(hipStreamSynchronize(0));
     return KBBQ_OK;
 }
 
