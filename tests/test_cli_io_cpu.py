@@ -12,7 +12,7 @@ import pytest
 
 import common
 
-CLI = os.path.join(common.ROOT, "kbbq_amd", "kbbq")
+CLI = os.environ.get("KBBQ_CLI", os.path.join(common.ROOT, "kbbq_amd", "kbbq"))   # KBBQ_CLI: e.g. a sanitizer build
 
 
 def ref_name_rules(fullname):
