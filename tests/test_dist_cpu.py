@@ -54,7 +54,7 @@ def _worker_or(rank, world, port, sizes, tmp):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_or_allreduce_equals_elementwise_or(tmp_path, world):
     sizes = [(8, 1 << 20), (1000, 64), (1001, 100), (4096, 4096), (12345, 1000), (7, 2)]
     mp.spawn(_worker_or, args=(world, _free_port(), sizes, str(tmp_path)), nprocs=world, join=True)
