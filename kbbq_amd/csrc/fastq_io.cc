@@ -2,6 +2,7 @@
 #include "fastq_io.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace kbbq {
@@ -354,12 +355,24 @@ const unsigned char kEofBlock[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff
 }
 
 // one BGZF block from data[0..len) appended to `out`; halves the input if the compressed form does not fit 64 KiB
+// compression level: zlib's default, which is what bgzf_open(fn, "w") of the reference gives (htsiter.cc:73);
+// KBBQ_BGZF_LEVEL=0..9 trades size for speed (the decompressed stream is the same)
+static int bgzf_level() {
+    static const int level = [] {
+        const char *s = getenv("KBBQ_BGZF_LEVEL");
+        if (!s || !*s) return Z_DEFAULT_COMPRESSION;
+        const int v = atoi(s);
+        return v < 0 || v > 9 ? Z_DEFAULT_COMPRESSION : v;
+    }();
+    return level;
+}
+
 static bool deflate_block(const unsigned char *data, size_t len, std::vector<unsigned char> &out) {
     if (!len) return true;
     unsigned char block[0x10000];
     z_stream zs;
     memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    if (deflateInit2(&zs, bgzf_level(), Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
     zs.next_in = const_cast<unsigned char *>(data);
     zs.avail_in = (uInt)len;
     zs.next_out = block + 18;

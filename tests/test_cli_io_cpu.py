@@ -133,3 +133,16 @@ def test_bgzf_writer_round_trip_and_block_structure(tmp_path):
         # the pool only changes who deflates a block, not the stream
         threaded = subprocess.run([CLI, "--io-test", "bgzf", "5"], input=payload, capture_output=True, check=True).stdout
         assert threaded == out
+
+
+def test_bgzf_level_knob_changes_size_not_content(tmp_path):
+    rng = np.random.RandomState(1)
+    payload = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(list(b"ACGT"), 150).tolist()), bytes(rng.randint(35, 74, 150).tolist()))
+                       for i in range(3000))
+    sizes = {}
+    for level in ("", "1", "9", "bogus"):
+        out = subprocess.run([CLI, "--io-test", "bgzf", "3"], input=payload, capture_output=True, check=True,
+                             env=dict(os.environ, KBBQ_BGZF_LEVEL=level)).stdout
+        assert gzip.decompress(out) == payload
+        sizes[level] = len(out)
+    assert sizes["1"] > sizes[""] >= sizes["9"] and sizes["bogus"] == sizes[""]     # default = zlib's default level, like the reference
