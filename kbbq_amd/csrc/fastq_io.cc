@@ -361,8 +361,7 @@ static int bgzf_level() {
     static const int level = [] {
         const char *s = getenv("KBBQ_BGZF_LEVEL");
         if (!s || !*s) return Z_DEFAULT_COMPRESSION;
-        const int v = atoi(s);
-        return v < 0 || v > 9 ? Z_DEFAULT_COMPRESSION : v;
+        return s[0] >= '0' && s[0] <= '9' && !s[1] ? s[0] - '0' : Z_DEFAULT_COMPRESSION;
     }();
     return level;
 }
