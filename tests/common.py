@@ -114,6 +114,15 @@ def make_sparse_rg_dataset(**kw):
     return d
 
 
+def make_wide_quality_dataset(seed=40, **kw):
+    """Un-binned qualities: every value 2..41 occurs, in several read groups, so the tally's and the apply
+    kernel's LDS tables (compacted over the qualities present) do not hold all groups at once."""
+    d = make_dataset(seed=seed, **kw)
+    rng = np.random.RandomState(seed)
+    d["qual"] = np.ascontiguousarray(np.where(d["qual"] <= 2, d["qual"], rng.randint(3, 42, size=len(d["qual"]))).astype(np.uint8))
+    return d
+
+
 # The seeded inputs of the GPU parity suite: name -> (dataset builder, dataset kwargs, run kwargs, engine kwargs).
 # tests/test_coverage_cpu.py proves on the CPU that together they reach every branch of get_errors.
 PARITY_CASES = {
@@ -140,6 +149,8 @@ PARITY_CASES = {
     "config4_60x_k21": (make_dataset, dict(seed=6021, genome_len=40_000, coverage=60), dict(k=21, alpha=0.05), dict(uniform=True)),
     "sparse_read_groups": (make_sparse_rg_dataset, dict(seed=55, genome_len=20000, coverage=20, paired=True, extra_errors=60), dict(n_rg=5),
                            dict(uniform=True, n_batches=3)),
+    "wide_qualities_6rg_250": (make_wide_quality_dataset, dict(genome_len=15000, coverage=24, read_len=250, n_rg=6, paired=True,
+                                                              extra_errors=40), dict(n_rg=6), dict(uniform=True, n_batches=2)),
     "reads_400": (make_dataset, dict(seed=400, genome_len=20000, coverage=20, read_len=400, n_per_million=500,
                                      extra_errors=60), dict(), dict(uniform=True)),
 }

@@ -275,6 +275,38 @@ def test_single_rank_exchange_is_a_no_op():
     e.close()
 
 
+def test_pass3_qualities_unseen_by_pass2_are_still_tallied():
+    """The tally's LDS tables are laid out over the quality values pass 2 saw; a batch of pass 3 with other
+    values (a caller may tally other reads than it trusted) must count them all the same."""
+    from oracle import pyoracle
+    d = common.make_dataset(seed=808, genome_len=15000, coverage=24, n_rg=3, paired=True, extra_errors=40)
+    rng = np.random.RandomState(8)
+    qual_b = np.where(d["qual"] <= 2, d["qual"], rng.randint(3, 60, size=len(d["qual"]))).astype(np.uint8)
+    alpha_ld, cov, approx = plan_parameters(d["genome_len"], d["coverage"], None)
+    rg32, sec = np.ascontiguousarray(d["rg"], dtype=np.int32), np.ascontiguousarray(d["second"], dtype=np.uint8)
+    o = pyoracle.Oracle(32, alpha_ld, 777, approx)
+    o.sample(d["seq"], d["off"])
+    o.compute_thresholds()
+    o.trusted(d["seq"], d["qual"], d["off"])
+    want_err = o.errors(d["seq"], qual_b, d["off"], rg32, sec)
+    want = o.covariates()
+    e = Engine(32, alpha_ld, 777, approx, n_rg=3, max_read_len=150)
+    a = ReadBatch(d["seq"], d["qual"], d["off"], d["rg"], d["second"], uniform=True)
+    b = ReadBatch(d["seq"], qual_b, d["off"], d["rg"], d["second"], uniform=True)
+    e.subsample_kmers(a, 0)
+    e.sample_finish()
+    e.compute_thresholds()
+    e.find_trusted_kmers(a)
+    e.trusted_finish()
+    got_err = e.get_covariatedata(b, want_errors=True)
+    got = e.covariates()
+    e.close()
+    assert np.array_equal(got_err, np.asarray(want_err).astype(got_err.dtype))
+    R, C = want["R"], want["C"]
+    assert np.array_equal(got["rg"][:R], want["rg"]) and np.array_equal(got["q"][:R], want["q"])
+    assert np.array_equal(got["cycle"][:R, :, :, :C], want["cycle"]) and np.array_equal(got["dinuc"][:R], want["dinuc"])
+
+
 def test_fixed_mode_tally_matches_oracle():
     # --fixed (kbbq.cc:367-378): caller-supplied error flags feed the tally directly
     d = common.make_dataset(seed=77, genome_len=8000, coverage=15, n_rg=2, paired=True)
