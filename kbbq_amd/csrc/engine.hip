@@ -682,6 +682,7 @@ int kbbq_count_kmer_positions(kbbq_engine *e, const kbbq_reads *reads, uint64_t 
 }
 
 }  // extern "C"
+
 template <template <int> class Launcher, typename... Args>
 static int dispatch_nw(int max_len, Args... args) {
     if (max_len <= 192) return Launcher<3>::go(args...);
@@ -689,9 +690,6 @@ static int dispatch_nw(int max_len, Args... args) {
     return Launcher<8>::go(args...);
 }
 
-extern "C" {
-
-}  // extern "C"
 template <int NW> struct LaunchSample {
     static int go(kbbq_engine *e, ReadsDev R, const uint64_t *mask, uint64_t mask_words, const uint64_t *kofs) {
         Timed t(e, "k_insert_sampled");
@@ -767,6 +765,7 @@ int kbbq_set_thresholds(kbbq_engine *e, const int32_t *thresholds, int32_t n) {
 
 // ---- pass 2
 }  // extern "C"
+
 template <int NW> struct LaunchTrusted {
     static int go(kbbq_engine *e, ReadsDev R, uint32_t *take_bits, uint32_t *err_out) {
         Thresholds thr;
@@ -846,6 +845,7 @@ int kbbq_trusted_finish(kbbq_engine *e, uint64_t *inserted) {
 
 // ---- pass 3
 }  // extern "C"
+
 template <int NW> struct LaunchScan {
     static int go(kbbq_engine *e, ReadsDev R, uint64_t *tmask, uint8_t *dirty, uint32_t *err_bits, int fast) {
         Timed t(e, "k_scan_trusted", e->cur);
@@ -856,9 +856,6 @@ template <int NW> struct LaunchScan {
     }
 };
 
-extern "C" {
-
-}  // extern "C"
 template <int MAXL, int BLOCK>
 static int launch_correct(kbbq_engine *e, ReadsDev R, const uint32_t *list, const uint64_t *tmask, int tw,
                           uint32_t *err_bits, uint32_t *patch) {
@@ -878,10 +875,6 @@ static int launch_correct(kbbq_engine *e, ReadsDev R, const uint32_t *list, cons
     return KBBQ_OK;
 }
 
-extern "C" {
-
-
-}  // extern "C"
 template <int NB, int NN>
 static int launch_correct_wave(kbbq_engine *e, ReadsDev R, const uint32_t *list, const uint64_t *tmask, int tw,
                                uint32_t *err_bits, uint32_t *patch) {
