@@ -337,18 +337,24 @@ def main():
             launches_per_step = kernels[dom]["launches"] // args.steps
             full_launches = (n_local // BATCH_READS) >= 1 and READ_LEN == 150 and BATCH_READS == 1 << 22
             if k and full_launches:
-                traffic = round((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0)
-                traffic_note = ("FETCH_SIZE + WRITE_SIZE per launch of %d reads, %s (%d launches per step here, the last one partial)"
-                                % (BATCH_READS, pmc["summary_file"], launches_per_step))
+                # gfx950: FETCH_SIZE tallies the L2's 128-byte memory requests at 64 bytes each (MI355X_MICROARCH.md, HBM
+                # section; tools/probe_req: every random lookup is one TCC_EA0_RDREQ_128B) -- doubled here
+                traffic = round((2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0)
+                traffic_note = ("2 x FETCH_SIZE + WRITE_SIZE per launch of %d reads, %s (%d launches per step here, the last one partial); "
+                                "FETCH_SIZE counts the 128-byte requests of gfx950's L2 as 64 bytes" % (BATCH_READS, pmc["summary_file"], launches_per_step))
         except (OSError, ValueError, KeyError):
             pass
         roof = dict(bound="hbm", kernel=dom, achieved=kernels[dom]["achieved_GBps"], peak=HBM_PEAK_GBPS, unit="GB/s",
                     frac=round(kernels[dom]["achieved_GBps"] / HBM_PEAK_GBPS, 4), traffic=traffic,
                     algorithmic_bytes_per_launch=kernels[dom]["alg_bytes_per_launch"], avg_launch_ms=kernels[dom]["avg_ms"],
                     traffic_note=traffic_note,
-                    note="one random 64-byte line per lookup: tools/probe_hbm measures about 3100 GB/s as this chip's ceiling for the "
-                         "Bloom access pattern; traffic below the algorithmic bytes = lookups answered by hint bits; dominant = largest total "
-                         "among the kernels that run alone (pass-3 kernels overlap on two streams, flagged `overlapped`)")
+                    traffic_GBps=None if traffic is None else round(traffic / kernels[dom]["avg_ms"] / 1e6, 1),
+                    note="achieved = SURVEY 8d's algorithmic bytes (64 per Bloom query) over the launch time.  The engine's blocks are 16 bytes, "
+                         "but the L2 fetches a whole 128-byte line per random lookup (tools/probe_req: TCC_EA0_RDREQ_128B = lookups), so the "
+                         "HBM traffic is above the algorithmic figure although 23 % of the queries are answered by hint bits; in those real "
+                         "bytes the kernel runs at traffic / avg_launch_ms of HBM bandwidth, and the probe's ceiling for this access pattern is "
+                         "54 G lookups/s = 6.9 TB/s.  dominant = largest total among the kernels that run alone (pass-3 kernels overlap on "
+                         "two streams, flagged `overlapped`)")
         line = {
             "metric": "recalibrated Gbases/sec", "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
