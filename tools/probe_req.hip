@@ -67,7 +67,7 @@ template <typename F> float timeit(F f) {
 }
 int main(int argc, char **argv) {
     const int mode = argc > 1 ? atoi(argv[1]) : 0;   // 0 hipMalloc, 1 uncached, 2 fine-grained
-    const uint32_t nblocks = 1u << 27;      // 2 GiB of 16-byte blocks (buffer offsets are 32-bit)
+    const uint32_t nblocks = 1u << (argc > 3 ? atoi(argv[3]) : 27);      // default 2 GiB of 16-byte blocks (buffer offsets are 32-bit)
     uint64_t *t, *sink;
     if (mode == 0) CK(hipMalloc(&t, (uint64_t)nblocks * 16));
     else CK(hipExtMallocWithFlags((void **)&t, (uint64_t)nblocks * 16, mode == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained));
@@ -81,7 +81,7 @@ int main(int argc, char **argv) {
     RUN("global x4, 4 in flight", (k_globr<4>))
     { const uint64_t pa = per / 4; float ms = timeit([&] { hipLaunchKernelGGL(k_atom<1>, dim3(grid), dim3(256), 0, 0, t, nblocks, pa, sink); }); printf("  %-44s %8.2f ms  %6.2f Gblk/s\n", "atomicOr 8B", ms, lanes * pa / ms / 1e6);
       ms = timeit([&] { hipLaunchKernelGGL(k_atom<2>, dim3(grid), dim3(256), 0, 0, t, nblocks, pa, sink); }); printf("  %-44s %8.2f ms  %6.2f Gblk/s\n", "atomicOr 2 x 8B", ms, lanes * pa / ms / 1e6); }
-    if (argc > 2) return 0;
+    if (argc > 2 && argv[2][0] == 's') return 0;
     RUN("buffer b128 aux=0", (k_buf<0, 16>)) RUN("buffer b128 sc0", (k_buf<1, 16>)) RUN("buffer b128 nt", (k_buf<2, 16>)) RUN("buffer b128 sc0 nt", (k_buf<3, 16>))
     RUN("buffer b128 sc1", (k_buf<16, 16>)) RUN("buffer b128 sc1 sc0", (k_buf<17, 16>)) RUN("buffer b128 sc1 nt", (k_buf<18, 16>)) RUN("buffer b128 sc1 sc0 nt", (k_buf<19, 16>))
     RUN("buffer b64 aux=0", (k_buf<0, 8>)) RUN("buffer b64 nt", (k_buf<2, 8>)) RUN("buffer b64 sc1 sc0 nt", (k_buf<19, 8>))
