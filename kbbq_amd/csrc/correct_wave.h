@@ -375,9 +375,23 @@ struct WaveCorrector {
             }
             if (got >= need) return anchor;
         }
-        // second loop: wind the anchor back by up to k/2 bases
+        // second loop: wind the anchor back by up to k/2 bases.  Its probes do not depend on one another (the
+        // sequence does not change here) and inside an anchor an alternative base is almost never trusted, so the
+        // first k-mer of every (position, candidate) is asked in ONE round -- lane = 4 * i + candidate, k/2 <= 16
+        // positions -- and the loop below only probes the positions where something answered.
+        uint64_t hits;
+        {
+            const int i_l = lane >> 2, y = lane & 3;
+            const bool in = i_l <= k / 2 - 1 && anchor > i_l + k - 1;
+            const int mod_l = in ? anchor - i_l : anchor;
+            const int m_abs = lo + (dir > 0 ? mod_l : n - 1 - mod_l);
+            const bool act = in && code(m_abs) != y;
+            const Pair p = kmer_pair(m_abs - (dir > 0 ? k - 1 : 0), m_abs, y);
+            hits = uni((uint64_t)__ballot(ask(act, p)));
+        }
 #pragma unroll 1
         for (int i = k / 2 - 1; i >= 0 && anchor > i + k - 1; --i) {
+            if (!((hits >> (4 * i)) & 0xF)) continue;      // no candidate's first k-mer is trusted: nothing happens here
             const int mod2 = anchor - i;
             const int rel2 = dir > 0 ? mod2 : n - 1 - mod2;
             const Probe p2 = probe(lo, n, lo + rel2, dir);
