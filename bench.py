@@ -47,7 +47,9 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-PASS3_KERNELS = ("k_scan_trusted", "k_compact", "k_correct_wave", "k_correct", "k_tally")
+# kernels that share the chip with a kernel of the neighbouring batch on the other stream (pass 1: draw beside insert;
+# pass 3: walk + tally beside scan): their event durations are not exclusive costs
+PASS3_KERNELS = ("k_draw_mask", "k_insert_sampled", "k_scan_trusted", "k_compact", "k_correct_wave", "k_correct", "k_tally")
 
 
 def run_step(e, xch, batches, ordinals, out_buf, hints):
@@ -321,8 +323,8 @@ def main():
             if model:
                 ent["alg_bytes_per_launch"] = model
                 ent["achieved_GBps"] = round(model / (ms / launches) / 1e6, 1)
-            # pass 3 runs on two streams (walk + tally of batch i beside scan + fast path of batch i+1): the event
-            # duration of such a kernel includes time it shared the chip, so it is not an exclusive cost
+            # passes 1 and 3 run on two streams (draw of batch i+1 beside insert of batch i; walk + tally of batch i beside
+            # scan + fast path of batch i+1): the event duration of such a kernel includes time it shared the chip
             if name in PASS3_KERNELS and not os.environ.get("KBBQ_NO_OVERLAP"):
                 ent["overlapped"] = True
             kernels[name] = ent

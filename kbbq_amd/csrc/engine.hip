@@ -79,6 +79,10 @@ struct kbbq_engine {
     // the pass and its counters exist twice; an event per side says when a side's buffers are free again.
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_main = nullptr, ev_side[2] = {nullptr, nullptr};
+    // pass 1: the draw of batch i+1 (ALU only, side stream) runs beside the insert of batch i (main stream); two mask buffers
+    hipEvent_t ev_draw = nullptr, ev_ins[2] = {nullptr, nullptr};
+    bool ins_pending[2] = {false, false};
+    int draw_turn = 0;
     bool side_busy[2] = {false, false};     // counters of that side not yet added to stats
     uint64_t side_reads[2] = {0, 0};
     int side_turn = 0;
@@ -367,6 +371,8 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_draw, hipEventDisableTiming);
+    for (int t = 0; t < 2 && he == hipSuccess; ++t) he = hipEventCreateWithFlags(&e->ev_ins[t], hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_side[0], hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_side[1], hipEventDisableTiming);
     e->cur = e->stream;
@@ -441,6 +447,8 @@ void kbbq_engine_destroy(kbbq_engine *e) {
     for (int i = 0; i < 16; ++i) hipFree(e->scratch[i]);
     if (e->stream2) { hipStreamSynchronize(e->stream2); hipStreamDestroy(e->stream2); }
     if (e->ev_main) hipEventDestroy(e->ev_main);
+    if (e->ev_draw) hipEventDestroy(e->ev_draw);
+    for (int t = 0; t < 2; ++t) if (e->ev_ins[t]) hipEventDestroy(e->ev_ins[t]);
     for (int i = 0; i < 2; ++i) if (e->ev_side[i]) hipEventDestroy(e->ev_side[i]);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
@@ -710,21 +718,39 @@ int kbbq_sample_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t first_km
     const uint64_t *kofs; uint64_t n_draws;
     if ((rc = kmer_prefix(e, R, &kofs, &n_draws))) return rc;
     if (n_draws == 0) return KBBQ_OK;
-    if ((rc = ensure_scratch(e, 0, (n_draws / 64 + 2) * 8))) return rc;
-    uint64_t *mask = (uint64_t *)e->scratch[0];
+    static const bool no_overlap = getenv("KBBQ_NO_OVERLAP") != nullptr;
+    const bool overlap = reads->on_device && !no_overlap;
+    const int turn = overlap ? e->draw_turn : 0;
+    const int slot = turn ? 13 : 0;
+    if ((rc = ensure_scratch(e, slot, (n_draws / 64 + 2) * 8))) return rc;
+    uint64_t *mask = (uint64_t *)e->scratch[slot];
+    hipStream_t ds = overlap ? e->stream2 : e->stream;
+    if (overlap) {
+        e->draw_turn ^= 1;
+        if (e->ins_pending[turn]) HIP_TRY(hipStreamWaitEvent(ds, e->ev_ins[turn], 0));   // the insert that last read this mask
+    }
     {
-        Timed t(e, "k_draw_mask");
+        Timed t(e, "k_draw_mask", ds);
         const uint64_t lanes = (n_draws + DRAWS_PER_LANE - 1) / DRAWS_PER_LANE;
         // the host jumps to the batch's first draw (a few thousand xoshiro steps); the lanes then only jump by
         // their offset inside the batch, which has far fewer set bits than the file-wide ordinal
         uint64_t st[4];
         xoshiro_state_at(e->p.seed, first_kmer_ordinal, st);
-        hipLaunchKernelGGL(k_draw_mask, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, e->stream,
+        hipLaunchKernelGGL(k_draw_mask, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, ds,
                            st[0], st[1], st[2], st[3],
                            (uint64_t)0, n_draws, e->draw_threshold, e->draw_always ? 1 : 0, mask);
         HIP_TRY(hipGetLastError());
     }
-    return dispatch_nw<LaunchSample>(max_len, e, R, (const uint64_t *)mask, n_draws / 64 + 2, kofs);
+    if (overlap) {
+        HIP_TRY(hipEventRecord(e->ev_draw, ds));
+        HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_draw, 0));
+    }
+    rc = dispatch_nw<LaunchSample>(max_len, e, R, (const uint64_t *)mask, n_draws / 64 + 2, kofs);
+    if (!rc && overlap) {
+        HIP_TRY(hipEventRecord(e->ev_ins[turn], e->stream));
+        e->ins_pending[turn] = true;
+    }
+    return rc;
 }
 
 int kbbq_sample_finish(kbbq_engine *e, uint64_t *inserted) {
