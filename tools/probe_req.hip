@@ -46,6 +46,18 @@ __global__ void __launch_bounds__(256) k_atom(uint64_t *t, uint32_t nblocks, uin
         if (N > 1) atomicOr((unsigned long long *)&t[b * 2 + 1], 1ull << (i & 63));
     }
 }
+template <int N, int SCOPE>   // atomic OR at a given HIP memory scope (1 wavefront, 2 workgroup, 3 agent, 4 system), after a look or blind
+__global__ void __launch_bounds__(256) k_atom_scope(uint64_t *t, uint32_t nblocks, uint64_t per_lane, uint64_t *sink, int look) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t acc = 0;
+    for (uint64_t i = 0; i < per_lane; ++i) {
+        const uint64_t b = __umul64hi(mix64(tid * per_lane + i), (uint64_t)nblocks);
+        if (look) { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(t + b * 2); acc ^= v.x ^ v.y; }
+        __hip_atomic_fetch_or(&t[b * 2], (1ull << (i & 63)) | (acc & 1), __ATOMIC_RELAXED, SCOPE);
+        if (N > 1) __hip_atomic_fetch_or(&t[b * 2 + 1], 1ull << (i & 63), __ATOMIC_RELAXED, SCOPE);
+    }
+    if (acc == 0x1234567) sink[0] = acc;
+}
 template <int R>   // R independent loads in flight per lane
 __global__ void __launch_bounds__(256) k_globr(const uint64_t *t, uint32_t nblocks, uint64_t per_lane, uint64_t *sink) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -81,6 +93,21 @@ int main(int argc, char **argv) {
     RUN("global x4, 4 in flight", (k_globr<4>))
     { const uint64_t pa = per / 4; float ms = timeit([&] { hipLaunchKernelGGL(k_atom<1>, dim3(grid), dim3(256), 0, 0, t, nblocks, pa, sink); }); printf("  %-44s %8.2f ms  %6.2f Gblk/s\n", "atomicOr 8B", ms, lanes * pa / ms / 1e6);
       ms = timeit([&] { hipLaunchKernelGGL(k_atom<2>, dim3(grid), dim3(256), 0, 0, t, nblocks, pa, sink); }); printf("  %-44s %8.2f ms  %6.2f Gblk/s\n", "atomicOr 2 x 8B", ms, lanes * pa / ms / 1e6); }
+    if (argc > 2 && argv[2][0] == 'a') {   // atomic scopes
+        const uint64_t pa = per / 4;
+#define RUNA(name, kern, look) { float ms = timeit([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, t, nblocks, pa, sink, look); }); \
+        printf("  %-44s %8.2f ms  %6.2f Gblk/s\n", name, ms, lanes * pa / ms / 1e6); }
+        RUNA("2 x atomicOr wavefront scope, blind", (k_atom_scope<2, __HIP_MEMORY_SCOPE_WAVEFRONT>), 0)
+        RUNA("2 x atomicOr workgroup scope, blind", (k_atom_scope<2, __HIP_MEMORY_SCOPE_WORKGROUP>), 0)
+        RUNA("2 x atomicOr agent scope, blind", (k_atom_scope<2, __HIP_MEMORY_SCOPE_AGENT>), 0)
+        RUNA("2 x atomicOr system scope, blind", (k_atom_scope<2, __HIP_MEMORY_SCOPE_SYSTEM>), 0)
+        RUNA("2 x atomicOr wavefront scope, after look", (k_atom_scope<2, __HIP_MEMORY_SCOPE_WAVEFRONT>), 1)
+        RUNA("2 x atomicOr workgroup scope, after look", (k_atom_scope<2, __HIP_MEMORY_SCOPE_WORKGROUP>), 1)
+        RUNA("2 x atomicOr agent scope, after look", (k_atom_scope<2, __HIP_MEMORY_SCOPE_AGENT>), 1)
+        RUNA("1 x atomicOr workgroup scope, blind", (k_atom_scope<1, __HIP_MEMORY_SCOPE_WORKGROUP>), 0)
+        RUNA("1 x atomicOr agent scope, blind", (k_atom_scope<1, __HIP_MEMORY_SCOPE_AGENT>), 0)
+        return 0;
+    }
     if (argc > 2 && argv[2][0] == 's') return 0;
     RUN("buffer b128 aux=0", (k_buf<0, 16>)) RUN("buffer b128 sc0", (k_buf<1, 16>)) RUN("buffer b128 nt", (k_buf<2, 16>)) RUN("buffer b128 sc0 nt", (k_buf<3, 16>))
     RUN("buffer b128 sc1", (k_buf<16, 16>)) RUN("buffer b128 sc1 sc0", (k_buf<17, 16>)) RUN("buffer b128 sc1 nt", (k_buf<18, 16>)) RUN("buffer b128 sc1 sc0 nt", (k_buf<19, 16>))
