@@ -776,7 +776,7 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
                                                  int ccap, int minscore, int vec_ok, TallyPlan P, const uint32_t *present,
                                                  const uint32_t *read_index) {
     extern __shared__ uint32_t lds[];
-    const int ns = P.n_slots, cbase = P.cbase;
+    const int ns = COMPACT ? P.n_slots : KBBQ_NQ, cbase = P.cbase;     // not COMPACT: the identity layout, a compile-time 94
     if (present) {      // none of this launch's read groups occurs in the batch
         bool any = false;
         for (int g = P.rg_base; g < P.rg_base + P.n_rgs; ++g) any = any || ((present[g >> 5] >> (g & 31)) & 1);
