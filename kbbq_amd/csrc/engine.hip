@@ -746,7 +746,7 @@ int kbbq_sample_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t first_km
         HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_draw, 0));
     }
     rc = dispatch_nw<LaunchSample>(max_len, e, R, (const uint64_t *)mask, n_draws / 64 + 2, kofs);
-    if (!rc && overlap) {
+    if (!rc) {     // (also for an in-order batch: a later overlapped draw into the same buffer must wait for this insert)
         HIP_TRY(hipEventRecord(e->ev_ins[turn], e->stream));
         e->ins_pending[turn] = true;
     }

@@ -131,6 +131,39 @@ def test_device_resident_batches_match_host_batches():
     e.close()
 
 
+def test_host_and_device_batches_interleaved():
+    """A caller may hand over some batches as host buffers and keep others resident: the passes' stream and buffer
+    bookkeeping (pass 1 and pass 3 run device batches on two streams) must order them all the same."""
+    d = common.make_dataset(seed=1717, genome_len=20000, coverage=24, n_per_million=1000, extra_errors=80)
+    ref = common.run_engine(d, uniform=True)
+    alpha_ld, cov, approx = plan_parameters(d["genome_len"], d["coverage"], None)
+    e = Engine(32, alpha_ld, 777, approx, n_rg=1, max_read_len=150)
+    full = ReadBatch(d["seq"], d["qual"], d["off"], d["rg"], d["second"], uniform=True)
+    n = full.n_reads
+    cuts = [n * i // 6 for i in range(7)]
+    host = [full.slice(cuts[i], cuts[i + 1]) for i in range(6)]
+    mixed = [b if i % 3 == 1 else e.upload(b) for i, b in enumerate(host)]     # D H D D H D
+    ordinal = 0
+    for b, hb in zip(mixed, host):
+        e.subsample_kmers(b, ordinal)
+        ordinal += hb.n_kmer_positions(32)
+    assert e.sample_finish() == ref["sampled_inserted"]
+    assert np.array_equal(e.filter_table(0), ref["sampled_table"])
+    e.compute_thresholds()
+    for b in mixed:
+        e.find_trusted_kmers(b)
+    assert e.trusted_finish() == ref["trusted_inserted"]
+    assert np.array_equal(e.filter_table(1), ref["trusted_table"])
+    for b in mixed:
+        e.get_covariatedata(b)
+    c = e.covariates()
+    assert np.array_equal(c["cycle"], ref["cov"]["cycle"]) and np.array_equal(c["dinuc"], ref["cov"]["dinuc"])
+    for b in mixed:
+        if not isinstance(b, ReadBatch):
+            b.free()
+    e.close()
+
+
 def test_hint_arrays_do_not_change_results():
     """kbbq_reads.hint_sampled / hint_trusted only skip lookups whose answer is known."""
     import torch
