@@ -401,7 +401,8 @@ int main(int argc, char *argv[]) {
     uint64_t seqlen = 0, n_reads = 0;
     size_t longest = 0;
     BamHeader bam_header;
-    const size_t batch_reads = 1 << 20;
+    // reads per engine call; KBBQ_BATCH_READS shrinks it so that tests cross many batch boundaries with small files
+    const size_t batch_reads = getenv("KBBQ_BATCH_READS") ? std::max<size_t>(1, strtoull(getenv("KBBQ_BATCH_READS"), nullptr, 10)) : (size_t)1 << 20;
     Batch batch;
     struct Resident {
         std::vector<kbbq_reads> dev;

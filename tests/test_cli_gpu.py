@@ -316,3 +316,29 @@ def ref_rg_index_of_empty(names, cut):
     of named_dataset already introduced as index 0."""
     assert ref_name_rules(names[0])[0] == "" and cut > 0
     return 0
+
+
+def test_cli_output_does_not_depend_on_the_batch_size(tmp_path):
+    """KBBQ_BATCH_READS (a testing knob) cuts the input into many engine calls: sampler ordinals, resident batches with
+    their hint arrays, the two-stream passes, the record cache and the writers all cross batch boundaries; the bytes of
+    the decompressed output must stay those of the one-batch run -- FASTQ and BAM, resident and streaming."""
+    d, names, n_rg = named_dataset(seed=4040, genome_len=20000, coverage=24, n_per_million=2000, ragged=True, mid_reads=60,
+                                   short_reads=10, extra_errors=80)
+    fq = tmp_path / "in.fq.gz"
+    write_fastq(fq, d, names)
+    rc, one, err = run_cli(["-g", d["genome_len"], fq], {"KBBQ_SEED": "99"})
+    assert rc == 0, err
+    one = gzip.decompress(one)
+    for env in ({"KBBQ_BATCH_READS": "257"}, {"KBBQ_BATCH_READS": "1000", "KBBQ_RESIDENT": "0"},
+                {"KBBQ_BATCH_READS": "64", "KBBQ_HOST_CACHE_MB": "0"}):
+        rc, out, err = run_cli(["-g", d["genome_len"], fq], dict(env, KBBQ_SEED="99"))
+        assert rc == 0, err
+        assert gzip.decompress(out) == one, env
+    db, recs, path, n_rg_b = bam_dataset(tmp_path, seed=78, genome_len=20000, coverage=24, n_per_million=2000, ragged=True, extra_errors=60)
+    rc, one_b, err = run_cli(["--set-oq", path], {"KBBQ_SEED": "7"})
+    assert rc == 0, err
+    one_b = bamutil.bgzf_decompress(one_b)
+    for env in ({"KBBQ_BATCH_READS": "300"}, {"KBBQ_BATCH_READS": "777", "KBBQ_RESIDENT": "0"}):
+        rc, out, err = run_cli(["--set-oq", path], dict(env, KBBQ_SEED="7"))
+        assert rc == 0, err
+        assert bamutil.bgzf_decompress(out) == one_b, env
