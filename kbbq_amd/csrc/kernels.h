@@ -10,9 +10,10 @@
 //           k_correct_wave     get_errors, one read per wavefront (correct_wave.h); k_correct: one read per lane (correct.h)
 //           k_tally            covariate histograms                      (covariateutils.cc:30-164,193-202)
 //   pass 4  k_recalibrate      delta-Q apply                             (readutils.cc:572-595)
-//   helpers k_kmer_counts, k_exclusive_scan, k_or_words, k_or_pieces, k_synth
-// Integer / hash / bit work throughout: no MFMA.  What bounds passes 1-3 is the rate of random 64-byte lines
-// (one per Bloom lookup), see DESIGN.md section 4.
+//   helpers k_kmer_counts, k_scan_tiles / k_scan_tile_sums / k_scan_add, k_read_index, k_rg_presence, k_or_words,
+//           k_or_pieces, k_synth
+// Integer / hash / bit work throughout: no MFMA.  What bounds passes 1-3 is HBM bandwidth at the L2's line
+// granularity: every Bloom lookup fetches one random 128-byte line for its 16-byte block.
 #pragma once
 #include <hip/hip_runtime.h>
 
