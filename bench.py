@@ -35,7 +35,8 @@ from kbbq_amd import _lib, synth  # noqa: E402
 from kbbq_amd.dist import EnginePeer, Exchange, shard_range  # noqa: E402
 from kbbq_amd.engine import Engine, plan_parameters  # noqa: E402
 
-K = 32
+K = int(os.environ.get("KBBQ_BENCH_K", 32))          # BASELINE configs[1]: 32; configs[4] (60x, k=21, -a 0.05) via the KBBQ_BENCH_* knobs
+ALPHA = os.environ.get("KBBQ_BENCH_ALPHA") or None     # text, parsed to long double like the command line's --alpha
 READ_LEN = 150
 SEED_DATA = 12345
 SEED_SAMPLER = 777
@@ -244,7 +245,7 @@ def main():
 
     G, cov = args.genome_len, args.coverage
     n_reads_total = G * cov // READ_LEN
-    alpha_ld, cov, approx = plan_parameters(G, cov, None)
+    alpha_ld, cov, approx = plan_parameters(G, cov, ALPHA)
     a, b = shard_range(n_reads_total, rank, world)
     n_local = b - a
     nk_per_read = READ_LEN - K + 1
@@ -361,8 +362,9 @@ def main():
             "metric": "recalibrated Gbases/sec", "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%dx synthetic WGS reads, genome %d bp, %d bp reads, k=%d (BASELINE configs[1])"
-                                   % (cov, G, READ_LEN, K),
+            "config": {"workload": "%dx synthetic WGS reads, genome %d bp, %d bp reads, k=%d%s (%s)"
+                                   % (cov, G, READ_LEN, K, "" if ALPHA is None else ", alpha " + ALPHA,
+                                      "BASELINE configs[1]" if (K, ALPHA, cov) == (32, None, 30) else "another shape than BASELINE configs[1]"),
                        "reads": n_reads_total, "bases": bases_total, "batch_reads": BATCH_READS,
                        "parallelism": "reads sharded x%d, Bloom OR all-reduce + histogram sum over RCCL" % world
                        if world > 1 else "1 GPU, reads resident in HBM"},
