@@ -63,8 +63,9 @@ typedef struct kbbq_params {
 #define KBBQ_F_PROFILE 1    /* time every kernel with HIP events (kbbq_profile_get) */
 
 /* One batch of reads, structure of arrays.  All pointers are device pointers if
- * on_device != 0, host pointers otherwise (the engine then stages them through
- * pinned memory with hipMemcpyAsync).
+ * on_device != 0, host pointers otherwise (the engine then copies them to device
+ * buffers of its own with hipMemcpyAsync on its stream and frees those at its next
+ * synchronisation; page-locked caller memory makes the copies faster, it is not required).
  *   bases   2 bits per base, base i of the batch in bits [2*(i%32), +2) of word
  *           i/32; A=0 C=1 G=2 T=3 (seq_nt16_int[seq_nt16_table[ch]], bloom.hh:351);
  *           anything else is stored as 0 with its nmask bit set.
