@@ -64,8 +64,10 @@ typedef struct kbbq_params {
 
 /* One batch of reads, structure of arrays.  All pointers are device pointers if
  * on_device != 0, host pointers otherwise (the engine then copies them to device
- * buffers of its own with hipMemcpyAsync on its stream and frees those at its next
- * synchronisation; page-locked caller memory makes the copies faster, it is not required).
+ * buffers of its own with hipMemcpyAsync on its stream; page-locked caller memory makes
+ * the copies faster, it is not required).  A call with a host batch has completed when it
+ * returns: the caller may reuse the batch's memory at once.  Calls with device batches only
+ * queue work (see the individual functions).
  *   bases   2 bits per base, base i of the batch in bits [2*(i%32), +2) of word
  *           i/32; A=0 C=1 G=2 T=3 (seq_nt16_int[seq_nt16_table[ch]], bloom.hh:351);
  *           anything else is stored as 0 with its nmask bit set.

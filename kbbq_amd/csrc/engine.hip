@@ -686,7 +686,9 @@ int kbbq_count_kmer_positions(kbbq_engine *e, const kbbq_reads *reads, uint64_t 
     int rc = device_view(e, reads, &R, &max_len);
     if (rc) return rc;
     const uint64_t *kofs;
-    return kmer_prefix(e, R, &kofs, out);
+    rc = kmer_prefix(e, R, &kofs, out);
+    if (!rc && !reads->on_device) rc = sync_engine(e);
+    return rc;
 }
 
 }  // extern "C"
@@ -750,6 +752,9 @@ int kbbq_sample_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t first_km
         HIP_TRY(hipEventRecord(e->ev_ins[turn], e->stream));
         e->ins_pending[turn] = true;
     }
+    // a host batch is the caller's again when the call returns (its memory may be page-locked: the copies are then
+    // truly asynchronous), and the engine's copies of it are freed
+    if (!rc && !reads->on_device) rc = sync_engine(e);
     return rc;
 }
 
@@ -853,7 +858,8 @@ int kbbq_trusted_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *infer_
         HIP_TRY(hipMemsetAsync(take_bits, 0, (R.n_bases / 64 + 2) * 8, e->stream));
     }
     if ((rc = dispatch_nw<LaunchTrusted>(max_len, e, R, take_bits, d_err))) return rc;
-    return bit_out_end(e, reads, infer_errors_out, d_err);
+    if ((rc = bit_out_end(e, reads, infer_errors_out, d_err))) return rc;
+    return reads->on_device ? KBBQ_OK : sync_engine(e);      // host batches complete before the call returns
 }
 
 int kbbq_trusted_finish(kbbq_engine *e, uint64_t *inserted) {
@@ -1077,7 +1083,8 @@ int kbbq_tally_batch(kbbq_engine *e, const kbbq_reads *reads, const uint64_t *er
         if ((rc = stage_array(e, errors, reads->n_bases / 64 + 1, 1, &tmp))) return rc;
         d_err = (const uint32_t *)tmp;
     }
-    return run_tally(e, R, d_err, nullptr, max_len);
+    if ((rc = run_tally(e, R, d_err, nullptr, max_len))) return rc;
+    return reads->on_device ? KBBQ_OK : sync_engine(e);      // host batches complete before the call returns
 }
 
 void *kbbq_covariates_device(kbbq_engine *e, uint64_t *n_words) {

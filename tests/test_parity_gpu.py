@@ -164,6 +164,50 @@ def test_host_and_device_batches_interleaved():
     e.close()
 
 
+def test_host_batches_in_reused_page_locked_memory():
+    """A host batch belongs to the caller again when the call returns -- also when its memory is page-locked (the
+    engine's copies are then truly asynchronous) and the caller refills the same buffers for the next batch at once."""
+    import torch
+    d = common.make_dataset(seed=3131, genome_len=30000, coverage=24, extra_errors=60)
+    ref = common.run_engine(d, uniform=True)
+    alpha_ld, cov, approx = plan_parameters(d["genome_len"], d["coverage"], None)
+    e = Engine(32, alpha_ld, 777, approx, n_rg=1, max_read_len=150)
+    full = ReadBatch(d["seq"], d["qual"], d["off"], d["rg"], d["second"], uniform=True)
+    n = full.n_reads // 4 // 32 * 32
+    parts = [full.slice(i * n, (i + 1) * n) for i in range(4)]          # equal sizes: one set of buffers serves all
+    keep = []
+
+    def pinned(a):
+        t = torch.empty(a.nbytes, dtype=torch.uint8).pin_memory()
+        keep.append(t)
+        return t.numpy().view(a.dtype)
+
+    pb, pm, pq = pinned(parts[0].bases), pinned(parts[0].nmask), pinned(parts[0].qual)
+    shell = parts[0]
+    shell.c.bases, shell.c.nmask, shell.c.qual = pb.ctypes.data, pm.ctypes.data, pq.ctypes.data
+    arrays = [(p.bases.copy(), p.nmask.copy(), p.qual.copy()) for p in parts]
+
+    def each(fn):
+        for i, (b, m, q) in enumerate(arrays):
+            pb[:], pm[:], pq[:] = b, m, q          # refill the same page-locked buffers right after the previous call
+            fn(i)
+
+    each(lambda i: e.subsample_kmers(shell, i * n * (150 - 32 + 1)))
+    e.sample_finish()
+    sub = common.run_engine(dict(d, seq=d["seq"][:4 * n * 150], qual=d["qual"][:4 * n * 150], off=d["off"][:4 * n + 1],
+                                 rg=d["rg"][:4 * n], second=d["second"][:4 * n]), uniform=True)
+    assert np.array_equal(e.filter_table(0), sub["sampled_table"])
+    e.compute_thresholds()
+    each(lambda i: e.find_trusted_kmers(shell))
+    assert e.trusted_finish() == sub["trusted_inserted"]
+    assert np.array_equal(e.filter_table(1), sub["trusted_table"])
+    each(lambda i: e.get_covariatedata(shell))
+    c = e.covariates()
+    assert np.array_equal(c["cycle"], sub["cov"]["cycle"]) and np.array_equal(c["dinuc"], sub["cov"]["dinuc"])
+    e.close()
+    assert ref["sampled_inserted"] >= sub["sampled_inserted"]
+
+
 def test_hint_arrays_do_not_change_results():
     """kbbq_reads.hint_sampled / hint_trusted only skip lookups whose answer is known."""
     import torch
