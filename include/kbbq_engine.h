@@ -243,7 +243,9 @@ int kbbq_set_dq(kbbq_engine *e, const kbbq_dq *dq); /* e.g. tables computed on a
 
 /* ---- pass 4: CReadData::recalibrate (readutils.cc:572-595) ---------------- */
 
-/* qual_out: n_bases bytes, device or host like the batch. */
+/* qual_out: n_bases bytes, device or host like the batch.  A device output is queued on the engine's stream
+ * (complete after kbbq_engine_sync, or order your own work behind kbbq_engine_stream); a host output is complete
+ * when the call returns. */
 int kbbq_recalibrate_batch(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qual_out);
 /* Same, but qual_out is always HOST memory (a device-resident batch whose new qualities go to a writer). */
 int kbbq_recalibrate_batch_host(kbbq_engine *e, const kbbq_reads *reads, uint8_t *host_qual_out);
