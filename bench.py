@@ -25,15 +25,22 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from kbbq_amd import _lib, synth  # noqa: E402
-from kbbq_amd.dist import EnginePeer, Exchange, shard_range  # noqa: E402
-from kbbq_amd.engine import Engine, plan_parameters  # noqa: E402
+# torch, numpy and the engine library are imported in _imports(), AFTER the decision to spawn ranks: the parent of a
+# self-launched multi-rank run must never load a GPU runtime (it only relays rank 0's line).
+np = torch = _lib = synth = EnginePeer = Exchange = shard_range = Engine = plan_parameters = None
+
+
+def _imports():
+    global np, torch, _lib, synth, EnginePeer, Exchange, shard_range, Engine, plan_parameters
+    import numpy as np_
+    import torch as torch_
+    from kbbq_amd import _lib as lib_, synth as synth_
+    from kbbq_amd.dist import EnginePeer as EP, Exchange as EX, shard_range as SR
+    from kbbq_amd.engine import Engine as EN, plan_parameters as PP
+    np, torch, _lib, synth, EnginePeer, Exchange, shard_range, Engine, plan_parameters = np_, torch_, lib_, synth_, EP, EX, SR, EN, PP
 
 K = int(os.environ.get("KBBQ_BENCH_K", 32))          # BASELINE configs[1]: 32; configs[4] (60x, k=21, -a 0.05) via the KBBQ_BENCH_* knobs
 ALPHA = os.environ.get("KBBQ_BENCH_ALPHA") or None     # text, parsed to long double like the command line's --alpha
@@ -186,9 +193,30 @@ def pcie_inclusive(genome_len, coverage, local_rank):
                                  sample="same batches, uploaded once and kept resident (1.4 B/base H2D, 1 B/base D2H, pageable host memory)"))
 
 
+def host_cpu():
+    """Model name, online cores and last-level cache of the box's host CPU (for the cpu_baseline line)."""
+    model, llc = "unknown", "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    for idx in (3, 2):
+        try:
+            llc = open("/sys/devices/system/cpu/cpu0/cache/index%d/size" % idx).read().strip()
+            break
+        except OSError:
+            continue
+    return model, os.cpu_count() or 0, llc
+
+
 def cpu_baseline(e, genome_len, coverage):
-    """Oracle (CPU restatement, 1 thread) on a bounded sample of the same workload."""
+    """Oracle (CPU restatement, 1 thread, built here with the reference's -O2 -march=native) on a bounded sample of
+    the same workload."""
     from oracle import pyoracle
+    native = pyoracle.use_native()
     n_reads = genome_len * coverage // READ_LEN
     sp = synth.synth_params(SEED_DATA, genome_len, n_reads, READ_LEN, n_rg=1, paired=False, n_per_million=100)
     dev = e.synth_reads(sp, 0, n_reads)
@@ -203,12 +231,50 @@ def cpu_baseline(e, genome_len, coverage):
     off = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(READ_LEN)
     alpha_ld, cov, approx = plan_parameters(genome_len, coverage, None)
     o = pyoracle.Oracle(K, alpha_ld, SEED_SAMPLER, approx)
+    filt_mb = (o.filter_info(0)["bits"] + o.filter_info(1)["bits"]) / 8e6
     t0 = time.perf_counter()
     o.run_all(seq, qual, off, None, None)
     dt = time.perf_counter() - t0
-    return dict(value=nb / dt / 1e9, unit="Gbases/s", cores=1, kind="port",
-                sample="oracle (CPU restatement), %d reads x %d bp = %.3g bases, genome %d x %dx, k=%d, %.1f s, I/O excluded"
-                       % (n_reads, READ_LEN, nb, genome_len, coverage, K, dt))
+    model, cores_online, llc = host_cpu()
+    return dict(value=nb / dt / 1e9, unit="Gbases/s", cores=1, kind="port", cpu_model=model, host_cores_online=cores_online,
+                host_llc=llc, flags="-O2 -march=native" if native else "-O2 (portable build: no compiler on this host)",
+                sample="oracle (CPU restatement of the reference, single-threaded like the reference's compute path), %d reads x %d bp = "
+                       "%.3g bases, genome %d x %dx, k=%d, both Bloom filters %.0f MB in the reference's 512-bit layout (past the "
+                       "last-level cache: %s), %.1f s, I/O excluded; the 100 Mbp slice of BASELINE.md would take ~7 min and is "
+                       "available as --cpu-genome-len 100000000"
+                       % (n_reads, READ_LEN, nb, genome_len, coverage, K, filt_mb, llc, dt))
+
+
+def spawn_ranks(n):
+    """Start `n` ranks of this script under torch.distributed.run (one per GPU, RCCL over xGMI unless
+    KBBQ_BENCH_BACKEND says otherwise), relay rank 0's JSON line to stdout, return the launcher's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    log("[launcher] %s" % " ".join(cmd))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = []
+    for ln in proc.stdout:
+        if ln.startswith("{"):
+            lines.append(ln)
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc == 0 and len(lines) != 1:
+        log("[launcher] expected one JSON line from rank 0, got %d" % len(lines))
+        rc = 1
+    for ln in lines[-1:]:
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    return rc
 
 
 def main():
@@ -218,15 +284,25 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genome-len", type=int, default=int(os.environ.get("KBBQ_BENCH_GENOME", 3_000_000_000)))
     ap.add_argument("--coverage", type=int, default=30)
-    ap.add_argument("--cpu-genome-len", type=int, default=4_000_000)
+    ap.add_argument("--cpu-genome-len", type=int, default=8_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcie", action="store_true", help="also time a bounded step with host-resident batches (PCIe-inclusive rate)")
     ap.add_argument("--pcie-genome-len", type=int, default=100_000_000)
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  It has not imported torch or the
+        # engine library and never touches a GPU; the ranks are fresh CHILD processes (no exec of this one).
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a line for a different rank count"
+                         % (args.gpus, world))
+    _imports()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     # KBBQ_BENCH_BACKEND=gloo with KBBQ_BENCH_ONE_GPU=1 runs every rank on device 0 and stages the collectives
@@ -280,6 +356,7 @@ def main():
     for _ in range(args.warmup):
         info = run_step(e, xch, batches, ordinals, out_buf, hints)
     e.profile_reset()
+    xch.reset_timers()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -362,6 +439,8 @@ def main():
             "metric": "recalibrated Gbases/sec", "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "ranks_seen": dist.get_world_size() if world > 1 else 1,
+            "exchange_ms": {k: round(v / args.steps, 2) for k, v in xch.ms.items()},
             "config": {"workload": "%dx synthetic WGS reads, genome %d bp, %d bp reads, k=%d%s (%s)"
                                    % (cov, G, READ_LEN, K, "" if ALPHA is None else ", alpha " + ALPHA,
                                       "BASELINE configs[1]" if (K, ALPHA, cov) == (32, None, 30) else "another shape than BASELINE configs[1]"),

@@ -118,6 +118,9 @@ struct kbbq_engine {
     std::vector<PendingEvent> pending;
     uint32_t *d_qcum = nullptr, *d_errthr = nullptr;
     uint32_t qcum_len = 0;
+    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: what this engine has raised on ITS device
+    size_t attr_lds_tally = 0, attr_lds_recal = 0;
+    std::map<const void *, size_t> attr_lds_correct;
 };
 
 namespace {
@@ -214,6 +217,29 @@ int sync_engine(kbbq_engine *e) {
     e->staged.clear();
     return KBBQ_OK;
 }
+
+// A host batch is the caller's again when the entry point returns, on EVERY path: error returns after staging
+// has begun, and returns that skip the kernels, still wait for the copies in flight and free the staged buffers.
+struct HostBatchDone {
+    kbbq_engine *e;
+    bool host;
+    HostBatchDone(kbbq_engine *e_, const kbbq_reads *r) : e(e_), host(r && !r->on_device) {}
+    ~HostBatchDone() {
+        if (host && (!e->staged.empty())) {
+            hipStreamSynchronize(e->stream);
+            hipStreamSynchronize(e->stream2);
+            for (size_t i = 0; i < e->staged.size(); ++i) hipFree(e->staged[i]);
+            e->staged.clear();
+        }
+    }
+};
+
+// every ABI entry that takes an engine works on the engine's device, whatever the caller's current device is
+#define ENGINE_DEVICE(e)                                                                              \
+    do {                                                                                              \
+        if (!(e)) return fail(KBBQ_EINVAL, "null engine");                                            \
+        HIP_TRY(hipSetDevice((e)->p.device));                                                         \
+    } while (0)
 
 template <typename T>
 int stage_array(kbbq_engine *e, const T *host, size_t count, size_t pad_count, const T **dev) {
@@ -425,6 +451,7 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
 
 void kbbq_engine_destroy(kbbq_engine *e) {
     if (!e) return;
+    hipSetDevice(e->p.device);
     if (e->stream) { hipStreamSynchronize(e->stream); }
     drain_profile(e);
     for (size_t i = 0; i < e->staged.size(); ++i) hipFree(e->staged[i]);
@@ -455,6 +482,7 @@ void kbbq_engine_destroy(kbbq_engine *e) {
 }
 
 int kbbq_engine_reset(kbbq_engine *e) {
+    ENGINE_DEVICE(e);
     if (!e) return fail(KBBQ_EINVAL, "null engine");
     int rc0 = sync_engine(e);     // a tally may still be adding to the histograms on the side stream
     if (rc0) return rc0;
@@ -476,6 +504,7 @@ int kbbq_engine_reset(kbbq_engine *e) {
 }
 
 int kbbq_engine_sync(kbbq_engine *e) {
+    ENGINE_DEVICE(e);
     if (!e) return fail(KBBQ_EINVAL, "null engine");
     return sync_engine(e);
 }
@@ -483,6 +512,7 @@ int kbbq_engine_sync(kbbq_engine *e) {
 void *kbbq_engine_stream(kbbq_engine *e) { return e ? (void *)e->stream : nullptr; }
 
 int kbbq_filter_info_get(kbbq_engine *e, int which, kbbq_filter_info *out) {
+    ENGINE_DEVICE(e);
     if (!e || !out || which < 0 || which > 1) return fail(KBBQ_EINVAL, "bad argument");
     const FilterSpec &s = e->filt[which].spec;
     memset(out, 0, sizeof *out);
@@ -504,6 +534,7 @@ void *kbbq_filter_device_table(kbbq_engine *e, int which) { return e && which >=
 void *kbbq_filter_device_counter(kbbq_engine *e, int which) { return e && which >= 0 && which < 2 ? e->filt[which].d_inserted : nullptr; }
 
 int kbbq_filter_download(kbbq_engine *e, int which, uint64_t *host_words, uint64_t n_words) {
+    ENGINE_DEVICE(e);
     if (!e || !host_words || which < 0 || which > 1) return fail(KBBQ_EINVAL, "bad argument");
     const uint64_t n_blocks = e->filt[which].spec.n_blocks;
     if (n_words != n_blocks * 8) return fail(KBBQ_EINVAL, "filter has %llu words", (unsigned long long)n_blocks * 8);
@@ -521,6 +552,7 @@ int kbbq_filter_download(kbbq_engine *e, int which, uint64_t *host_words, uint64
 }
 
 int kbbq_filter_patterns_download(kbbq_engine *e, int which, uint64_t *host_words) {
+    ENGINE_DEVICE(e);
     if (!e || !host_words || which < 0 || which > 1) return fail(KBBQ_EINVAL, "bad argument");
     std::vector<uint64_t> packed(kNumPatterns * 2);
     HIP_TRY(hipMemcpy(packed.data(), e->filt[which].d_patterns, kNumPatterns * kEngineBlockBytes, hipMemcpyDeviceToHost));
@@ -529,6 +561,7 @@ int kbbq_filter_patterns_download(kbbq_engine *e, int which, uint64_t *host_word
 }
 
 int kbbq_filter_or_from(kbbq_engine *e, int which, const void *src_device, uint64_t word_offset, uint64_t n_words) {
+    ENGINE_DEVICE(e);
     if (!e || !src_device || which < 0 || which > 1) return fail(KBBQ_EINVAL, "bad argument");
     const uint64_t total = e->filt[which].spec.n_blocks * 2;   // words of the engine's 128-bit blocks
     if (word_offset > total || n_words > total - word_offset || (word_offset & 1)) return fail(KBBQ_EINVAL, "range outside the filter");
@@ -541,6 +574,7 @@ int kbbq_filter_or_from(kbbq_engine *e, int which, const void *src_device, uint6
 }
 
 int kbbq_device_or(kbbq_engine *e, void *dst_device, const void *src_device, uint64_t n_words) {
+    ENGINE_DEVICE(e);
     if (!e || !dst_device || !src_device) return fail(KBBQ_EINVAL, "bad argument");
     if (((uintptr_t)dst_device | (uintptr_t)src_device) & 15) return fail(KBBQ_EINVAL, "buffers must be 16-byte aligned");
     if (!n_words) return KBBQ_OK;
@@ -553,6 +587,7 @@ int kbbq_device_or(kbbq_engine *e, void *dst_device, const void *src_device, uin
 
 int kbbq_device_or_pieces(kbbq_engine *e, void *dst_device, const void *src_device, uint64_t piece_words,
                           int32_t n_pieces, int32_t skip) {
+    ENGINE_DEVICE(e);
     if (!e || !dst_device || !src_device || n_pieces < 1) return fail(KBBQ_EINVAL, "bad argument");
     if ((((uintptr_t)dst_device | (uintptr_t)src_device) & 15) || (piece_words & 1))
         return fail(KBBQ_EINVAL, "buffers must be 16-byte aligned and pieces an even number of words");
@@ -565,6 +600,7 @@ int kbbq_device_or_pieces(kbbq_engine *e, void *dst_device, const void *src_devi
 }
 
 int kbbq_filter_set_inserted(kbbq_engine *e, int which, uint64_t inserted) {
+    ENGINE_DEVICE(e);
     if (!e || which < 0 || which > 1) return fail(KBBQ_EINVAL, "bad argument");
     HIP_TRY(hipMemcpyAsync(e->filt[which].d_inserted, &inserted, 8, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -590,8 +626,9 @@ int kbbq_pack_bases(const uint8_t *seq, uint64_t n_bases, uint64_t *bases_out, u
 }
 
 int kbbq_reads_upload(kbbq_engine *e, const kbbq_reads *host, kbbq_reads *dev) {
-    (void)e;   // may be NULL: batches can be made resident before the engine (whose size depends on them) exists
+    // e may be NULL: batches can be made resident before the engine (whose size depends on them) exists
     if (!host || !dev) return fail(KBBQ_EINVAL, "null argument");
+    if (e) HIP_TRY(hipSetDevice(e->p.device));
     if (host->on_device) return fail(KBBQ_EINVAL, "batch is already on the device");
     *dev = *host;
     dev->on_device = 1;
@@ -629,6 +666,7 @@ int kbbq_reads_free(kbbq_engine *e, kbbq_reads *dev) {
     if (!dev) return fail(KBBQ_EINVAL, "null argument");
     if (!dev->on_device) return fail(KBBQ_EINVAL, "not a device batch");
     if (e) {
+        HIP_TRY(hipSetDevice(e->p.device));
         int rc = sync_engine(e);
         if (rc) return rc;
     } else {
@@ -681,7 +719,9 @@ int kbbq_device_memory(int32_t device, uint64_t *free_bytes, uint64_t *total_byt
 
 // ---- pass 1
 int kbbq_count_kmer_positions(kbbq_engine *e, const kbbq_reads *reads, uint64_t *out) {
+    ENGINE_DEVICE(e);
     if (!e || !reads || !out) return fail(KBBQ_EINVAL, "null argument");
+    HostBatchDone host_done(e, reads);
     ReadsDev R; int max_len;
     int rc = device_view(e, reads, &R, &max_len);
     if (rc) return rc;
@@ -713,7 +753,9 @@ template <int NW> struct LaunchSample {
 extern "C" {
 
 int kbbq_sample_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t first_kmer_ordinal) {
+    ENGINE_DEVICE(e);
     if (!e) return fail(KBBQ_EINVAL, "null engine");
+    HostBatchDone host_done(e, reads);
     ReadsDev R; int max_len;
     int rc = device_view(e, reads, &R, &max_len);
     if (rc) return rc;
@@ -759,6 +801,7 @@ int kbbq_sample_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t first_km
 }
 
 int kbbq_sample_finish(kbbq_engine *e, uint64_t *inserted) {
+    ENGINE_DEVICE(e);
     if (!e) return fail(KBBQ_EINVAL, "null engine");
     int rc = sync_engine(e);
     if (rc) return rc;
@@ -769,6 +812,7 @@ int kbbq_sample_finish(kbbq_engine *e, uint64_t *inserted) {
 // ---- between passes
 int kbbq_compute_thresholds(kbbq_engine *e, const char *alpha_text, int32_t *thresholds_out, double *fpr_out,
                             char *p_text_out, size_t p_text_len) {
+    ENGINE_DEVICE(e);
     if (!e || !alpha_text) return fail(KBBQ_EINVAL, "null argument");
     int rc = sync_engine(e);
     if (rc) return rc;
@@ -787,6 +831,7 @@ int kbbq_compute_thresholds(kbbq_engine *e, const char *alpha_text, int32_t *thr
 }
 
 int kbbq_set_thresholds(kbbq_engine *e, const int32_t *thresholds, int32_t n) {
+    ENGINE_DEVICE(e);
     if (!e || !thresholds) return fail(KBBQ_EINVAL, "null argument");
     if (n != e->p.k + 1) return fail(KBBQ_EINVAL, "expected k+1 = %d thresholds", e->p.k + 1);
     if (thresholds != e->thresholds.data()) e->thresholds.assign(thresholds, thresholds + n);
@@ -842,8 +887,10 @@ static int bit_out_end(kbbq_engine *e, const kbbq_reads *reads, uint64_t *user, 
 }
 
 int kbbq_trusted_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *infer_errors_out) {
+    ENGINE_DEVICE(e);
     if (!e) return fail(KBBQ_EINVAL, "null engine");
     if (!e->thresholds_set) return fail(KBBQ_ESTATE, "thresholds are not set");
+    HostBatchDone host_done(e, reads);
     ReadsDev R; int max_len;
     int rc = device_view(e, reads, &R, &max_len);
     if (rc) return rc;
@@ -863,6 +910,7 @@ int kbbq_trusted_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *infer_
 }
 
 int kbbq_trusted_finish(kbbq_engine *e, uint64_t *inserted) {
+    ENGINE_DEVICE(e);
     if (!e) return fail(KBBQ_EINVAL, "null engine");
     int rc = sync_engine(e);
     if (rc) return rc;
@@ -893,10 +941,10 @@ static int launch_correct(kbbq_engine *e, ReadsDev R, const uint32_t *list, cons
                           uint32_t *err_bits, uint32_t *patch) {
     typedef Corrector<MAXL> C;
     const size_t lds = (size_t)C::WORDS * BLOCK * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
+    size_t &raised = e->attr_lds_correct[(const void *)k_correct<MAXL, BLOCK>];
+    if (lds > raised) {
         HIP_TRY(hipFuncSetAttribute((const void *)k_correct<MAXL, BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        raised = lds;
     }
     Timed t(e, "k_correct", e->cur);
     // the work-list length is only known on the device: size the grid for the batch and let lanes stride
@@ -956,11 +1004,10 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
     const size_t budget = (size_t)n_rg * per_rg <= 70 * 1024 ? 70 * 1024 : 140 * 1024;
     const int per_launch = compact ? (int)std::max<size_t>(1, std::min<size_t>((size_t)n_rg, budget / per_rg)) : 1;
     const size_t lds = (size_t)per_launch * per_rg + 4 + 96 + 4;
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
+    if (lds > e->attr_lds_tally) {
         HIP_TRY(hipFuncSetAttribute((const void *)k_tally<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void *)k_tally<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds = lds;
+        e->attr_lds_tally = lds;
     }
     // 16 wavefronts share one set of LDS tables: one 1024-lane block per CU, two when the tables leave room
     const uint64_t groups = (R.n_bases + 15) / 16;
@@ -991,6 +1038,7 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
 }
 
 int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_out) {
+    ENGINE_DEVICE(e);
     if (!e || !reads) return fail(KBBQ_EINVAL, "null argument");
     const bool own_err = !(errors_out && reads->on_device);
     // A device-resident batch stays put after this call returns, so it may still be in flight while the next one
@@ -1006,6 +1054,7 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
     } else {
         if ((rc = sync_engine(e))) return rc;              // (before the batch is staged: this frees staging buffers)
     }
+    HostBatchDone host_done(e, reads);
     ReadsDev R; int max_len;
     if ((rc = device_view(e, reads, &R, &max_len))) return rc;
     const int NW = max_len <= 192 ? 3 : max_len <= 320 ? 5 : 8;
@@ -1073,7 +1122,9 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
 }
 
 int kbbq_tally_batch(kbbq_engine *e, const kbbq_reads *reads, const uint64_t *errors) {
+    ENGINE_DEVICE(e);
     if (!e || !errors) return fail(KBBQ_EINVAL, "null argument");
+    HostBatchDone host_done(e, reads);
     ReadsDev R; int max_len;
     int rc = device_view(e, reads, &R, &max_len);
     if (rc) return rc;
@@ -1104,6 +1155,7 @@ static int fetch_hist(kbbq_engine *e, std::vector<uint64_t> &cyc, std::vector<ui
 }
 
 int kbbq_covariates_get(kbbq_engine *e, kbbq_covariates *out) {
+    ENGINE_DEVICE(e);
     if (!e || !out) return fail(KBBQ_EINVAL, "null argument");
     std::vector<uint64_t> cyc, di, q, rg;
     int rc = fetch_hist(e, cyc, di);
@@ -1119,6 +1171,7 @@ int kbbq_covariates_get(kbbq_engine *e, kbbq_covariates *out) {
 }
 
 int kbbq_train(kbbq_engine *e) {
+    ENGINE_DEVICE(e);
     if (!e) return fail(KBBQ_EINVAL, "null engine");
     std::vector<uint64_t> cyc, di, q, rg;
     int rc = fetch_hist(e, cyc, di);
@@ -1129,6 +1182,7 @@ int kbbq_train(kbbq_engine *e) {
 }
 
 int kbbq_dq_get(kbbq_engine *e, kbbq_dq *out) {
+    ENGINE_DEVICE(e);
     if (!e || !out) return fail(KBBQ_EINVAL, "null argument");
     if (!e->dq_set) return fail(KBBQ_ESTATE, "no delta-Q tables yet");
     const DqTables &d = e->dq;
@@ -1143,6 +1197,7 @@ int kbbq_dq_get(kbbq_engine *e, kbbq_dq *out) {
 }
 
 int kbbq_set_dq(kbbq_engine *e, const kbbq_dq *in) {
+    ENGINE_DEVICE(e);
     if (!e || !in || !in->meanq || !in->rgdq || !in->qdq || !in->cycledq || !in->dinucdq) return fail(KBBQ_EINVAL, "null argument");
     if (in->n_rg != (uint64_t)e->p.n_rg || in->n_cycle != (uint64_t)e->p.max_read_len)
         return fail(KBBQ_EINVAL, "delta-Q tables must be [%d rg][%d cycles]", e->p.n_rg, e->p.max_read_len);
@@ -1161,17 +1216,21 @@ int kbbq_set_dq(kbbq_engine *e, const kbbq_dq *in) {
 static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qual_out, bool out_on_host);
 
 int kbbq_recalibrate_batch(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qual_out) {
+    ENGINE_DEVICE(e);
     if (!reads) return fail(KBBQ_EINVAL, "null argument");
     return recalibrate_impl(e, reads, qual_out, !reads->on_device);
 }
 
 int kbbq_recalibrate_batch_host(kbbq_engine *e, const kbbq_reads *reads, uint8_t *host_qual_out) {
+    ENGINE_DEVICE(e);
     return recalibrate_impl(e, reads, host_qual_out, true);
 }
 
 static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qual_out, bool out_on_host) {
+    ENGINE_DEVICE(e);
     if (!e || !qual_out || !reads) return fail(KBBQ_EINVAL, "null argument");
     if (!e->dq_set) return fail(KBBQ_ESTATE, "no delta-Q tables yet");
+    HostBatchDone host_done(e, reads);
     ReadsDev R; int max_len;
     int rc = device_view(e, reads, &R, &max_len);
     if (rc) return rc;
@@ -1196,10 +1255,9 @@ static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qu
         const int budget = per_rg + 96 <= 64 * 1024 ? 64 * 1024 - 96 : 152 * 1024 - 96;
         const int lds_rgs = std::max(0, std::min(D.n_rg, budget / per_rg));
         const size_t lds = 96 + (size_t)lds_rgs * per_rg;
-        static size_t attr_lds = 0;
-        if (lds > attr_lds) {
+        if (lds > e->attr_lds_recal) {
             HIP_TRY(hipFuncSetAttribute((const void *)k_recalibrate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_lds = lds;
+            e->attr_lds_recal = lds;
         }
         const unsigned blocks = (unsigned)std::min<uint64_t>((lanes + 1023) / 1024, lds > 76 * 1024 ? 256 : 256 * 2);
         hipLaunchKernelGGL(k_recalibrate, dim3(blocks), dim3(1024), lds, e->stream,
@@ -1234,6 +1292,7 @@ int kbbq_synth_tables(const kbbq_synth_params *sp, uint32_t *qcum /* [read_len][
 }
 
 int kbbq_synth_reads(kbbq_engine *e, const kbbq_synth_params *sp, uint64_t first_read, uint64_t n, kbbq_reads *dev) {
+    ENGINE_DEVICE(e);
     if (!e || !sp || !dev || n == 0) return fail(KBBQ_EINVAL, "bad argument");
     if (sp->read_len == 0 || sp->genome_len < sp->read_len || sp->n_rg == 0) return fail(KBBQ_EINVAL, "bad synthetic parameters");
     if (e->qcum_len != sp->read_len) {
@@ -1276,6 +1335,7 @@ int kbbq_synth_reads(kbbq_engine *e, const kbbq_synth_params *sp, uint64_t first
 
 // ---- measurement
 int kbbq_profile_get(kbbq_engine *e, kbbq_profile_entry *out, int32_t max_entries, int32_t *n_out) {
+    ENGINE_DEVICE(e);
     if (!e || !n_out) return fail(KBBQ_EINVAL, "null argument");
     int rc = sync_engine(e);
     if (rc) return rc;
@@ -1291,6 +1351,7 @@ int kbbq_profile_get(kbbq_engine *e, kbbq_profile_entry *out, int32_t max_entrie
 }
 
 int kbbq_profile_reset(kbbq_engine *e) {
+    ENGINE_DEVICE(e);
     if (!e) return fail(KBBQ_EINVAL, "null engine");
     int rc = sync_engine(e);
     if (rc) return rc;
@@ -1299,6 +1360,7 @@ int kbbq_profile_reset(kbbq_engine *e) {
 }
 
 int kbbq_stats_get(kbbq_engine *e, uint64_t *out, int32_t n) {
+    ENGINE_DEVICE(e);
     if (!e || !out) return fail(KBBQ_EINVAL, "null argument");
     int rc = sync_engine(e);      // batches of pass 3 may still be in flight; their counters are collected here
     if (rc) return rc;

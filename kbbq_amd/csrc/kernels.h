@@ -935,8 +935,10 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
             if ((threadIdx.x & 63) == 0 && tot) atomicAdd(l_reads, tot);
         }
         __syncthreads();
-        if (*l_reads >= 40000u || it + 1 == iters) {
-            __syncthreads();
+        // a block-uniform decision: everyone reads the counter before anyone may add to it again (next iteration)
+        const bool flush = *l_reads >= 40000u || it + 1 == iters;
+        __syncthreads();
+        if (flush) {
             for (int lr = 0; lr < P.n_rgs; ++lr) {
                 uint32_t *t = lds + lr * per_rg;
                 const int rg = P.rg_base + lr;

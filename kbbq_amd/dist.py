@@ -20,6 +20,9 @@ array instead of the (N-1) arrays of a gather-everything scheme.
 The functions take torch tensors and a process group, so the same code runs on
 `nccl` (= RCCL) with device tensors and on `gloo` with CPU tensors (tests).
 """
+import contextlib
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -31,12 +34,19 @@ def world(group=None):
     return dist.get_rank(group), dist.get_world_size(group)
 
 
-def or_allreduce_(t, or_into, slab_words=1 << 27, group=None, or_pieces=None, force=False):
-    """In-place bitwise-OR all-reduce of a 1-D int64 tensor.
+def or_allreduce_(t, or_into, slab_words=1 << 26, group=None, or_pieces=None, force=False, stream=None):
+    """In-place bitwise-OR all-reduce of a 1-D int64 tensor, software-pipelined over slabs.
 
     or_into(dst, src): dst |= src for two equally long int64 tensors (the HIP
     kernel on a GPU, tensor.bitwise_or_ on the CPU).  or_pieces(dst, recv, piece, n, skip), when
     given, ORs all n-1 foreign pieces of `recv` into dst in one launch.
+
+    Pipeline (two receive buffers): the all_to_all of slab s+1 is issued BEFORE the OR of slab s, so on RCCL
+    (collectives run on the communicator's own stream, in issue order) the links move slab s+1 while the OR kernel
+    reduces slab s; the all_gather of slab s follows.  `stream` (a torch stream wrapping the engine's HIP stream)
+    is made current for the whole exchange: work.wait() then orders that stream behind a collective and every
+    collective behind the kernels queued on it so far -- no host-side synchronisation inside the loop.  On gloo
+    (CPU tensors) wait() blocks the host and the same code is simply sequential.
     """
     rank, n = world(group)
     if n == 1 and not force:      # force: run the collectives anyway (single-rank plumbing check)
@@ -46,30 +56,44 @@ def or_allreduce_(t, or_into, slab_words=1 << 27, group=None, or_pieces=None, fo
     piece = max(2, (min(slab_words, total) + n - 1) // n)
     piece += piece & 1                     # keep pieces 16-byte aligned
     slab = piece * n
-    recv = torch.empty(slab, dtype=torch.int64, device=t.device)
-    mine = torch.empty(piece, dtype=torch.int64, device=t.device)
-    pad = None
-    for s in range(0, total, slab):
-        ln = min(slab, total - s)
-        if ln == slab:
-            view = t[s:s + slab]
-        else:
-            if pad is None:
-                pad = torch.zeros(slab, dtype=torch.int64, device=t.device)
-            pad[:ln].copy_(t[s:s + ln])
-            pad[ln:].zero_()
-            view = pad
-        dist.all_to_all_single(recv, view, group=group)
-        mine.copy_(recv[rank * piece:(rank + 1) * piece])
-        if or_pieces is not None:
-            or_pieces(mine, recv, piece, n, rank)
-        else:
-            for j in range(n):
-                if j != rank:
-                    or_into(mine, recv[j * piece:(j + 1) * piece])
-        dist.all_gather_into_tensor(view, mine, group=group)
-        if ln != slab:
-            t[s:s + ln].copy_(pad[:ln])
+    n_slabs = (total + slab - 1) // slab
+    ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+    with ctx:
+        recv = [torch.empty(slab, dtype=torch.int64, device=t.device) for _ in range(min(2, n_slabs))]
+        mine = [torch.empty(piece, dtype=torch.int64, device=t.device) for _ in range(min(2, n_slabs))]
+        pad = None
+        tail = total - (n_slabs - 1) * slab
+        if tail != slab:                   # the ragged last slab travels through a zero-padded copy
+            pad = torch.zeros(slab, dtype=torch.int64, device=t.device)
+            pad[:tail].copy_(t[total - tail:])
+
+        def view_of(s):
+            return pad if (s == n_slabs - 1 and pad is not None) else t[s * slab:(s + 1) * slab]
+
+        def start_a2a(s):
+            return dist.all_to_all_single(recv[s & 1], view_of(s), group=group, async_op=True)
+
+        gathers = []
+        w = start_a2a(0)
+        for s in range(n_slabs):
+            w_next = start_a2a(s + 1) if s + 1 < n_slabs else None
+            w.wait()
+            r, m = recv[s & 1], mine[s & 1]
+            m.copy_(r[rank * piece:(rank + 1) * piece])
+            if or_pieces is not None:
+                or_pieces(m, r, piece, n, rank)
+            else:
+                for j in range(n):
+                    if j != rank:
+                        or_into(m, r[j * piece:(j + 1) * piece])
+            gathers.append(dist.all_gather_into_tensor(view_of(s), m, group=group, async_op=True))
+            if len(gathers) > 2:           # keeps the handle list short; its buffers were reused safely anyway
+                gathers.pop(0).wait()
+            w = w_next
+        for g in gathers:
+            g.wait()
+        if pad is not None:
+            t[total - tail:].copy_(pad[:tail])
     return t
 
 
@@ -97,7 +121,7 @@ class Exchange:
     aliasing the tallied histograms, train() -> dict of int32 arrays, set_dq(dict), quiesce().
     """
 
-    def __init__(self, peer, group=None, slab_words=1 << 27, device=None, force=False, stage_host=False):
+    def __init__(self, peer, group=None, slab_words=1 << 26, device=None, force=False, stage_host=False):
         self.peer = peer
         self.group = group
         self.slab_words = slab_words
@@ -107,6 +131,12 @@ class Exchange:
         # stage_host: the peer's tensors live on a GPU but the process group cannot move device memory (gloo):
         # copy to the host, reduce there, copy back.  Lets several ranks share one GPU in the tests.
         self.stage_host = stage_host
+        # host wall-clock spent in the exchange steps since the last reset_timers() (each step ends synchronised)
+        self.ms = {"filter0": 0.0, "filter1": 0.0, "histograms": 0.0, "broadcast": 0.0}
+
+    def reset_timers(self):
+        for k in self.ms:
+            self.ms[k] = 0.0
 
     def _reduce(self, t, fn):
         if not self.stage_host:
@@ -124,25 +154,30 @@ class Exchange:
         if self.n == 1 and not self.force:
             return local
         self.peer.quiesce()
+        t0 = time.perf_counter()
         if self.stage_host:
             self._reduce(self.peer.table_tensor(which),
                          lambda c: or_allreduce_(c, lambda dst, src: dst.bitwise_or_(src), self.slab_words, self.group, None, force=self.force))
         else:
+            stream = self.peer.torch_stream() if hasattr(self.peer, "torch_stream") else None
             or_allreduce_(self.peer.table_tensor(which), self.peer.or_into, self.slab_words, self.group,
-                          getattr(self.peer, "or_pieces", None), force=self.force)
+                          getattr(self.peer, "or_pieces", None), force=self.force, stream=stream)
         cnt = torch.tensor([local], dtype=torch.int64, device=self.device)
         sum_allreduce_(cnt, self.group)
         total = int(cnt.item())
         self.peer.quiesce()
         self.peer.set_inserted(which, total)
+        self.ms["filter%d" % which] += (time.perf_counter() - t0) * 1e3
         return total
 
     def histograms_done(self):
         if self.n == 1 and not self.force:
             return
         self.peer.quiesce()
+        t0 = time.perf_counter()
         self._reduce(self.peer.hist_tensor(), lambda c: sum_allreduce_(c, self.group))
         self.peer.quiesce()
+        self.ms["histograms"] += (time.perf_counter() - t0) * 1e3
 
     def train_and_share(self):
         """Rank 0 trains (host, long double), the int32 tables are broadcast and installed everywhere."""
@@ -156,10 +191,12 @@ class Exchange:
         else:
             shapes = self.peer.dq_shapes()
             flat = torch.empty(int(sum(int(np.prod(s)) for s in shapes)), dtype=torch.int32)
+        t0 = time.perf_counter()
         if self.device is not None:
             flat = flat.to(self.device)
         dist.broadcast(flat, src=0, group=self.group)
         flat = flat.cpu().numpy()
+        self.ms["broadcast"] += (time.perf_counter() - t0) * 1e3
         out, pos = {}, 0
         for k, s in zip(keys, shapes):
             cnt = int(np.prod(s))
@@ -177,6 +214,7 @@ class EnginePeer:
         from .engine import device_tensor
         self.e = engine
         self._dt = device_tensor
+        self._stream = None
 
     def quiesce(self):
         self.e.sync()
@@ -187,17 +225,21 @@ class EnginePeer:
         return self._dt(self.e.L.kbbq_filter_device_table(self.e.h, which), info["table_bytes"], torch.int64,
                         self.e.params.device)
 
+    def torch_stream(self):
+        """The engine's HIP stream as a torch stream: collectives issued under it are ordered against the engine's
+        kernels by events, not by host-side waits."""
+        if self._stream is None:
+            self._stream = torch.cuda.ExternalStream(self.e.stream_ptr(), device=torch.device("cuda", self.e.params.device))
+        return self._stream
+
+    # the OR kernels are queued on the engine's stream; or_allreduce_ runs with that stream current
     def or_into(self, dst, src):
         from . import _lib
-        torch.cuda.synchronize()
         _lib.check(self.e.L.kbbq_device_or(self.e.h, dst.data_ptr(), src.data_ptr(), dst.numel()))
-        self.e.sync()
 
     def or_pieces(self, dst, recv, piece, n, skip):
         from . import _lib
-        torch.cuda.synchronize()
         _lib.check(self.e.L.kbbq_device_or_pieces(self.e.h, dst.data_ptr(), recv.data_ptr(), piece, n, skip))
-        self.e.sync()
 
     def get_inserted(self, which):
         return self.e.filter_info(which)["inserted"]

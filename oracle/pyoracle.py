@@ -23,18 +23,37 @@ c_dbl = ctypes.c_double
 NQ = 94
 
 
-def build(force=False):
-    so = os.path.join(_HERE, "liboracle.so")
+_NATIVE = False
+
+
+def build(force=False, native=False):
+    """liboracle.so (portable -O2: what travels to the GPU box) or liboracle_native.so (-O2 -march=native, the
+    reference's own flags, CMakeLists.txt:19 -- built on the machine that runs it, never shipped)."""
+    name = "liboracle_native.so" if native else "liboracle.so"
+    so = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "kbbq_oracle.cc")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    if force or native or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-B" if (force or native) else "-s", "-C", _HERE, name], stdout=subprocess.DEVNULL)
     return so
+
+
+def use_native():
+    """Make lib() load a -march=native build compiled on THIS host (bench.py's cpu_baseline leg).  Must be called
+    before the first lib(); returns False (and keeps the portable build) when the compiler is not there."""
+    global _NATIVE
+    assert _LIB is None, "use_native() must come before the first lib()"
+    try:
+        build(native=True)
+        _NATIVE = True
+    except (OSError, subprocess.CalledProcessError):
+        _NATIVE = False
+    return _NATIVE
 
 
 def lib():
     global _LIB
     if _LIB is None:
-        L = ctypes.CDLL(build())
+        L = ctypes.CDLL(build(native=_NATIVE))
         L.ko_new.restype = ctypes.c_void_p
         L.ko_new.argtypes = [ctypes.c_int, ctypes.c_char_p, c_u32, c_u64, c_dbl, c_dbl, c_u64]
         L.ko_free.argtypes = [ctypes.c_void_p]

@@ -37,24 +37,23 @@ def test_bench_prints_one_contract_line():
 
 
 def test_bench_two_ranks_reproduce_one_rank():
-    """The N > 1 path of bench.py as the driver launches it (torch.distributed.run, one process per rank), here
-    with both ranks on the one GPU of the box and gloo instead of RCCL: shards, ordinals, the three exchange steps
-    and the digest must give the N = 1 answer."""
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    """The N > 1 path of bench.py launched the plain way -- `python bench.py --gpus 2`, no torchrun: the script
+    spawns its own ranks before it touches a GPU -- here with both ranks on the one GPU of the box and gloo instead
+    of RCCL: shards, ordinals, the three exchange steps and the digest must give the N = 1 answer."""
     common_args = ["--steps", "1", "--warmup", "0", "--genome-len", "30000000", "--no-cpu-baseline"]
     one = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common_args, cwd=common.ROOT, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-2000:]
     env = dict(os.environ, KBBQ_BENCH_BACKEND="gloo", KBBQ_BENCH_ONE_GPU="1")
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), "bench.py", "--gpus", "2"] + common_args,
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    two = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + common_args,
                          cwd=common.ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert two.returncode == 0, two.stderr[-3000:]
+    assert len([ln for ln in two.stdout.splitlines() if ln.strip()]) == 1      # the launcher relays rank 0's line only
     a = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     b = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
-    assert b["n_gpus"] == 2 and "x2" in b["config"]["parallelism"]
+    assert a["n_gpus"] == 1 and a["ranks_seen"] == 1
+    assert b["n_gpus"] == 2 and b["ranks_seen"] == 2 and "x2" in b["config"]["parallelism"]
+    assert set(b["exchange_ms"]) == {"filter0", "filter1", "histograms", "broadcast"} and b["exchange_ms"]["filter1"] > 0
     for key in ("sampled_inserted", "trusted_inserted", "fpr", "recal_qual_sum"):
         assert a["result"][key] == b["result"][key], key

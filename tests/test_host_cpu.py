@@ -302,3 +302,12 @@ def test_block_index_is_the_exact_remainder():
         hs += [(2 ** 32 // d) * d % 2 ** 32, ((2 ** 32 // d) * d - 1) % 2 ** 32] if d <= 2 ** 32 else []
         for h in hs:
             assert L.kbbq_host_block_index(h, d) == h % d, (h, d)
+
+
+def test_bench_refuses_a_rank_count_it_was_not_launched_with():
+    """bench.py --gpus N under a launcher with another WORLD_SIZE must not print a line (checked before any GPU use)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE=3" in out.stderr and not out.stdout.strip()

@@ -9,6 +9,7 @@ The read-level functions (infer_read_errors, get_errors, ...) have no reference 
 "parity unpinned" beyond these anchors.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -210,3 +211,24 @@ def test_pattern_table_equals_real_libstdcxx(filters, R):
         ref = np.zeros(65536 * 8, dtype=np.uint64)
         R.ref_pattern_table(3061464579, nsalt, ref.ctypes.data_as(pyoracle.u64p))
         assert np.array_equal(filters.filter_patterns(which), ref)
+
+
+def test_native_build_of_the_oracle_equals_the_portable_one(tmp_path):
+    """bench.py's cpu_baseline times an -O2 -march=native build of the oracle (the reference's flags,
+    CMakeLists.txt:19), compiled on the host that runs it; its results must be those of the portable build."""
+    import subprocess
+    import sys
+    import common
+    d = common.make_dataset(seed=5150, genome_len=20000, coverage=20, n_rg=2, paired=True, extra_errors=40)
+    a = common.run_oracle(d, n_rg=2)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); from oracle import pyoracle; "
+            "assert pyoracle.use_native(); import common; "
+            "d = common.make_dataset(seed=5150, genome_len=20000, coverage=20, n_rg=2, paired=True, extra_errors=40); "
+            "o = common.run_oracle(d, n_rg=2); "
+            "np.savez(%r, recal=o['recal'], errors=o['errors'], t0=o['sampled_table'], t1=o['trusted_table'], p=np.frombuffer(o['p_text'].encode(), dtype=np.uint8))"
+            % (common.ROOT, os.path.join(common.ROOT, "tests"), str(tmp_path / "n.npz")))
+    subprocess.run([sys.executable, "-c", code], check=True, timeout=600)
+    b = np.load(str(tmp_path / "n.npz"))
+    assert np.array_equal(a["recal"], b["recal"]) and np.array_equal(a["errors"], b["errors"])
+    assert np.array_equal(a["sampled_table"], b["t0"]) and np.array_equal(a["trusted_table"], b["t1"])
+    assert a["p_text"] == b["p"].tobytes().decode()
