@@ -84,6 +84,66 @@ def run_step(e, xch, batches, ordinals, out_buf, hints):
     return dict(sampled_inserted=sampled, trusted_inserted=trusted, fpr=fpr, fpr_too_high=too_high)
 
 
+def emulate_rank(e, batches, ordinals, mine, out_buf, hints, emu, args, G, cov):
+    """Per-rank compute of rank R in an N-rank strong-scaling job, measured on ONE GPU (diagnostic, not the metric).
+
+    What a rank does between the exchanges is timed on its shard with the filters in the state they have at that
+    point of the real job: pass 1 into EMPTY filters (the young-filter regime of the inserts), pass 2 against the
+    GLOBAL sampled filter (the other shards' pass 1 runs untimed in between: that is what the OR all-reduce
+    delivers) into a trusted filter that holds this shard only, pass 3 against the global trusted filter, the
+    model, pass 4.  The exchanges themselves are not in it (priced from bytes and link rates in DESIGN.md)."""
+    t = {}
+    kern = {}
+
+    def timed(name, fn):
+        e.sync()
+        e.profile_reset()
+        t0 = time.perf_counter()
+        fn()
+        e.sync()
+        t[name] = t.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+        for k, (n, ms) in e.profile().items():
+            a = kern.setdefault(k, [0, 0.0])
+            a[0] += n
+            a[1] += ms
+
+    sel = [(b, o) for b, o, m in zip(batches, ordinals, mine) if m]
+    rest = [(b, o) for b, o, m in zip(batches, ordinals, mine) if not m]
+    for step in range(args.warmup + args.steps):
+        if step == args.warmup:
+            t.clear()
+            kern.clear()
+        e.reset()
+        hints.zero_()
+        torch.cuda.synchronize()
+        timed("pass1", lambda: ([e.subsample_kmers(b, o) for b, o in sel], e.sample_finish()))
+        for b, o in rest:
+            e.subsample_kmers(b, o)
+        e.sample_finish()
+        e.compute_thresholds()
+        timed("pass2", lambda: ([e.find_trusted_kmers(b) for b, _ in sel], e.trusted_finish()))
+        for b, _ in rest:
+            e.find_trusted_kmers(b)
+        e.trusted_finish()
+        timed("pass3", lambda: [e.get_covariatedata(b) for b, _ in sel])
+        for b, _ in rest:
+            e.get_covariatedata(b)
+        timed("model", lambda: e.get_dqs())
+        timed("pass4", lambda: [e.recalibrate(b, out_buf.data_ptr()) for b, _ in sel])
+    n = args.steps
+    shard_bases = sum(b.n_bases for b, _ in sel)
+    total = sum(t.values()) / n
+    print(json.dumps({
+        "metric": "DIAGNOSTIC: per-rank compute of rank %d/%d of the strong-scaling job, emulated on one GPU "
+                  "(filters in their real state per pass, exchanges excluded)" % emu,
+        "value": None, "shard_bases": shard_bases, "shard_batches": len(sel), "rank_compute_ms": round(total, 2),
+        "pass_ms": {k: round(v / n, 2) for k, v in t.items()},
+        "ideal_ms_note": "1/N of the N=1 step",
+        "overlap": not os.environ.get("KBBQ_NO_OVERLAP"), "bucketed_inserts": e.stats()["bucket_capacity"] > 0,
+        "kernels": {k: {"launches": v[0] // n, "avg_ms": round(v[1] / max(1, v[0]), 4)} for k, v in kern.items() if v[0]},
+        "config": {"workload": "%dx synthetic WGS reads, genome %d bp, %d bp reads, k=%d" % (cov, G, READ_LEN, K)}}), flush=True)
+
+
 def kernel_model(name, bases, nk, alpha, f_t, walk_queries=0.0):
     """Algorithmic HBM bytes one launch over `bases` bases / `nk` k-mer positions moves
     (packed bases 0.25 B, quals 1 B, Bloom query 64 B, insert 64 B + 64 B).
@@ -288,6 +348,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcie", action="store_true", help="also time a bounded step with host-resident batches (PCIe-inclusive rate)")
     ap.add_argument("--pcie-genome-len", type=int, default=100_000_000)
+    ap.add_argument("--emulate-shard", default=None, metavar="R/N",
+                    help="diagnostic: one process runs rank R's shard of an N-rank job (fresh filters, no collectives) -- "
+                         "the per-rank compute of the strong-scaling curve, measured on one GPU")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -323,6 +386,12 @@ def main():
     n_reads_total = G * cov // READ_LEN
     alpha_ld, cov, approx = plan_parameters(G, cov, ALPHA)
     a, b = shard_range(n_reads_total, rank, world)
+    emu = None
+    if args.emulate_shard:
+        if world != 1:
+            raise SystemExit("--emulate-shard is a one-process diagnostic")
+        emu = tuple(int(x) for x in args.emulate_shard.split("/"))
+        emu_range = shard_range(n_reads_total, emu[0], emu[1])      # all reads are generated; the shard is a sub-range
     n_local = b - a
     nk_per_read = READ_LEN - K + 1
     log("[rank %d] reads %d..%d of %d, alpha %.6f, approx_kmers %d" % (rank, a, b, n_reads_total, float(alpha_ld), approx))
@@ -336,11 +405,14 @@ def main():
     hint_bytes = (n_local * READ_LEN // 64 + 2) * 8
     hints = torch.zeros(2 * hint_bytes, dtype=torch.uint8, device="cuda")
     shard.set_hints(hints.data_ptr(), hints.data_ptr() + hint_bytes)
-    batches, ordinals = [], []
-    for s in range(0, n_local, BATCH_READS):
-        n = min(BATCH_READS, n_local - s)
-        batches.append(shard.view(s, n))
-        ordinals.append((a + s) * nk_per_read)
+    batches, ordinals, mine = [], [], []
+    cuts = [0, n_local] if not emu else sorted({0, emu_range[0], emu_range[1], n_local})
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        for s in range(lo, hi, BATCH_READS):
+            n = min(BATCH_READS, hi - s)
+            batches.append(shard.view(s, n))
+            ordinals.append((a + s) * nk_per_read)
+            mine.append(bool(emu) and emu_range[0] <= s < emu_range[1])
     out_buf = torch.empty(min(BATCH_READS, n_local) * READ_LEN + 16, dtype=torch.uint8, device="cuda")
     xch = Exchange(EnginePeer(e), device=torch.device("cuda", local_rank) if backend == "nccl" else None,
                    stage_host=backend != "nccl")
@@ -352,6 +424,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if emu:
+        emulate_rank(e, batches, ordinals, mine, out_buf, hints, emu, args, G, cov)
+        shard.free()
+        e.close()
+        return
     info = None
     for _ in range(args.warmup):
         info = run_step(e, xch, batches, ordinals, out_buf, hints)
@@ -424,7 +501,13 @@ def main():
                                 "FETCH_SIZE counts the 128-byte requests of gfx950's L2 as 64 bytes" % (BATCH_READS, pmc["summary_file"], launches_per_step))
         except (OSError, ValueError, KeyError):
             pass
-        roof = dict(bound="hbm", kernel=dom, achieved=kernels[dom]["achieved_GBps"], peak=HBM_PEAK_GBPS, unit="GB/s",
+        # bytes the dominant kernel NEEDS: its share of the reads plus 16 bytes (one 128-bit block) per Bloom lookup it
+        # really issued (counted by the kernel); the L2 fetches a 128-byte line for each, which is what `traffic` shows
+        useful = None
+        if dom == "k_infer" and stats.get("infer_lookups"):
+            per_launch = kernels[dom]["launches"] // args.steps
+            useful = round(n_local * READ_LEN * 1.25 / per_launch + 16.0 * stats["infer_lookups"] / per_launch)
+        roof = dict(bound="hbm", kernel=dom, useful_bytes=useful, achieved=kernels[dom]["achieved_GBps"], peak=HBM_PEAK_GBPS, unit="GB/s",
                     frac=round(kernels[dom]["achieved_GBps"] / HBM_PEAK_GBPS, 4), traffic=traffic,
                     algorithmic_bytes_per_launch=kernels[dom]["alg_bytes_per_launch"], avg_launch_ms=kernels[dom]["avg_ms"],
                     traffic_note=traffic_note,
@@ -453,6 +536,10 @@ def main():
                        "fpr": info["fpr"], "corrected_reads_per_step": stats["corrected_reads"],
                        "correction_queries_per_step": stats["correction_queries"],
                        "recal_qual_sum": digest},
+            # slice-bucketed inserts (kbbq_amd/csrc/bucket.h): records gathered per flush, flushes per step and filter,
+            # records that overflowed a region and were inserted directly
+            "bucketed_inserts": {"records_per_flush": stats["bucket_capacity"], "flushes_per_step": list(stats["bucket_flushes"]),
+                                 "direct_fallback_records": stats["bucket_direct"]},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(e, args.cpu_genome_len, cov)

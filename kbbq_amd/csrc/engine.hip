@@ -37,6 +37,7 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 #include "kernels.h"
+#include "bucket.h"
 
 // ============================================================ engine object
 
@@ -118,6 +119,20 @@ struct kbbq_engine {
     std::vector<PendingEvent> pending;
     uint32_t *d_qcum = nullptr, *d_errthr = nullptr;
     uint32_t qcum_len = 0;
+    // slice-bucketed inserts (bucket.h): record buffers shared by the two filters (a pass inserts into one)
+    struct Buckets {
+        int mode[2] = {-1, -1};          // -1 undecided, 0 direct inserts (k_insert_marked), 1 bucketed
+        bool allocated = false;
+        uint64_t capacity = 0;           // records gathered between two flushes
+        void *l1 = nullptr, *l2 = nullptr;
+        uint32_t *l1_cnt = nullptr, *l2_cnt = nullptr, *tickets = nullptr;
+        unsigned long long *direct = nullptr;
+        bool pending[2] = {false, false};
+        double pending_est[2] = {0, 0};  // estimated records since the last flush
+        double frac_trusted = 0.75;      // trusted inserts per base, learnt at every flush
+        uint64_t bases_since[2] = {0, 0}, inserted_at_flush[2] = {0, 0};
+        uint64_t flushes[2] = {0, 0};
+    } bk;
     // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: what this engine has raised on ITS device
     size_t attr_lds_tally = 0, attr_lds_recal = 0;
     std::map<const void *, size_t> attr_lds_correct;
@@ -362,6 +377,143 @@ int upload_dq(kbbq_engine *e) {
     return KBBQ_OK;
 }
 
+// ---- slice-bucketed inserts, host side (bucket.h) ----------------------------------------------------------
+uint64_t env_u64(const char *name, uint64_t dflt) {
+    const char *v = getenv(name);
+    return v && *v ? strtoull(v, nullptr, 10) : dflt;
+}
+
+void bucket_shape(uint64_t n_blocks, uint64_t capacity, uint32_t *n_sub, int *nb1, uint32_t *cap1, uint32_t *cap2) {
+    *n_sub = (uint32_t)((n_blocks + SUB_BLOCKS - 1) >> SUB_BITS);
+    *nb1 = (int)((*n_sub + NB2 - 1) >> NB2_BITS);
+    // Regions are sized for evenly spread hashes: a full level-1 bucket receives 2^21 / n_blocks of the records (an
+    // eighth of that per XCD), a full subslice 2^12 / n_blocks; plus 15 % (the XCDs' shares of the work differ a
+    // little) and 25 % (a few thousand records per subslice).  What does not fit is inserted directly.
+    const double f1 = std::min(1.0, (double)(1ULL << L1_SHIFT) / (double)n_blocks), f2 = std::min(1.0, (double)SUB_BLOCKS / (double)n_blocks);
+    *cap1 = (uint32_t)std::min(4.0e9, (double)capacity * 1.15 * f1 / N_XCD) + 64;
+    *cap2 = (uint32_t)std::min(4.0e9, (double)capacity * 1.25 * f2) + 32;
+}
+
+BucketDev bucket_dev(kbbq_engine *e, int w) {
+    BucketDev B;
+    bucket_shape(e->filt[w].spec.n_blocks, e->bk.capacity, &B.n_sub, &B.nb1, &B.cap1, &B.cap2);
+    B.l1 = (unsigned long long *)e->bk.l1;
+    B.l2 = (uint32_t *)e->bk.l2;
+    B.l1_cnt = e->bk.l1_cnt;
+    B.l2_cnt = e->bk.l2_cnt;
+    B.tickets = e->bk.tickets;
+    B.direct = e->bk.direct;
+    return B;
+}
+
+const size_t kL1CntBytes = (size_t)N_XCD * MAX_NB1 * CNT_STRIDE * 4, kL2CntBytes = (size_t)MAX_NB1 * NB2 * 4, kTicketBytes = (size_t)N_XCD * CNT_STRIDE * 4;
+
+// Decide (once per filter) whether its inserts are bucketed, and allocate the record buffers at the first use:
+// by then the caller's resident batches are in HBM, so "a share of what is free" is a safe size.
+bool bucket_on(kbbq_engine *e, int w) {
+    kbbq_engine::Buckets &b = e->bk;
+    if (b.mode[w] >= 0) return b.mode[w] == 1;
+    const char *env = getenv("KBBQ_BUCKET");      // 0: always direct, 1: always bucketed; default: by filter size
+    const uint64_t n_blocks = e->filt[w].spec.n_blocks;
+    bool want = env && *env ? atoi(env) != 0 : e->filt[w].table_bytes() >= (256u << 20);
+    if (n_blocks > ((uint64_t)MAX_NB1 << L1_SHIFT)) want = false;
+    if (want && !b.allocated) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        const uint64_t big = std::max(e->filt[0].spec.n_blocks, e->filt[1].spec.n_blocks);
+        uint64_t cap = (uint64_t)((double)free_b * 0.45 / 14.5);
+        cap = std::min<uint64_t>(cap, 4000000000ULL);
+        cap = std::min<uint64_t>(cap, std::max<uint64_t>(1u << 20, 32 * big));
+        cap = env_u64("KBBQ_BUCKET_RECORDS", cap);
+        cap = std::max<uint64_t>(cap, 4096);
+        size_t l1_bytes = 0, l2_bytes = 0;
+        for (int f = 0; f < 2; ++f) {
+            uint32_t n_sub, cap1, cap2; int nb1;
+            bucket_shape(e->filt[f].spec.n_blocks, cap, &n_sub, &nb1, &cap1, &cap2);
+            l1_bytes = std::max(l1_bytes, (size_t)N_XCD * nb1 * cap1 * 8);
+            l2_bytes = std::max(l2_bytes, (size_t)n_sub * cap2 * 4);
+        }
+        hipError_t he = hipMalloc(&b.l1, l1_bytes);
+        if (he == hipSuccess) he = hipMalloc(&b.l2, l2_bytes);
+        if (he == hipSuccess) he = hipMalloc(&b.l1_cnt, kL1CntBytes);
+        if (he == hipSuccess) he = hipMalloc(&b.l2_cnt, kL2CntBytes);
+        if (he == hipSuccess) he = hipMalloc(&b.tickets, kTicketBytes);
+        if (he == hipSuccess) he = hipMalloc(&b.direct, 8);
+        if (he == hipSuccess) he = hipMemsetAsync(b.l1_cnt, 0, kL1CntBytes, e->stream);
+        if (he == hipSuccess) he = hipMemsetAsync(b.l2_cnt, 0, kL2CntBytes, e->stream);
+        if (he == hipSuccess) he = hipMemsetAsync(b.direct, 0, 8, e->stream);
+        if (he != hipSuccess) {      // no room: the direct path needs none
+            (void)hipGetLastError();
+            hipFree(b.l1); hipFree(b.l2); hipFree(b.l1_cnt); hipFree(b.l2_cnt); hipFree(b.tickets); hipFree(b.direct);
+            b.l1 = b.l2 = nullptr; b.l1_cnt = b.l2_cnt = b.tickets = nullptr; b.direct = nullptr;
+            want = false;
+            b.mode[0] = b.mode[1] = 0;
+        } else {
+            b.allocated = true;
+            b.capacity = cap;
+        }
+    }
+    if (b.mode[w] < 0) b.mode[w] = want ? 1 : 0;
+    return b.mode[w] == 1;
+}
+
+// Partition the gathered records of filter w by subslice and OR them into the filter (k_split, k_apply).
+int bucket_flush(kbbq_engine *e, int w) {
+    kbbq_engine::Buckets &b = e->bk;
+    if (!b.pending[w]) return KBBQ_OK;
+    const BucketDev B = bucket_dev(e, w);
+    const FiltDev F = e->filt[w].dev();
+    HIP_TRY(hipMemsetAsync(b.tickets, 0, kTicketBytes, e->stream));
+    {
+        Timed t(e, w ? "k_split_trusted" : "k_split_sampled");
+        const uint32_t chunks = (B.cap1 + SPLIT_TILE - 1) / SPLIT_TILE;
+        hipLaunchKernelGGL(k_split, dim3(256 * 3), dim3(BK_THREADS), 0, e->stream, F, B, chunks);
+        HIP_TRY(hipGetLastError());
+    }
+    {
+        Timed t(e, w ? "k_apply_trusted" : "k_apply_sampled");
+        hipLaunchKernelGGL(k_apply, dim3(B.n_sub), dim3(APPLY_THREADS), 0, e->stream, F, B);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemsetAsync(b.l1_cnt, 0, kL1CntBytes, e->stream));
+    HIP_TRY(hipMemsetAsync(b.l2_cnt, 0, (size_t)B.nb1 * NB2 * 4, e->stream));
+    // how many records that was (the insert counter counts every one): the estimate that times the next flush
+    if (w == 1) {
+        unsigned long long now = 0;
+        HIP_TRY(hipMemcpyAsync(&now, e->filt[1].d_inserted, 8, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (b.bases_since[1] > 0 && now >= b.inserted_at_flush[1])
+            b.frac_trusted = std::min(1.0, 1.03 * (double)(now - b.inserted_at_flush[1]) / (double)b.bases_since[1] + 0.005);
+        b.inserted_at_flush[1] = now;
+    }
+    b.bases_since[w] = 0;
+    b.pending[w] = false;
+    b.pending_est[w] = 0;
+    b.flushes[w] += 1;
+    return KBBQ_OK;
+}
+
+// before filter w is read, sized up, exchanged or reset
+int bucket_flush_all(kbbq_engine *e) {
+    for (int w = 0; w < 2; ++w) {
+        int rc = bucket_flush(e, w);
+        if (rc) return rc;
+    }
+    return KBBQ_OK;
+}
+
+// room for `est` more records of filter w?  (the other filter's records share the buffers: they go first)
+int bucket_reserve(kbbq_engine *e, int w, double est, uint64_t bases) {
+    kbbq_engine::Buckets &b = e->bk;
+    int rc = bucket_flush(e, 1 - w);
+    if (rc) return rc;
+    if (b.pending[w] && b.pending_est[w] + est > 0.93 * (double)b.capacity && (rc = bucket_flush(e, w))) return rc;
+    b.pending[w] = true;
+    b.pending_est[w] += est;
+    b.bases_since[w] += bases;
+    return KBBQ_OK;
+}
+
 }  // namespace
 
 // ============================================================ C ABI
@@ -471,6 +623,7 @@ void kbbq_engine_destroy(kbbq_engine *e) {
     hipFree(e->d_rg_present[1]);
     hipFree(e->d_qcum);
     hipFree(e->d_errthr);
+    hipFree(e->bk.l1); hipFree(e->bk.l2); hipFree(e->bk.l1_cnt); hipFree(e->bk.l2_cnt); hipFree(e->bk.tickets); hipFree(e->bk.direct);
     for (int i = 0; i < 16; ++i) hipFree(e->scratch[i]);
     if (e->stream2) { hipStreamSynchronize(e->stream2); hipStreamDestroy(e->stream2); }
     if (e->ev_main) hipEventDestroy(e->ev_main);
@@ -493,6 +646,12 @@ int kbbq_engine_reset(kbbq_engine *e) {
     HIP_TRY(hipMemsetAsync(e->d_hist, 0, (e->hist_cycle_words + e->hist_dinuc_words) * 8, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_counters, 0, 64, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_qpresent, 0, 16, e->stream));
+    if (e->bk.allocated) {      // records gathered for the old filters are dropped
+        HIP_TRY(hipMemsetAsync(e->bk.l1_cnt, 0, kL1CntBytes, e->stream));
+        HIP_TRY(hipMemsetAsync(e->bk.l2_cnt, 0, kL2CntBytes, e->stream));
+        HIP_TRY(hipMemsetAsync(e->bk.direct, 0, 8, e->stream));
+    }
+    for (int w = 0; w < 2; ++w) { e->bk.pending[w] = false; e->bk.pending_est[w] = 0; e->bk.bases_since[w] = 0; e->bk.inserted_at_flush[w] = 0; e->bk.flushes[w] = 0; }
     {
         const uint32_t none[3] = {0, 0, 0};
         plan_tally_slots(e->tally_plan, none);
@@ -505,6 +664,7 @@ int kbbq_engine_reset(kbbq_engine *e) {
 
 int kbbq_engine_sync(kbbq_engine *e) {
     ENGINE_DEVICE(e);
+    { int frc = bucket_flush_all(e); if (frc) return frc; }      // deferred inserts reach the filters first (bucket.h)
     if (!e) return fail(KBBQ_EINVAL, "null engine");
     return sync_engine(e);
 }
@@ -513,6 +673,7 @@ void *kbbq_engine_stream(kbbq_engine *e) { return e ? (void *)e->stream : nullpt
 
 int kbbq_filter_info_get(kbbq_engine *e, int which, kbbq_filter_info *out) {
     ENGINE_DEVICE(e);
+    { int frc = bucket_flush_all(e); if (frc) return frc; }      // deferred inserts reach the filters first (bucket.h)
     if (!e || !out || which < 0 || which > 1) return fail(KBBQ_EINVAL, "bad argument");
     const FilterSpec &s = e->filt[which].spec;
     memset(out, 0, sizeof *out);
@@ -530,11 +691,16 @@ int kbbq_filter_info_get(kbbq_engine *e, int which, kbbq_filter_info *out) {
     return KBBQ_OK;
 }
 
-void *kbbq_filter_device_table(kbbq_engine *e, int which) { return e && which >= 0 && which < 2 ? e->filt[which].d_table : nullptr; }
+void *kbbq_filter_device_table(kbbq_engine *e, int which) {
+    if (!e || which < 0 || which > 1) return nullptr;
+    if (hipSetDevice(e->p.device) != hipSuccess || bucket_flush_all(e) != KBBQ_OK) return nullptr;      // the array is about to be read
+    return e->filt[which].d_table;
+}
 void *kbbq_filter_device_counter(kbbq_engine *e, int which) { return e && which >= 0 && which < 2 ? e->filt[which].d_inserted : nullptr; }
 
 int kbbq_filter_download(kbbq_engine *e, int which, uint64_t *host_words, uint64_t n_words) {
     ENGINE_DEVICE(e);
+    { int frc = bucket_flush_all(e); if (frc) return frc; }      // deferred inserts reach the filters first (bucket.h)
     if (!e || !host_words || which < 0 || which > 1) return fail(KBBQ_EINVAL, "bad argument");
     const uint64_t n_blocks = e->filt[which].spec.n_blocks;
     if (n_words != n_blocks * 8) return fail(KBBQ_EINVAL, "filter has %llu words", (unsigned long long)n_blocks * 8);
@@ -562,6 +728,7 @@ int kbbq_filter_patterns_download(kbbq_engine *e, int which, uint64_t *host_word
 
 int kbbq_filter_or_from(kbbq_engine *e, int which, const void *src_device, uint64_t word_offset, uint64_t n_words) {
     ENGINE_DEVICE(e);
+    { int frc = bucket_flush_all(e); if (frc) return frc; }      // deferred inserts reach the filters first (bucket.h)
     if (!e || !src_device || which < 0 || which > 1) return fail(KBBQ_EINVAL, "bad argument");
     const uint64_t total = e->filt[which].spec.n_blocks * 2;   // words of the engine's 128-bit blocks
     if (word_offset > total || n_words > total - word_offset || (word_offset & 1)) return fail(KBBQ_EINVAL, "range outside the filter");
@@ -601,6 +768,7 @@ int kbbq_device_or_pieces(kbbq_engine *e, void *dst_device, const void *src_devi
 
 int kbbq_filter_set_inserted(kbbq_engine *e, int which, uint64_t inserted) {
     ENGINE_DEVICE(e);
+    { int frc = bucket_flush_all(e); if (frc) return frc; }      // deferred inserts reach the filters first (bucket.h)
     if (!e || which < 0 || which > 1) return fail(KBBQ_EINVAL, "bad argument");
     HIP_TRY(hipMemcpyAsync(e->filt[which].d_inserted, &inserted, 8, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -750,6 +918,26 @@ template <int NW> struct LaunchSample {
     }
 };
 
+// the same reads -> (block, pattern) records for the slice-bucketed insert (bucket.h)
+template <int NW> struct LaunchEmit {
+    static int go(kbbq_engine *e, int w, ReadsDev R, const uint64_t *mask, uint64_t mask_words, const uint64_t *kofs,
+                  unsigned long long *inserted) {
+        constexpr int RPW = NW == 3 ? 4 : NW == 5 ? 2 : 1;
+        const BucketDev B = bucket_dev(e, w);
+        const uint64_t n_tiles = (R.n_reads + 8 * RPW - 1) / (8 * RPW);
+        const int grid = (int)std::min<uint64_t>(n_tiles, 256 * 2);
+        Timed t(e, w ? "k_emit_trusted" : "k_emit_sampled");
+        if (w == 0)
+            hipLaunchKernelGGL((k_emit_marked<NW, false, RPW>), dim3(grid), dim3(BK_THREADS), 0, e->stream, R, e->K, e->filt[0].dev(), B,
+                               mask, mask_words, kofs, inserted);
+        else
+            hipLaunchKernelGGL((k_emit_marked<NW, true, RPW>), dim3(grid), dim3(BK_THREADS), 0, e->stream, R, e->K, e->filt[1].dev(), B,
+                               mask, mask_words, kofs, inserted);
+        HIP_TRY(hipGetLastError());
+        return KBBQ_OK;
+    }
+};
+
 extern "C" {
 
 int kbbq_sample_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t first_kmer_ordinal) {
@@ -789,7 +977,13 @@ int kbbq_sample_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t first_km
         HIP_TRY(hipEventRecord(e->ev_draw, ds));
         HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_draw, 0));
     }
-    rc = dispatch_nw<LaunchSample>(max_len, e, R, (const uint64_t *)mask, n_draws / 64 + 2, kofs);
+    if (bucket_on(e, 0)) {
+        // deferred: the k-mers become records now and reach the filter at the next flush (bucket.h)
+        if ((rc = bucket_reserve(e, 0, (double)n_draws * std::min(1.0, e->p.alpha) * 1.01 + 4096.0, R.n_bases))) return rc;
+        rc = dispatch_nw<LaunchEmit>(max_len, e, 0, R, (const uint64_t *)mask, n_draws / 64 + 2, kofs, e->filt[0].d_inserted);
+    } else {
+        rc = dispatch_nw<LaunchSample>(max_len, e, R, (const uint64_t *)mask, n_draws / 64 + 2, kofs);
+    }
     if (!rc) {     // (also for an in-order batch: a later overlapped draw into the same buffer must wait for this insert)
         HIP_TRY(hipEventRecord(e->ev_ins[turn], e->stream));
         e->ins_pending[turn] = true;
@@ -802,6 +996,7 @@ int kbbq_sample_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t first_km
 
 int kbbq_sample_finish(kbbq_engine *e, uint64_t *inserted) {
     ENGINE_DEVICE(e);
+    { int frc = bucket_flush_all(e); if (frc) return frc; }      // deferred inserts reach the filters first (bucket.h)
     if (!e) return fail(KBBQ_EINVAL, "null engine");
     int rc = sync_engine(e);
     if (rc) return rc;
@@ -813,6 +1008,7 @@ int kbbq_sample_finish(kbbq_engine *e, uint64_t *inserted) {
 int kbbq_compute_thresholds(kbbq_engine *e, const char *alpha_text, int32_t *thresholds_out, double *fpr_out,
                             char *p_text_out, size_t p_text_len) {
     ENGINE_DEVICE(e);
+    { int frc = bucket_flush_all(e); if (frc) return frc; }      // deferred inserts reach the filters first (bucket.h)
     if (!e || !alpha_text) return fail(KBBQ_EINVAL, "null argument");
     int rc = sync_engine(e);
     if (rc) return rc;
@@ -850,8 +1046,14 @@ template <int NW> struct LaunchTrusted {
         {
             Timed t(e, "k_infer");
             hipLaunchKernelGGL(k_infer<NW>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
-                               e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent);
+                               e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3);
             HIP_TRY(hipGetLastError());
+        }
+        if (bucket_on(e, 1)) {
+            int rc = bucket_reserve(e, 1, (double)R.n_bases * e->bk.frac_trusted + 4096.0, R.n_bases);
+            if (rc) return rc;
+            return LaunchEmit<NW>::go(e, 1, R, (const uint64_t *)take_bits, R.n_bases / 64 + 2, (const uint64_t *)nullptr,
+                                      (unsigned long long *)nullptr);
         }
         {
             Timed t(e, "k_insert_trusted");
@@ -888,6 +1090,7 @@ static int bit_out_end(kbbq_engine *e, const kbbq_reads *reads, uint64_t *user, 
 
 int kbbq_trusted_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *infer_errors_out) {
     ENGINE_DEVICE(e);
+    { int frc = bucket_flush(e, 0); if (frc) return frc; }      // pass 2 reads the sampled filter: its deferred inserts go in first
     if (!e) return fail(KBBQ_EINVAL, "null engine");
     if (!e->thresholds_set) return fail(KBBQ_ESTATE, "thresholds are not set");
     HostBatchDone host_done(e, reads);
@@ -911,6 +1114,7 @@ int kbbq_trusted_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *infer_
 
 int kbbq_trusted_finish(kbbq_engine *e, uint64_t *inserted) {
     ENGINE_DEVICE(e);
+    { int frc = bucket_flush_all(e); if (frc) return frc; }      // deferred inserts reach the filters first (bucket.h)
     if (!e) return fail(KBBQ_EINVAL, "null engine");
     int rc = sync_engine(e);
     if (rc) return rc;
@@ -1039,6 +1243,7 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
 
 int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_out) {
     ENGINE_DEVICE(e);
+    { int frc = bucket_flush_all(e); if (frc) return frc; }      // deferred inserts reach the filters first (bucket.h)
     if (!e || !reads) return fail(KBBQ_EINVAL, "null argument");
     const bool own_err = !(errors_out && reads->on_device);
     // A device-resident batch stays put after this call returns, so it may still be in flight while the next one
@@ -1123,6 +1328,7 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
 
 int kbbq_tally_batch(kbbq_engine *e, const kbbq_reads *reads, const uint64_t *errors) {
     ENGINE_DEVICE(e);
+    { int frc = bucket_flush_all(e); if (frc) return frc; }      // deferred inserts reach the filters first (bucket.h)
     if (!e || !errors) return fail(KBBQ_EINVAL, "null argument");
     HostBatchDone host_done(e, reads);
     ReadsDev R; int max_len;
@@ -1364,7 +1570,14 @@ int kbbq_stats_get(kbbq_engine *e, uint64_t *out, int32_t n) {
     if (!e || !out) return fail(KBBQ_EINVAL, "null argument");
     int rc = sync_engine(e);      // batches of pass 3 may still be in flight; their counters are collected here
     if (rc) return rc;
+    HIP_TRY(hipMemcpy(&e->stats[3], e->d_counters + 3, 8, hipMemcpyDeviceToHost));      // [3] Bloom blocks fetched by k_infer
     for (int i = 0; i < n && i < 4; ++i) out[i] = e->stats[i];
+    // [4],[5] flushes of the bucketed inserts per filter, [6] records inserted directly because a region was full,
+    // [7] records gathered per flush (0: the filters take direct inserts)
+    unsigned long long direct = 0;
+    if (e->bk.allocated && n > 6) HIP_TRY(hipMemcpy(&direct, e->bk.direct, 8, hipMemcpyDeviceToHost));
+    const uint64_t extra[4] = {e->bk.flushes[0], e->bk.flushes[1], direct, e->bk.allocated ? e->bk.capacity : 0};
+    for (int i = 4; i < n && i < 8; ++i) out[i] = extra[i - 4];
     return KBBQ_OK;
 }
 

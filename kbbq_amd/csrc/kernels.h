@@ -251,7 +251,8 @@ struct Thresholds { int v[KBBQ_MAX_KMER + 1]; };
 
 template <int NW>
 __global__ void __launch_bounds__(256) k_infer(ReadsDev R, KParams K, FiltDev S, Thresholds thr, uint32_t *take_bits,
-                                                unsigned long long *inserted, uint32_t *err_out, uint32_t *qpresent) {
+                                                unsigned long long *inserted, uint32_t *err_out, uint32_t *qpresent,
+                                                unsigned long long *lookups) {
     using St = Stage<NW>;
     __shared__ uint32_t lds[4][St::LDS_U32];
     __shared__ int thr_lds[KBBQ_MAX_KMER + 1];
@@ -265,7 +266,7 @@ __global__ void __launch_bounds__(256) k_infer(ReadsDev R, KParams K, FiltDev S,
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t *hint = reinterpret_cast<const uint64_t *>(R.hint_sampled);
     const int k = K.k;
-    unsigned long long mine = 0;
+    unsigned long long mine = 0, looked = 0;
     if (lane < St::RES) { PW[lane] = 0; EW[lane] = 0; }
     uint64_t off = 0, word = 0;
     uint32_t len = 0;
@@ -322,6 +323,7 @@ __global__ void __launch_bounds__(256) k_infer(ReadsDev R, KParams K, FiltDev S,
                 const bool present = known[c] || (valid[c] && ((p[c].x & ~t[c].x) | (p[c].y & ~t[c].y)) == 0);
                 const uint64_t P = __ballot(present);
                 V[c] = __ballot(valid[c]);
+                looked += __popcll(__ballot(valid[c] && !known[c]));      // blocks actually fetched (reported, not used)
                 if (lane < 2) PW[1 + 2 * c + lane] = (uint32_t)(P >> (32 * lane));
             } else if (lane < 2) {
                 PW[1 + 2 * c + lane] = 0;
@@ -362,6 +364,7 @@ __global__ void __launch_bounds__(256) k_infer(ReadsDev R, KParams K, FiltDev S,
         }
     }
     if (lane == 0 && mine) atomicAdd(inserted, mine);
+    if (lane == 0 && looked) atomicAdd(lookups, looked);
 }
 
 // ---- pass 3a': the isolated-error fast path (inside k_scan_trusted) -------------------
