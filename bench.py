@@ -163,16 +163,21 @@ def kernel_model(name, bases, nk, alpha, f_t, walk_queries=0.0):
 
 
 class HostPacked:
-    """A packed batch in host memory (what a driver that decodes on the CPU hands over the boundary)."""
+    """A packed batch in PAGE-LOCKED host memory (kbbq_host_alloc): what a driver that decodes on the CPU hands over
+    the boundary (caller-owned pinned SoA buffers)."""
 
     def __init__(self, e, dev):
         from kbbq_amd import _lib
         h = e.download(dev)
-        self.arrays = h
-        self.qual = np.zeros(dev.n_bases + 16, dtype=np.uint8)
-        self.qual[:dev.n_bases] = h["qual"]
-        self.bases = np.concatenate([h["bases"], np.zeros(1, dtype=np.uint64)])
-        self.nmask = np.concatenate([h["nmask"], np.zeros(1, dtype=np.uint64)])
+        nb = dev.n_bases
+        self.pins = [_lib.PinnedArray(nb + 16, np.uint8), _lib.PinnedArray(nb // 32 + 2, np.uint64), _lib.PinnedArray(nb // 64 + 2, np.uint64)]
+        self.qual, self.bases, self.nmask = (p.array for p in self.pins)
+        self.qual[:nb] = h["qual"]
+        self.qual[nb:] = 0
+        self.bases[:len(h["bases"])] = h["bases"]
+        self.bases[len(h["bases"]):] = 0
+        self.nmask[:len(h["nmask"])] = h["nmask"]
+        self.nmask[len(h["nmask"]):] = 0
         self.n_reads, self.n_bases = dev.n_reads, dev.n_bases
         self.c = _lib.Reads()
         self.c.n_reads, self.c.n_bases = dev.n_reads, dev.n_bases
@@ -183,12 +188,25 @@ class HostPacked:
         self.c.read_len = READ_LEN
         self.c.on_device = 0
 
+    def free(self):
+        self.qual = self.bases = self.nmask = None
+        for p in self.pins:
+            p.free()
+
 
 def pcie_inclusive(genome_len, coverage, local_rank):
-    """One step of the same path with every batch handed over as HOST buffers on every pass (the boundary's
-    other mode): H2D of bases + N mask + qualities four times, D2H of the new qualities once, synchronous
-    staging.  Bounded sample; reported beside `value`, never as `value`."""
+    """The boundary's other mode on a bounded sample: batches handed over as HOST buffers (page-locked), reported
+    beside `value`, never as `value`.  Two ways over the same boundary:
+      resubmit     every pass re-submits every batch (what the reference's four re-reads of its input imply):
+                   bases + N mask four times, qualities three times = 4.5 B/base H2D, new qualities 1 B/base D2H
+      upload_once  kbbq_reads_upload once (while pass 1 of the batch before runs), batches and hint arrays resident for
+                   passes 2-4, new qualities back through kbbq_recalibrate_batch_host: 1.4 B/base H2D, 1 B/base D2H
+    with the host link's measured rates (one 1 GiB pinned copy each way) and, from them, each mode's bound
+    sum over passes of max(transfer, resident compute) -- transfers of passes 1 and 4 cannot hide behind passes 2-3."""
     from kbbq_amd import _lib
+    L = _lib.lib()
+    up, dn = ctypes.c_double(), ctypes.c_double()
+    _lib.check(L.kbbq_measure_host_link(local_rank, 1 << 30, ctypes.byref(up), ctypes.byref(dn)))
     n_reads = genome_len * coverage // READ_LEN
     alpha_ld, cov, approx = plan_parameters(genome_len, coverage, None)
     e = Engine(K, alpha_ld, SEED_SAMPLER, approx, n_rg=1, max_read_len=READ_LEN, device=local_rank)
@@ -199,58 +217,82 @@ def pcie_inclusive(genome_len, coverage, local_rank):
         n = min(BATCH_READS, n_reads - s)
         host.append(HostPacked(e, dev.view(s, n)))
         ordinals.append(s * (READ_LEN - K + 1))
-    dev.free()
-    out = np.zeros(BATCH_READS * READ_LEN + 16, dtype=np.uint8)
-    e.sync()
-    t0 = time.perf_counter()
-    for b, o in zip(host, ordinals):
-        e.subsample_kmers(b, o)
-    e.sample_finish()
-    e.compute_thresholds()
-    for b in host:
-        e.find_trusted_kmers(b)
-    e.trusted_finish()
-    for b in host:
-        e.get_covariatedata(b)
-    e.get_dqs()
-    for b in host:
-        _lib.check(e.L.kbbq_recalibrate_batch(e.h, ctypes.byref(b.c), out.ctypes.data))
-    e.sync()
-    dt = time.perf_counter() - t0
     nb = n_reads * READ_LEN
-    # the other way over the same boundary, the one the command line takes: every batch is uploaded ONCE (while
-    # pass 1 of the batch before it runs), stays resident with its hint arrays, and only the new qualities come back
+
+    def passes(run_batches):
+        """time the four passes separately (each ends synchronised)"""
+        t = []
+        for fn in run_batches:
+            e.sync()
+            t0 = time.perf_counter()
+            fn()
+            e.sync()
+            t.append(time.perf_counter() - t0)
+        return t
+
+    # resident reference for the bound: the same batches from HBM
+    hint_bytes = (nb // 64 + 2) * 8
+    hints = torch.zeros(2 * hint_bytes, dtype=torch.uint8, device="cuda")
+    dev.set_hints(hints.data_ptr(), hints.data_ptr() + hint_bytes)
+    res = [dev.view(s, min(BATCH_READS, n_reads - s)) for s in range(0, n_reads, BATCH_READS)]
+    out_dev = torch.empty(BATCH_READS * READ_LEN + 16, dtype=torch.uint8, device="cuda")
+    t_res = passes([lambda: ([e.subsample_kmers(b, o) for b, o in zip(res, ordinals)], e.sample_finish(), e.compute_thresholds()),
+                    lambda: ([e.find_trusted_kmers(b) for b in res], e.trusted_finish()),
+                    lambda: ([e.get_covariatedata(b) for b in res], e.get_dqs()),
+                    lambda: [e.recalibrate(b, out_dev.data_ptr()) for b in res]])
+    dev.free()
+    del hints
+    out_pin = _lib.PinnedArray(BATCH_READS * READ_LEN + 16, np.uint8)
+    out = out_pin.array
     _lib.check(e.L.kbbq_engine_reset(e.h))
-    e.sync()
-    t0 = time.perf_counter()
+    t_sub = passes([lambda: ([e.subsample_kmers(b, o) for b, o in zip(host, ordinals)], e.sample_finish(), e.compute_thresholds()),
+                    lambda: ([e.find_trusted_kmers(b) for b in host], e.trusted_finish()),
+                    lambda: ([e.get_covariatedata(b) for b in host], e.get_dqs()),
+                    lambda: [_lib.check(e.L.kbbq_recalibrate_batch(e.h, ctypes.byref(b.c), out.ctypes.data)) for b in host]])
+    _lib.check(e.L.kbbq_engine_reset(e.h))
     resident = []
-    for b, o in zip(host, ordinals):
-        d = _lib.Reads()
-        _lib.check(e.L.kbbq_reads_upload(e.h, ctypes.byref(b.c), ctypes.byref(d)))
-        _lib.check(e.L.kbbq_reads_alloc_hints(ctypes.byref(d)))
-        _lib.check(e.L.kbbq_sample_batch(e.h, ctypes.byref(d), o))
-        resident.append(d)
-    e.sample_finish()
-    e.compute_thresholds()
-    for d in resident:
-        _lib.check(e.L.kbbq_trusted_batch(e.h, ctypes.byref(d), None))
-    e.trusted_finish()
-    for d in resident:
-        _lib.check(e.L.kbbq_errors_batch(e.h, ctypes.byref(d), None))
-    e.get_dqs()
-    for d in resident:
-        _lib.check(e.L.kbbq_recalibrate_batch_host(e.h, ctypes.byref(d), out.ctypes.data))
-    e.sync()
-    dt2 = time.perf_counter() - t0
+
+    def upload_and_sample():
+        for b, o in zip(host, ordinals):
+            d = _lib.Reads()
+            _lib.check(e.L.kbbq_reads_upload(e.h, ctypes.byref(b.c), ctypes.byref(d)))
+            _lib.check(e.L.kbbq_reads_alloc_hints(ctypes.byref(d)))
+            _lib.check(e.L.kbbq_sample_batch(e.h, ctypes.byref(d), o))
+            resident.append(d)
+        e.sample_finish()
+        e.compute_thresholds()
+
+    t_once = passes([upload_and_sample,
+                     lambda: ([_lib.check(e.L.kbbq_trusted_batch(e.h, ctypes.byref(d), None)) for d in resident], e.trusted_finish()),
+                     lambda: ([_lib.check(e.L.kbbq_errors_batch(e.h, ctypes.byref(d), None)) for d in resident], e.get_dqs()),
+                     lambda: [_lib.check(e.L.kbbq_recalibrate_batch_host(e.h, ctypes.byref(d), out.ctypes.data)) for d in resident]])
     for d in resident:
         _lib.check(e.L.kbbq_reads_free_hints(ctypes.byref(d)))
         _lib.check(e.L.kbbq_reads_free(e.h, ctypes.byref(d)))
     e.close()
-    return dict(value=round(nb / dt / 1e9, 4), unit="Gbases/s", seconds=round(dt, 3),
-                sample="%d reads x %d bp = %.3g bases as host batches of %d reads, every pass re-submits them (5.5 B/base H2D, 1 B/base D2H)"
-                       % (n_reads, READ_LEN, nb, BATCH_READS),
-                upload_once=dict(value=round(nb / dt2 / 1e9, 4), unit="Gbases/s", seconds=round(dt2, 3),
-                                 sample="same batches, uploaded once and kept resident (1.4 B/base H2D, 1 B/base D2H, pageable host memory)"))
+    for b in host:
+        b.free()
+    out = None
+    out_pin.free()
+    h2d, d2h = up.value * 1e9, dn.value * 1e9
+    # per pass: bytes each way per base (bases 0.25 + N mask 0.125 + qualities 1)
+    sub_bytes = [(0.375, 0.0), (1.375, 0.0), (1.375, 0.0), (1.375, 1.0)]
+    once_bytes = [(1.375, 0.0), (0.0, 0.0), (0.0, 0.0), (0.0, 1.0)]
+
+    def bound(bytes_per_pass):
+        return sum(max(nb * u / h2d + nb * dwn / d2h, c) for (u, dwn), c in zip(bytes_per_pass, t_res))
+
+    def mode(t, bytes_per_pass, text):
+        b = bound(bytes_per_pass)
+        return dict(value=round(nb / sum(t) / 1e9, 4), unit="Gbases/s", seconds=round(sum(t), 3), pass_seconds=[round(x, 3) for x in t],
+                    bound_Gbases_per_s=round(nb / b / 1e9, 4), fraction_of_bound=round(b / sum(t), 3), traffic=text)
+
+    return dict(host_link=dict(h2d_GBps=round(up.value, 2), d2h_GBps=round(dn.value, 2), how="one 1 GiB copy each way, page-locked host memory"),
+                sample="%d reads x %d bp = %.3g bases as page-locked host batches of %d reads" % (n_reads, READ_LEN, nb, BATCH_READS),
+                resident_pass_seconds=[round(x, 3) for x in t_res],
+                bound="per mode: sum over the four passes of max(bytes / measured link rate, the pass's resident time)",
+                resubmit=mode(t_sub, sub_bytes, "4.5 B/base H2D (pass 1 sends no qualities), 1 B/base D2H"),
+                upload_once=mode(t_once, once_bytes, "1.4 B/base H2D, 1 B/base D2H"))
 
 
 def host_cpu():
@@ -346,7 +388,8 @@ def main():
     ap.add_argument("--coverage", type=int, default=30)
     ap.add_argument("--cpu-genome-len", type=int, default=8_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pcie", action="store_true", help="also time a bounded step with host-resident batches (PCIe-inclusive rate)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the bounded PCIe-inclusive leg (host batches over the boundary)")
+    ap.add_argument("--pcie", action="store_true", help="(kept for older command lines: the leg now runs by default)")
     ap.add_argument("--pcie-genome-len", type=int, default=100_000_000)
     ap.add_argument("--emulate-shard", default=None, metavar="R/N",
                     help="diagnostic: one process runs rank R's shard of an N-rank job (fresh filters, no collectives) -- "
@@ -543,10 +586,13 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(e, args.cpu_genome_len, cov)
-        if world == 1 and args.pcie:
+        if world == 1 and not args.no_pcie:
+            shard.free()      # the leg needs HBM for its own resident copy
+            shard = None
             line["pcie_inclusive"] = pcie_inclusive(args.pcie_genome_len, cov, local_rank)
         print(json.dumps(line), flush=True)
-    shard.free()
+    if shard is not None:
+        shard.free()
     e.close()
     if world > 1:
         dist.destroy_process_group()

@@ -63,11 +63,16 @@ typedef struct kbbq_params {
 #define KBBQ_F_PROFILE 1    /* time every kernel with HIP events (kbbq_profile_get) */
 
 /* One batch of reads, structure of arrays.  All pointers are device pointers if
- * on_device != 0, host pointers otherwise (the engine then copies them to device
- * buffers of its own with hipMemcpyAsync on its stream; page-locked caller memory makes
- * the copies faster, it is not required).  A call with a host batch has completed when it
- * returns: the caller may reuse the batch's memory at once.  Calls with device batches only
- * queue work (see the individual functions).
+ * on_device != 0, host pointers otherwise.  A host batch is copied into one of the
+ * engine's device staging slots (a ring of three, no allocation per call) with
+ * hipMemcpyAsync on the engine's copy stream -- DMA straight out of the caller's memory
+ * when that is page-locked (kbbq_host_alloc), staged by the runtime otherwise -- and the
+ * pass's kernels wait for the copy by event.  The call returns when the COPY has landed:
+ * the caller may reuse the batch's memory at once, while the kernels are still queued or
+ * running, so the copy of batch i+1 overlaps the kernels of batch i.  Results a call hands
+ * back in host memory (error masks, recalibrated qualities) are complete on return; results
+ * that stay in the engine (filters, histograms) are complete after the pass's *_finish or
+ * kbbq_engine_sync.  Calls with device batches only queue work (see the individual functions).
  *   bases   2 bits per base, base i of the batch in bits [2*(i%32), +2) of word
  *           i/32; A=0 C=1 G=2 T=3 (seq_nt16_int[seq_nt16_table[ch]], bloom.hh:351);
  *           anything else is stored as 0 with its nmask bit set.
@@ -98,6 +103,13 @@ typedef struct kbbq_reads {
      * inserted into the trusted filter, pass 3 skips those.  Results are unchanged. */
     uint64_t *hint_sampled;
     uint64_t *hint_trusted;
+    /* Optional (NULL = every base is upper-case): 1 bit per base, layout of nmask, set where the raw character is an
+     * ACGT base but not the upper-case letter -- 'a','c','g','t' of a soft-masked FASTQ, and the digits '0'..'3'
+     * that seq_nt16_table also folds to bases.  K-mers, covariates and the apply step fold case (bloom.hh:351), but
+     * three loops of the reference compare RAW characters with 'A','C','G','T' (bloom.cc:142,218,249;
+     * readutils.cc:202), so for such a base they also try the candidate equal to it; the engine reproduces that.
+     * kbbq_pack_bases_case fills the array.  Device or host like the batch. */
+    const uint64_t *offcase;
 } kbbq_reads;
 
 typedef struct kbbq_filter_info {
@@ -159,10 +171,19 @@ int kbbq_filter_set_inserted(kbbq_engine *e, int which, uint64_t inserted);
  * seq/qual_ascii hold n_bases characters; bases_out/nmask_out must have
  * n_bases/32+2 and n_bases/64+2 words; qual_out n_bases bytes (qual_ascii-33). */
 int kbbq_pack_bases(const uint8_t *seq, uint64_t n_bases, uint64_t *bases_out, uint64_t *nmask_out);
+/* Same, and the off-case bit array of kbbq_reads.offcase (n_bases/64+2 words); *n_offcase (optional) = bits set, so
+ * that a driver can leave kbbq_reads.offcase NULL for the usual all-upper-case batch. */
+int kbbq_pack_bases_case(const uint8_t *seq, uint64_t n_bases, uint64_t *bases_out, uint64_t *nmask_out, uint64_t *offcase_out,
+                         uint64_t *n_offcase);
 /* Copy a host batch to device memory owned by the engine library; *dev gets
  * device pointers (on_device=1).  Free with kbbq_reads_free. */
 int kbbq_reads_upload(kbbq_engine *e, const kbbq_reads *host, kbbq_reads *dev);
 int kbbq_reads_free(kbbq_engine *e, kbbq_reads *dev);
+/* Page-locked host memory for batch arrays and outputs (hipHostMalloc): what makes the copies of host batches
+ * true DMA at the link's rate.  kbbq_measure_host_link times one `bytes`-sized copy each way from such memory. */
+int kbbq_host_alloc(size_t bytes, void **out);
+int kbbq_host_free(void *p);
+int kbbq_measure_host_link(int32_t device, uint64_t bytes, double *h2d_gbps, double *d2h_gbps);
 /* For both, e may be NULL (current device): a driver can make its batches resident in HBM while it is
  * still counting the bases that size the engine (kbbq.cc:229-264), then run every pass from HBM.
  * kbbq_reads_alloc_hints gives a device batch zeroed hint arrays (see kbbq_reads.hint_*), owned by the

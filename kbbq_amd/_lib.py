@@ -36,7 +36,7 @@ class Params(ctypes.Structure):
 class Reads(ctypes.Structure):
     _fields_ = [("n_reads", c_u64), ("n_bases", c_u64), ("bases", c_vp), ("nmask", c_vp), ("qual", c_vp),
                 ("offsets", c_vp), ("flags", c_vp), ("rg", c_vp), ("read_len", ctypes.c_uint32),
-                ("on_device", ctypes.c_int32), ("hint_sampled", c_vp), ("hint_trusted", c_vp)]
+                ("on_device", ctypes.c_int32), ("hint_sampled", c_vp), ("hint_trusted", c_vp), ("offcase", c_vp)]
 
 
 class FilterInfo(ctypes.Structure):
@@ -81,6 +81,7 @@ SYMBOLS = {
     "kbbq_device_or_pieces": (ctypes.c_int, [c_vp, c_vp, c_vp, c_u64, ctypes.c_int32, ctypes.c_int32]),
     "kbbq_filter_set_inserted": (ctypes.c_int, [c_vp, ctypes.c_int, c_u64]),
     "kbbq_pack_bases": (ctypes.c_int, [c_u8p, c_u64, c_u64p, c_u64p]),
+    "kbbq_pack_bases_case": (ctypes.c_int, [c_u8p, c_u64, c_u64p, c_u64p, c_u64p, c_u64p]),
     "kbbq_reads_upload": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads), ctypes.POINTER(Reads)]),
     "kbbq_reads_free": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads)]),
     "kbbq_sample_batch": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads), c_u64]),
@@ -103,6 +104,9 @@ SYMBOLS = {
     "kbbq_reads_alloc_hints": (ctypes.c_int, [ctypes.POINTER(Reads)]),
     "kbbq_reads_free_hints": (ctypes.c_int, [ctypes.POINTER(Reads)]),
     "kbbq_device_memory": (ctypes.c_int, [ctypes.c_int32, c_u64p, c_u64p]),
+    "kbbq_host_alloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(c_vp)]),
+    "kbbq_host_free": (ctypes.c_int, [c_vp]),
+    "kbbq_measure_host_link": (ctypes.c_int, [ctypes.c_int32, c_u64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "kbbq_synth_tables": (ctypes.c_int, [ctypes.POINTER(SynthParams), c_u32p, c_u32p]),
     "kbbq_synth_reads": (ctypes.c_int, [c_vp, ctypes.POINTER(SynthParams), c_u64, c_u64, ctypes.POINTER(Reads)]),
     "kbbq_profile_get": (ctypes.c_int, [c_vp, ctypes.POINTER(ProfileEntry), ctypes.c_int32, c_i32p]),
@@ -163,3 +167,27 @@ def check(rc):
     if rc < 0:
         raise KbbqError(rc, lib().kbbq_last_error().decode(errors="replace"))
     return rc
+
+
+class PinnedArray:
+    """A numpy array over page-locked host memory from kbbq_host_alloc (DMA-able at the host link's rate)."""
+
+    def __init__(self, count, dtype):
+        import numpy as np
+        self.nbytes = max(1, int(count) * np.dtype(dtype).itemsize)
+        self.ptr = c_vp()
+        check(lib().kbbq_host_alloc(self.nbytes, ctypes.byref(self.ptr)))
+        buf = (ctypes.c_uint8 * self.nbytes).from_address(self.ptr.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(count))
+
+    def free(self):
+        if self.ptr is not None and self.ptr.value:
+            self.array = None
+            lib().kbbq_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -39,19 +39,21 @@ constexpr int NB2 = 1 << NB2_BITS;
 constexpr int L1_SHIFT = SUB_BITS + NB2_BITS;    // 21
 constexpr int MAX_NB1 = 512;                     // filters up to 2^30 blocks (16 GiB in the engine's layout)
 constexpr int N_XCD = 8;
-constexpr int CNT_STRIDE = 32;                   // level-1 counters sit on 128-byte lines of their own
+constexpr int CNT_STRIDE = 32;                   // shared level-1 counters sit on 128-byte lines of their own
 constexpr int BK_THREADS = 512;
-constexpr uint32_t BK_OVERFLOW = 0xFFFFFFFFu;
+constexpr int EMIT_GRID = 512;                   // workgroups of k_emit_marked = level-1 source regions per bucket (private mode)
 
 struct BucketDev {
-    unsigned long long *l1;   // [N_XCD][nb1][cap1] records: block << 16 | pattern
-    uint32_t *l1_cnt;         // [N_XCD][nb1] x CNT_STRIDE
-    uint32_t *l2;             // [nb1 * NB2][cap2] records: block-in-subslice << 16 | pattern
+    unsigned long long *l1;   // [n_src][nb1][cap1] records: block << 16 | pattern
+    uint32_t *l1_cnt;         // [n_src][nb1] x cnt_stride
+    uint32_t *l2;             // [n_sub][cap2] records: block-in-subslice << 16 | pattern
     uint32_t *l2_cnt;         // [nb1 * NB2]
     uint32_t *tickets;        // [N_XCD] x CNT_STRIDE: work queues of k_split
     unsigned long long *direct;   // records that did not fit a region and were inserted directly (statistics)
     uint32_t cap1, cap2;
     int nb1;
+    int n_src;                // source regions per level-1 bucket: EMIT_GRID (one per emitting workgroup) or N_XCD (one per XCD)
+    int cnt_stride;           // 1 or CNT_STRIDE
     uint32_t n_sub;           // subslices that exist: ceil(n_blocks / SUB_BLOCKS)
 };
 
@@ -80,88 +82,97 @@ __device__ __forceinline__ uint32_t block_scan512(uint32_t v, uint32_t *wave_tot
 // ---- level 1: emit -----------------------------------------------------------------------------------
 // The read loop of k_insert_marked (one read per wavefront, staged in the wave's LDS slice, one lane per k-mer
 // start), but a marked k-mer becomes a record instead of a read-modify-write of the table.  A tile = RPW reads
-// per wavefront x 8 wavefronts; its records are counted per bucket while they are produced (LDS atomics give
-// each its rank), the block reserves one run per bucket in this XCD's regions (one global atomic per bucket and
-// tile), the records are placed in bucket order in LDS and copied out in runs.
-template <int NW, bool BY_BASE, int RPW>
+// per wavefront x 8 wavefronts (the packed words of all RPW reads are in flight at once, and the next tile's
+// travel during this tile's sort); its records are counted per bucket while they are produced (LDS atomics give
+// each its rank), every bucket's run gets its place in the bucket's region, the records are put in bucket order
+// in LDS and copied out in runs.  PRIV: every workgroup appends to regions of its own (region = blockIdx.x), whose
+// fill counters live in its LDS for the length of the launch -- no global atomic anywhere, at the price of 512
+// partly written tail lines per bucket instead of eight (they are completed in the L2 / the Infinity Cache before
+// they reach HBM).  !PRIV: one region per (XCD, bucket) and one global atomic per bucket and tile.
+// CH = chunks of 64 k-mer starts a read can have (<= NW).
+template <int NW, int CH, bool BY_BASE, int RPW, bool PRIV>
 __global__ void __launch_bounds__(BK_THREADS) k_emit_marked(ReadsDev R, KParams K, FiltDev F, BucketDev B, const uint64_t *mask,
                                                              uint64_t mask_words, const uint64_t *kofs,
                                                              unsigned long long *inserted) {
     using S = Stage<NW>;
-    constexpr int SLOTS = RPW * NW;
-    constexpr int TCAP = 8 * SLOTS * 64;
+    constexpr int SLOTS = RPW * CH;
+    extern __shared__ unsigned long long sorted[];      // 8 * SLOTS * 64 records
     __shared__ uint32_t stage[8][2 * S::WORDS];
-    __shared__ uint32_t hist[MAX_NB1], ofs_l[MAX_NB1], gbase_l[MAX_NB1], wave_tot[8];
-    __shared__ unsigned long long sorted[TCAP];
+    __shared__ uint32_t hist[MAX_NB1], ofs_l[MAX_NB1], gbase_l[MAX_NB1], fill_l[MAX_NB1], wave_tot[8];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *L32 = stage[w];
     const int k = K.k;
-    const int xcd = xcc_id();
+    const int src = PRIV ? (int)blockIdx.x : xcc_id();
     const uint64_t reads_per_tile = 8 * RPW;
     const uint64_t n_tiles = (R.n_reads + reads_per_tile - 1) / reads_per_tile;
     unsigned long long mine = 0, direct = 0;
     hist[threadIdx.x] = 0;
+    if (PRIV) fill_l[threadIdx.x] = (int)threadIdx.x < B.nb1 ? B.l1_cnt[(size_t)src * B.nb1 + threadIdx.x] : 0u;
     __syncthreads();
+    uint64_t off[RPW], kb[RPW], word[RPW];
+    uint32_t len[RPW];
+    auto fetch_tile = [&](uint64_t tile) {
+        const uint64_t r0 = (tile * 8 + w) * RPW;
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            off[rr] = 0; kb[rr] = 0; word[rr] = 0; len[rr] = 0;
+            if (r0 + rr < R.n_reads) {     // wave-uniform
+                read_span(R, r0 + rr, off[rr], len[rr]);
+                kb[rr] = BY_BASE ? off[rr] : kmer_base(kofs, r0 + rr, R.read_len, k);
+                word[rr] = stage_fetch<NW>(R, nullptr, mask, kb[rr], mask_words - 1, off[rr], lane);
+            }
+        }
+    };
+    if (blockIdx.x < n_tiles) fetch_tile(blockIdx.x);
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         unsigned long long rec[SLOTS];
         int rk[SLOTS];
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) { rec[s] = 0; rk[s] = -1; }
-        const uint64_t r0 = (tile * 8 + w) * RPW;
         // ---- produce and count
-        uint64_t off = 0, kb = 0, word = 0;
-        uint32_t len = 0;
-        if (r0 < R.n_reads) {
-            read_span(R, r0, off, len);
-            kb = BY_BASE ? off : kmer_base(kofs, r0, R.read_len, k);
-            word = stage_fetch<NW>(R, nullptr, mask, kb, mask_words - 1, off, lane);
-        }
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
-            const uint64_t r = r0 + rr;
-            if (r < R.n_reads) {     // wave-uniform
+            const int nk = (int)len[rr] - k + 1;
+            if (nk > 0) {     // wave-uniform (a read past the end of the batch has len 0)
                 __builtin_amdgcn_wave_barrier();
-                if (lane < S::WORDS) stage_store(L32, lane, word);
+                if (lane < S::WORDS) stage_store(L32, lane, word[rr]);
                 __builtin_amdgcn_wave_barrier();
-                const uint64_t cur = off;
-                const int o31 = (int)(off & 31), o63 = (int)(off & 63), x63 = (int)(kb & 63);
-                const int nk = (int)len - k + 1;
-                if (rr + 1 < RPW && r + 1 < R.n_reads) {     // the next read's words travel while this one is processed
-                    read_span(R, r + 1, off, len);
-                    kb = BY_BASE ? off : kmer_base(kofs, r + 1, R.read_len, k);
-                    word = stage_fetch<NW>(R, nullptr, mask, kb, mask_words - 1, off, lane);
-                }
-                if (nk > 0) {
+                const int o31 = (int)(off[rr] & 31), o63 = (int)(off[rr] & 63), x63 = (int)(kb[rr] & 63);
 #pragma unroll
-                    for (int c = 0; c < NW; ++c) {
-                        if (c * 64 < nk) {
-                            const int s = c * 64 + lane;
-                            bool take = false;
-                            if (s < nk && lds_bit(L32 + 2 * S::X, x63 + s)) {
-                                const bool valid = (lds_window32(L32 + 2 * S::M, o63 + s) & K.nmask_bits) == 0;
-                                take = BY_BASE || valid;
-                            }
-                            if (take) {
-                                const uint64_t key = canon_key(lds_window64(L32 + 2 * S::B, 2 * (o31 + s)), K);
-                                const uint32_t blk = block_of(F, key);
-                                rec[rr * NW + c] = ((unsigned long long)blk << 16) | pattern_of(F, key);
-                                rk[rr * NW + c] = (int)atomicAdd(&hist[blk >> L1_SHIFT], 1u);
-                            }
-                            const unsigned long long bal = __ballot(take);
-                            if (!BY_BASE && R.hint_sampled) or_bits64(R.hint_sampled, cur + (uint64_t)c * 64, bal, lane);
-                            mine += __popcll(bal);
+                for (int c = 0; c < CH; ++c) {
+                    if (c * 64 < nk) {
+                        const int s = c * 64 + lane;
+                        bool take = false;
+                        if (s < nk && lds_bit(L32 + 2 * S::X, x63 + s)) {
+                            const bool valid = (lds_window32(L32 + 2 * S::M, o63 + s) & K.nmask_bits) == 0;
+                            take = BY_BASE || valid;
                         }
+                        if (take) {
+                            const uint64_t key = canon_key(lds_window64(L32 + 2 * S::B, 2 * (o31 + s)), K);
+                            const uint32_t blk = block_of(F, key);
+                            rec[rr * CH + c] = ((unsigned long long)blk << 16) | pattern_of(F, key);
+                            rk[rr * CH + c] = (int)atomicAdd(&hist[blk >> L1_SHIFT], 1u);
+                        }
+                        const unsigned long long bal = __ballot(take);
+                        if (!BY_BASE && R.hint_sampled) or_bits64(R.hint_sampled, off[rr] + (uint64_t)c * 64, bal, lane);
+                        mine += __popcll(bal);
                     }
                 }
             }
         }
+        if (tile + gridDim.x < n_tiles) fetch_tile(tile + gridDim.x);      // travels while this tile is sorted and written
         __syncthreads();
-        // ---- one run per bucket: reserve it in this XCD's region, find its place in the tile
+        // ---- one run per bucket: its place in the bucket's region and in the tile
         const uint32_t cnt = hist[threadIdx.x];
         hist[threadIdx.x] = 0;
         uint32_t g = 0;
-        if (cnt) g = atomicAdd(&B.l1_cnt[((size_t)xcd * B.nb1 + threadIdx.x) * CNT_STRIDE], cnt);
+        if (PRIV) {
+            g = fill_l[threadIdx.x];
+            fill_l[threadIdx.x] = g + cnt;
+        } else if (cnt) {
+            g = atomicAdd(&B.l1_cnt[((size_t)src * B.nb1 + threadIdx.x) * CNT_STRIDE], cnt);
+        }
         uint32_t total;
         const uint32_t ex = block_scan512(cnt, wave_tot, &total);
         ofs_l[threadIdx.x] = ex;
@@ -177,7 +188,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_emit_marked(ReadsDev R, KParams 
             const uint32_t b = (uint32_t)(v >> (16 + L1_SHIFT));
             const uint32_t pos = gbase_l[b] + (i - ofs_l[b]);
             if (pos < B.cap1) {
-                B.l1[((size_t)xcd * B.nb1 + b) * B.cap1 + pos] = v;
+                B.l1[((size_t)src * B.nb1 + b) * B.cap1 + pos] = v;
             } else {
                 bloom_put(F, (uint32_t)(v >> 16), (uint32_t)(v & 0xFFFFu));
                 ++direct;
@@ -185,6 +196,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_emit_marked(ReadsDev R, KParams 
         }
         // (the next tile's counting only touches hist[]; ofs_l/gbase_l/sorted are rewritten behind its barriers)
     }
+    if (PRIV && (int)threadIdx.x < B.nb1) B.l1_cnt[(size_t)src * B.nb1 + threadIdx.x] = fill_l[threadIdx.x];
     if (inserted && lane == 0 && mine) atomicAdd(inserted, mine);
     if (direct) atomicAdd(B.direct, direct);
 }
@@ -206,7 +218,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_split(FiltDev F, BucketDev B, ui
     for (int qi = 0; qi < N_XCD; ++qi) {
         const int q = (home + qi) & (N_XCD - 1);
         const uint32_t n_buckets = B.nb1 > q ? (uint32_t)(B.nb1 - q + N_XCD - 1) / N_XCD : 0;     // b1 = q, q+8, ...
-        const uint32_t n_units = n_buckets * N_XCD * chunks_per_region;
+        const uint32_t n_units = n_buckets * (uint32_t)B.n_src * chunks_per_region;
         for (;;) {
             __syncthreads();      // (also: everyone is done with unit_l, sorted[] and the tables of the previous unit)
             if (threadIdx.x == 0) unit_l = atomicAdd(&B.tickets[q * CNT_STRIDE], 1u);
@@ -214,9 +226,9 @@ __global__ void __launch_bounds__(BK_THREADS) k_split(FiltDev F, BucketDev B, ui
             const uint32_t unit = unit_l;
             if (unit >= n_units) break;      // block-uniform: every wave of the block leaves together
             const uint32_t chunk = unit % chunks_per_region, rest = unit / chunks_per_region;
-            const int x = (int)(rest % N_XCD), b1 = q + (int)(rest / N_XCD) * N_XCD;
+            const int x = (int)(rest % (uint32_t)B.n_src), b1 = q + (int)(rest / (uint32_t)B.n_src) * N_XCD;
             const size_t region = (size_t)x * B.nb1 + b1;
-            const uint32_t n = min(B.l1_cnt[region * CNT_STRIDE], B.cap1);
+            const uint32_t n = min(B.l1_cnt[region * B.cnt_stride], B.cap1);
             const uint32_t first = chunk * (uint32_t)SPLIT_TILE;
             if (first >= n) continue;
             const uint32_t m = min((uint32_t)SPLIT_TILE, n - first);
@@ -286,14 +298,24 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply(FiltDev F, BucketDev B)
     __syncthreads();
     const uint32_t *src = B.l2 + (size_t)sub * B.cap2;
     unsigned long long *w = reinterpret_cast<unsigned long long *>(blk_l);
-    for (uint32_t i = threadIdx.x; i < n; i += APPLY_THREADS) {
-        const uint32_t v = src[i];
-        const uint32_t bi = v >> 16;
-        const ulonglong2 p = F.patterns[v & 0xFFFFu];
-        const ulonglong2 t = blk_l[bi];
-        const unsigned long long mx = p.x & ~t.x, my = p.y & ~t.y;
-        if (mx) atomicOr(&w[2 * bi], mx);
-        if (my) atomicOr(&w[2 * bi + 1], my);
+    // four records per lane in flight: record -> pattern (L2) -> LDS is a chain of two loads per record
+    for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 4 * APPLY_THREADS) {
+        uint32_t v[4];
+        ulonglong2 p[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t i = i0 + j * APPLY_THREADS; v[j] = i < n ? src[i] : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = F.patterns[v[j] & 0xFFFFu];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (i0 + j * APPLY_THREADS < n) {
+                const uint32_t bi = v[j] >> 16;
+                const ulonglong2 t = blk_l[bi];
+                const unsigned long long mx = p[j].x & ~t.x, my = p[j].y & ~t.y;
+                if (mx) atomicOr(&w[2 * bi], mx);
+                if (my) atomicOr(&w[2 * bi + 1], my);
+            }
+        }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nblk; i += APPLY_THREADS) F.table[b0 + i] = blk_l[i];

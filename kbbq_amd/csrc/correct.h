@@ -50,7 +50,12 @@ struct Corrector {
     static constexpr int OFF_ON = 2 * NWB + NWN;        // its non-ACGT mask
     static constexpr int OFF_E = 2 * NWB + 2 * NWN;     // error flags
     static constexpr int OFF_T = 2 * NWB + 3 * NWN;     // trusted k-mer mask of the original read
-    static constexpr int WORDS = 2 * NWB + 4 * NWN;
+    // Off-case bases ('a','c','g','t' and the digits seq_nt16_table folds to bases): three loops of the reference
+    // compare RAW characters with the candidates 'A','C','G','T' (bloom.cc:142,218,249; readutils.cc:202), so for
+    // such a base the candidate equal to it is tried as well -- on this->seq only; the left-hand walk runs on the
+    // upper-case `revcomped` string (readutils.cc:351-353).  A fix writes an upper-case letter: the bit is cleared.
+    static constexpr int OFF_LC = 2 * NWB + 4 * NWN;
+    static constexpr int WORDS = 2 * NWB + 5 * NWN;
 
     uint32_t *L;        // this lane's first LDS word
     int stride;         // distance between consecutive words of one lane
@@ -167,9 +172,10 @@ struct Corrector {
         kreset(head);
         for (int i = 0; i < k - 1; ++i) kpush(head, vcode(lo, n, dir, start + i));
         const int unfixed = vcode(lo, n, dir, start + k - 1);
+        const bool raw_differs = dir > 0 && bit(OFF_LC, lo + start + k - 1);      // bloom.cc:142 on an off-case base
         for (int jj = 0; jj < 4; ++jj) {
             const int cand = dir > 0 ? jj : 3 - jj;
-            if (cand == unfixed) continue;
+            if (cand == unfixed && !raw_differs) continue;
             Km m = head;
             int i = k - 1;
             kpush(m, cand);
@@ -207,7 +213,7 @@ struct Corrector {
         for (int i = mod - k + 1; i < mod; ++i) kpush(m, vcode(lo, n, dir, i));
         const int at_mod = vcode(lo, n, dir, mod);
         for (int c = 0; c < 4; ++c) {
-            if (at_mod == c) continue;
+            if (at_mod == c && !(dir > 0 && bit(OFF_LC, lo + mod))) continue;
             Km nk = m;
             kpush(nk, c);
             for (int i = 0; i <= k; ++i) {
@@ -222,7 +228,7 @@ struct Corrector {
             for (int j = mod - k + 1; j < mod; ++j) kpush(m, vcode(lo, n, dir, j));
             const int here = vcode(lo, n, dir, mod);
             for (int c = 0; c < 4; ++c) {
-                if (here == c) continue;
+                if (here == c && !(dir > 0 && bit(OFF_LC, lo + mod))) continue;
                 Km nk = m;
                 kpush(nk, c);
                 if (kvalid(nk) && query(nk)) {
@@ -269,7 +275,7 @@ struct Corrector {
         for (int i = 0; i < n; ++i) {
             const int orig = code(lo + i);
             for (int c = 0; c < 4; ++c) {
-                if (orig == c) continue;
+                if (orig == c && !bit(OFF_LC, lo + i)) continue;
                 setcode(lo + i, c);
                 const int start = i > k - 1 ? i - k + 1 : 0;
                 const int magic = i > k / 2 - 1 ? min(i - k / 2 + 1, n - k) : 0;
@@ -287,7 +293,7 @@ struct Corrector {
             }
             setcode(lo + i, orig);
         }
-        if (best_len > 0) setcode(lo + best_pos, best_base);
+        if (best_len > 0) { setcode(lo + best_pos, best_base); setbit(OFF_LC, lo + best_pos, false); }
         fixed_base = best_base;
         return best_pos;
     }
@@ -340,6 +346,7 @@ struct Corrector {
                         if (next_untrusted <= largest || largest - i + 1 < k) { res.bad_suffix = i; break; }
                     } else {
                         vset(lo, n, +1, i, fx.best0);
+                        setbit(OFF_LC, lo + i, false);
                         setbit(OFF_E, lo + i, true);
                     }
                     corrected = true;

@@ -19,6 +19,7 @@ struct ReadsDev {
     const uint64_t *offsets;   // null => uniform
     const uint8_t *flags;      // null => 0
     const uint16_t *rg;        // null => 0
+    const uint64_t *offcase;   // null => none: 1 bit per base, ACGT bases whose raw character is not the upper-case letter
     uint32_t *hint_sampled;    // optional: 1 bit per base, set where this read itself inserted the k-mer starting there
     uint32_t *hint_trusted;    //           into the sampled (pass 1) / trusted (pass 2) filter
     uint64_t n_reads;

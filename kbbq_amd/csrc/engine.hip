@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -109,10 +110,23 @@ struct kbbq_engine {
     int8_t *d_dq_cycle = nullptr;
     int8_t *d_dq_dinuc = nullptr;
     // scratch
-    void *scratch[16] = {};
-    size_t scratch_bytes[16] = {};
+    void *scratch[20] = {};
+    size_t scratch_bytes[20] = {};
     unsigned long long *d_counters = nullptr;   // [0] work-list length, [1] correction queries, [2] scan total
-    std::vector<void *> staged;   // device copies of host batches, freed at the next sync
+    // Host batches: a ring of device staging slots owned by the engine and a copy stream.  A host batch is copied
+    // into the next slot with hipMemcpyAsync on the copy stream (DMA straight from the caller's memory when that is
+    // page-locked), the pass's kernels wait for the copy by event, and the entry point returns as soon as the COPY
+    // has finished: the caller's memory is its own again while the kernels still run, so the copy of batch i+1
+    // overlaps the kernels of batch i.  A slot is reused once the kernels that read it have finished (events).
+    struct StageSlot {
+        char *dev = nullptr;
+        size_t bytes = 0;
+        hipEvent_t h2d = nullptr, done[2] = {nullptr, nullptr};     // done[0]: main stream, done[1]: side stream
+        bool busy[2] = {false, false};
+    } slot[3];
+    int slot_turn = 0, cur_slot = -1;
+    bool cur_slot_side = false;      // the batch in cur_slot is also read on the side stream (pass 3)
+    hipStream_t copy = nullptr;
     uint64_t stats[4] = {0, 0, 0, 0};
     // profiling
     std::vector<ProfileSlot> prof;
@@ -211,9 +225,10 @@ void drain_profile(kbbq_engine *e) {
 int collect_side(kbbq_engine *e, int t) {
     if (!e->side_busy[t]) return KBBQ_OK;
     HIP_TRY(hipEventSynchronize(e->ev_side[t]));
-    unsigned long long c[2];
+    unsigned long long c[2], c3 = 0;
     HIP_TRY(hipMemcpy(c, e->d_counters + 4 * t, 16, hipMemcpyDeviceToHost));
-    e->stats[0] += c[0];
+    HIP_TRY(hipMemcpy(&c3, e->d_counters + 6 + t, 8, hipMemcpyDeviceToHost));      // reads with off-case bases (lane-form walk)
+    e->stats[0] += c[0] + c3;
     e->stats[1] += c[1];
     e->stats[2] += e->side_reads[t];
     e->side_busy[t] = false;
@@ -228,24 +243,21 @@ int sync_engine(kbbq_engine *e) {
         if (rc) return rc;
     }
     drain_profile(e);
-    for (size_t i = 0; i < e->staged.size(); ++i) hipFree(e->staged[i]);
-    e->staged.clear();
     return KBBQ_OK;
 }
 
-// A host batch is the caller's again when the entry point returns, on EVERY path: error returns after staging
-// has begun, and returns that skip the kernels, still wait for the copies in flight and free the staged buffers.
+// A host batch is the caller's again when the entry point returns, on EVERY path (error returns included): the
+// guard waits for the batch's copy into its staging slot -- not for the kernels -- and notes when the slot is free.
 struct HostBatchDone {
     kbbq_engine *e;
-    bool host;
-    HostBatchDone(kbbq_engine *e_, const kbbq_reads *r) : e(e_), host(r && !r->on_device) {}
+    HostBatchDone(kbbq_engine *e_, const kbbq_reads *) : e(e_) { e->cur_slot = -1; e->cur_slot_side = false; }
     ~HostBatchDone() {
-        if (host && (!e->staged.empty())) {
-            hipStreamSynchronize(e->stream);
-            hipStreamSynchronize(e->stream2);
-            for (size_t i = 0; i < e->staged.size(); ++i) hipFree(e->staged[i]);
-            e->staged.clear();
-        }
+        if (e->cur_slot < 0) return;
+        kbbq_engine::StageSlot &s = e->slot[e->cur_slot];
+        if (hipEventRecord(s.done[0], e->stream) == hipSuccess) s.busy[0] = true;
+        if (e->cur_slot_side && hipEventRecord(s.done[1], e->stream2) == hipSuccess) s.busy[1] = true;
+        hipEventSynchronize(s.h2d);
+        e->cur_slot = -1;
     }
 };
 
@@ -256,20 +268,42 @@ struct HostBatchDone {
         HIP_TRY(hipSetDevice((e)->p.device));                                                         \
     } while (0)
 
-template <typename T>
-int stage_array(kbbq_engine *e, const T *host, size_t count, size_t pad_count, const T **dev) {
-    if (!host) { *dev = nullptr; return KBBQ_OK; }
-    void *d = nullptr;
-    HIP_TRY(hipMalloc(&d, (count + pad_count) * sizeof(T)));
-    e->staged.push_back(d);
-    if (pad_count) HIP_TRY(hipMemsetAsync((char *)d + count * sizeof(T), 0, pad_count * sizeof(T), e->stream));
-    HIP_TRY(hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, e->stream));
-    *dev = (const T *)d;
+// one non-blocking copy stream per device for uploads made before any engine exists (kept for the life of the process)
+hipStream_t shared_copy_stream(int device) {
+    static std::mutex m;
+    static std::map<int, hipStream_t> streams;
+    std::lock_guard<std::mutex> lock(m);
+    std::map<int, hipStream_t>::iterator it = streams.find(device);
+    if (it != streams.end()) return it->second;
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    streams[device] = st;
+    return st;
+}
+
+// next staging slot, at least `need` bytes, not read by any kernel any more
+int acquire_slot(kbbq_engine *e, size_t need, kbbq_engine::StageSlot **out) {
+    kbbq_engine::StageSlot &s = e->slot[e->slot_turn];
+    for (int t = 0; t < 2; ++t)
+        if (s.busy[t]) { HIP_TRY(hipEventSynchronize(s.done[t])); s.busy[t] = false; }
+    if (s.bytes < need) {
+        if (s.dev) HIP_TRY(hipFree(s.dev));
+        s.dev = nullptr; s.bytes = 0;
+        const size_t want = need + need / 8 + 4096;
+        HIP_TRY(hipMalloc(&s.dev, want));
+        s.bytes = want;
+    }
+    e->cur_slot = e->slot_turn;
+    e->slot_turn = (e->slot_turn + 1) % 3;
+    *out = &s;
     return KBBQ_OK;
 }
 
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 // device view of a batch; host batches are copied (freed at the next sync)
-int device_view(kbbq_engine *e, const kbbq_reads *in, ReadsDev *out, int *max_len) {
+// need_qual = false (pass 1: k-mers only): a host batch's qualities are not copied
+int device_view(kbbq_engine *e, const kbbq_reads *in, ReadsDev *out, int *max_len, bool need_qual = true) {
     if (!in) return fail(KBBQ_EINVAL, "null batch");
     if (in->n_reads == 0) return fail(KBBQ_EINVAL, "empty batch");
     if (!in->offsets && in->read_len == 0) return fail(KBBQ_EINVAL, "batch has neither offsets nor read_len");
@@ -282,19 +316,13 @@ int device_view(kbbq_engine *e, const kbbq_reads *in, ReadsDev *out, int *max_le
     R.read_len = in->read_len;
     R.hint_sampled = nullptr;
     R.hint_trusted = nullptr;
+    R.offcase = nullptr;
     if (in->on_device) {
         R.bases = in->bases; R.nmask = in->nmask; R.qual = in->qual;
         R.offsets = in->offsets; R.flags = in->flags; R.rg = in->rg;
         R.hint_sampled = (uint32_t *)in->hint_sampled;
         R.hint_trusted = (uint32_t *)in->hint_trusted;
-    } else {
-        int rc;
-        if ((rc = stage_array(e, in->bases, in->n_bases / 32 + 1, 1, &R.bases))) return rc;
-        if ((rc = stage_array(e, in->nmask, in->n_bases / 64 + 1, 1, &R.nmask))) return rc;
-        if ((rc = stage_array(e, in->qual, in->n_bases, 16, &R.qual))) return rc;
-        if ((rc = stage_array(e, in->offsets, in->offsets ? in->n_reads + 1 : 0, 0, &R.offsets))) return rc;
-        if ((rc = stage_array(e, in->flags, in->flags ? in->n_reads : 0, 0, &R.flags))) return rc;
-        if ((rc = stage_array(e, in->rg, in->rg ? in->n_reads : 0, 0, &R.rg))) return rc;
+        R.offcase = in->offcase;
     }
     uint64_t host_longest = 0;
     if (!in->on_device && in->offsets) {
@@ -306,6 +334,40 @@ int device_view(kbbq_engine *e, const kbbq_reads *in, ReadsDev *out, int *max_le
                 return fail(KBBQ_ERANGE, "read %llu is longer than params.max_read_len %d", (unsigned long long)r, e->p.max_read_len);
             host_longest = std::max(host_longest, l);
         }
+    }
+    if (!in->on_device) {
+        if (!in->bases || !in->nmask || !in->qual) return fail(KBBQ_EINVAL, "batch without bases, nmask or qual");
+        // one staging slot holds the batch: bases, N mask, qualities (+ offsets, flags, read groups), each padded as
+        // the kernels expect (one spare zero word behind the packed arrays, 16 zero bytes behind the qualities)
+        const size_t nb_b = (in->n_bases / 32 + 1) * 8, nb_m = (in->n_bases / 64 + 1) * 8, nb_q = in->n_bases;
+        const size_t nb_o = in->offsets ? (in->n_reads + 1) * 8 : 0, nb_f = in->flags ? in->n_reads : 0, nb_g = in->rg ? in->n_reads * 2 : 0;
+        const size_t nb_c = in->offcase ? nb_m : 0;
+        const size_t o_b = 0, o_m = align256(o_b + nb_b + 8), o_q = align256(o_m + nb_m + 8), o_o = align256(o_q + nb_q + 16),
+                     o_f = align256(o_o + nb_o), o_g = align256(o_f + nb_f), o_c = align256(o_g + nb_g), total = align256(o_c + nb_c + 8);
+        kbbq_engine::StageSlot *sl;
+        int rc = acquire_slot(e, total, &sl);
+        if (rc) return rc;
+        char *d = sl->dev;
+        HIP_TRY(hipMemsetAsync(d + o_b + nb_b, 0, 8, e->copy));
+        HIP_TRY(hipMemsetAsync(d + o_m + nb_m, 0, 8, e->copy));
+        HIP_TRY(hipMemsetAsync(d + o_q + nb_q, 0, 16, e->copy));
+        HIP_TRY(hipMemcpyAsync(d + o_b, in->bases, nb_b, hipMemcpyHostToDevice, e->copy));
+        HIP_TRY(hipMemcpyAsync(d + o_m, in->nmask, nb_m, hipMemcpyHostToDevice, e->copy));
+        if (need_qual) HIP_TRY(hipMemcpyAsync(d + o_q, in->qual, nb_q, hipMemcpyHostToDevice, e->copy));
+        if (nb_o) HIP_TRY(hipMemcpyAsync(d + o_o, in->offsets, nb_o, hipMemcpyHostToDevice, e->copy));
+        if (nb_f) HIP_TRY(hipMemcpyAsync(d + o_f, in->flags, nb_f, hipMemcpyHostToDevice, e->copy));
+        if (nb_g) HIP_TRY(hipMemcpyAsync(d + o_g, in->rg, nb_g, hipMemcpyHostToDevice, e->copy));
+        if (nb_c) {
+            HIP_TRY(hipMemsetAsync(d + o_c + nb_c, 0, 8, e->copy));
+            HIP_TRY(hipMemcpyAsync(d + o_c, in->offcase, nb_c, hipMemcpyHostToDevice, e->copy));
+        }
+        HIP_TRY(hipEventRecord(sl->h2d, e->copy));
+        HIP_TRY(hipStreamWaitEvent(e->stream, sl->h2d, 0));      // (the side stream only ever follows the main one)
+        R.bases = (const uint64_t *)(d + o_b); R.nmask = (const uint64_t *)(d + o_m); R.qual = (const uint8_t *)(d + o_q);
+        R.offsets = nb_o ? (const uint64_t *)(d + o_o) : nullptr;
+        R.flags = nb_f ? (const uint8_t *)(d + o_f) : nullptr;
+        R.rg = nb_g ? (const uint16_t *)(d + o_g) : nullptr;
+        R.offcase = nb_c ? (const uint64_t *)(d + o_c) : nullptr;
     }
     *out = R;
     // longest read (selects the kernel variants): uniform => read_len; ragged host batch => measured;
@@ -383,14 +445,20 @@ uint64_t env_u64(const char *name, uint64_t dflt) {
     return v && *v ? strtoull(v, nullptr, 10) : dflt;
 }
 
+bool bucket_private() {      // level-1 regions per emitting workgroup (default) or per XCD (KBBQ_BUCKET_SHARED=1), bucket.h
+    static const bool shared = getenv("KBBQ_BUCKET_SHARED") && atoi(getenv("KBBQ_BUCKET_SHARED")) != 0;
+    return !shared;
+}
+
 void bucket_shape(uint64_t n_blocks, uint64_t capacity, uint32_t *n_sub, int *nb1, uint32_t *cap1, uint32_t *cap2) {
     *n_sub = (uint32_t)((n_blocks + SUB_BLOCKS - 1) >> SUB_BITS);
     *nb1 = (int)((*n_sub + NB2 - 1) >> NB2_BITS);
-    // Regions are sized for evenly spread hashes: a full level-1 bucket receives 2^21 / n_blocks of the records (an
-    // eighth of that per XCD), a full subslice 2^12 / n_blocks; plus 15 % (the XCDs' shares of the work differ a
-    // little) and 25 % (a few thousand records per subslice).  What does not fit is inserted directly.
+    // Regions are sized for evenly spread hashes: a full level-1 bucket receives 2^21 / n_blocks of the records (one
+    // n_src-th of that per source region), a full subslice 2^12 / n_blocks; plus 15 % (the sources' shares of the work
+    // differ a little) and 25 % (a few thousand records per subslice).  What does not fit is inserted directly.
     const double f1 = std::min(1.0, (double)(1ULL << L1_SHIFT) / (double)n_blocks), f2 = std::min(1.0, (double)SUB_BLOCKS / (double)n_blocks);
-    *cap1 = (uint32_t)std::min(4.0e9, (double)capacity * 1.15 * f1 / N_XCD) + 64;
+    const int n_src = bucket_private() ? EMIT_GRID : N_XCD;
+    *cap1 = (uint32_t)std::min(4.0e9, (double)capacity * 1.15 * f1 / n_src) + 64;
     *cap2 = (uint32_t)std::min(4.0e9, (double)capacity * 1.25 * f2) + 32;
 }
 
@@ -403,10 +471,12 @@ BucketDev bucket_dev(kbbq_engine *e, int w) {
     B.l2_cnt = e->bk.l2_cnt;
     B.tickets = e->bk.tickets;
     B.direct = e->bk.direct;
+    B.n_src = bucket_private() ? EMIT_GRID : N_XCD;
+    B.cnt_stride = bucket_private() ? 1 : CNT_STRIDE;
     return B;
 }
 
-const size_t kL1CntBytes = (size_t)N_XCD * MAX_NB1 * CNT_STRIDE * 4, kL2CntBytes = (size_t)MAX_NB1 * NB2 * 4, kTicketBytes = (size_t)N_XCD * CNT_STRIDE * 4;
+const size_t kL1CntBytes = (size_t)EMIT_GRID * MAX_NB1 * 4, kL2CntBytes = (size_t)MAX_NB1 * NB2 * 4, kTicketBytes = (size_t)N_XCD * CNT_STRIDE * 4;
 
 // Decide (once per filter) whether its inserts are bucketed, and allocate the record buffers at the first use:
 // by then the caller's resident batches are in HBM, so "a share of what is free" is a safe size.
@@ -430,7 +500,7 @@ bool bucket_on(kbbq_engine *e, int w) {
         for (int f = 0; f < 2; ++f) {
             uint32_t n_sub, cap1, cap2; int nb1;
             bucket_shape(e->filt[f].spec.n_blocks, cap, &n_sub, &nb1, &cap1, &cap2);
-            l1_bytes = std::max(l1_bytes, (size_t)N_XCD * nb1 * cap1 * 8);
+            l1_bytes = std::max(l1_bytes, (size_t)(bucket_private() ? EMIT_GRID : N_XCD) * nb1 * cap1 * 8);
             l2_bytes = std::max(l2_bytes, (size_t)n_sub * cap2 * 4);
         }
         hipError_t he = hipMalloc(&b.l1, l1_bytes);
@@ -553,8 +623,13 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
     for (int t = 0; t < 2 && he == hipSuccess; ++t) he = hipEventCreateWithFlags(&e->ev_ins[t], hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_side[0], hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_side[1], hipEventDisableTiming);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->copy, hipStreamNonBlocking);
+    for (int i = 0; i < 3 && he == hipSuccess; ++i) {
+        he = hipEventCreateWithFlags(&e->slot[i].h2d, hipEventDisableTiming);
+        for (int t = 0; t < 2 && he == hipSuccess; ++t) he = hipEventCreateWithFlags(&e->slot[i].done[t], hipEventDisableTiming);
+    }
     e->cur = e->stream;
-    if (he != hipSuccess) { delete e; return fail(KBBQ_EIO, "hipStreamCreate: %s", hipGetErrorString(he)); }
+    if (he != hipSuccess) { kbbq_engine_destroy(e); return fail(KBBQ_EIO, "hipStreamCreate: %s", hipGetErrorString(he)); }
 #define CREATE_TRY(expr)                                                                           \
     do {                                                                                           \
         hipError_t _e = (expr);                                                                    \
@@ -605,8 +680,15 @@ void kbbq_engine_destroy(kbbq_engine *e) {
     if (!e) return;
     hipSetDevice(e->p.device);
     if (e->stream) { hipStreamSynchronize(e->stream); }
+    if (e->stream2) hipStreamSynchronize(e->stream2);
+    if (e->copy) hipStreamSynchronize(e->copy);
     drain_profile(e);
-    for (size_t i = 0; i < e->staged.size(); ++i) hipFree(e->staged[i]);
+    for (int i = 0; i < 3; ++i) {
+        hipFree(e->slot[i].dev);
+        if (e->slot[i].h2d) hipEventDestroy(e->slot[i].h2d);
+        for (int t = 0; t < 2; ++t) if (e->slot[i].done[t]) hipEventDestroy(e->slot[i].done[t]);
+    }
+    if (e->copy) hipStreamDestroy(e->copy);
     for (int w = 0; w < 2; ++w) {
         hipFree(e->filt[w].d_table);
         hipFree(e->filt[w].d_patterns);
@@ -624,7 +706,7 @@ void kbbq_engine_destroy(kbbq_engine *e) {
     hipFree(e->d_qcum);
     hipFree(e->d_errthr);
     hipFree(e->bk.l1); hipFree(e->bk.l2); hipFree(e->bk.l1_cnt); hipFree(e->bk.l2_cnt); hipFree(e->bk.tickets); hipFree(e->bk.direct);
-    for (int i = 0; i < 16; ++i) hipFree(e->scratch[i]);
+    for (int i = 0; i < 20; ++i) hipFree(e->scratch[i]);
     if (e->stream2) { hipStreamSynchronize(e->stream2); hipStreamDestroy(e->stream2); }
     if (e->ev_main) hipEventDestroy(e->ev_main);
     if (e->ev_draw) hipEventDestroy(e->ev_draw);
@@ -793,6 +875,23 @@ int kbbq_pack_bases(const uint8_t *seq, uint64_t n_bases, uint64_t *bases_out, u
     return KBBQ_OK;
 }
 
+int kbbq_pack_bases_case(const uint8_t *seq, uint64_t n_bases, uint64_t *bases_out, uint64_t *nmask_out, uint64_t *offcase_out,
+                         uint64_t *n_offcase) {
+    if (!offcase_out) return fail(KBBQ_EINVAL, "null argument");
+    int rc = kbbq_pack_bases(seq, n_bases, bases_out, nmask_out);
+    if (rc) return rc;
+    memset(offcase_out, 0, (n_bases / 64 + 2) * 8);
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < n_bases; ++i) {
+        const uint8_t ch = seq[i];
+        // an ACGT base (bloom.hh:351 folds a/c/g/t and '0'..'3' too) whose raw character is not the upper-case letter
+        const bool odd = ch == 'a' || ch == 'c' || ch == 'g' || ch == 't' || (ch >= '0' && ch <= '3');
+        if (odd) { offcase_out[i >> 6] |= 1ULL << (i & 63); ++n; }
+    }
+    if (n_offcase) *n_offcase = n;
+    return KBBQ_OK;
+}
+
 int kbbq_reads_upload(kbbq_engine *e, const kbbq_reads *host, kbbq_reads *dev) {
     // e may be NULL: batches can be made resident before the engine (whose size depends on them) exists
     if (!host || !dev) return fail(KBBQ_EINVAL, "null argument");
@@ -803,16 +902,27 @@ int kbbq_reads_upload(kbbq_engine *e, const kbbq_reads *host, kbbq_reads *dev) {
     dev->hint_sampled = nullptr;
     dev->hint_trusted = nullptr;
     dev->bases = nullptr; dev->nmask = nullptr; dev->qual = nullptr; dev->offsets = nullptr; dev->flags = nullptr; dev->rg = nullptr;
+    dev->offcase = nullptr;
+    // all arrays travel on ONE copy stream (the engine's, or the device's shared one when there is no engine yet) as
+    // asynchronous copies -- DMA straight from the caller's memory when it is page-locked (kbbq_host_alloc) -- and the
+    // call returns when the last one has landed: kernels of earlier batches keep running underneath
+    hipStream_t cs = e ? e->copy : nullptr;
+    if (!cs) {
+        int cur = 0;
+        HIP_TRY(hipGetDevice(&cur));
+        if (!(cs = shared_copy_stream(cur))) return fail(KBBQ_EIO, "no copy stream for device %d", cur);
+    }
 #define UP(field, type, count, pad)                                                               \
     if (host->field) {                                                                            \
         void *d = nullptr;                                                                        \
         hipError_t he = hipMalloc(&d, ((count) + (pad)) * sizeof(type));                          \
         if (he == hipSuccess) {                                                                   \
             dev->field = (const type *)d;                                                         \
-            he = hipMemset(d, 0, ((count) + (pad)) * sizeof(type));                               \
+            if (pad) he = hipMemsetAsync((char *)d + (count) * sizeof(type), 0, (pad) * sizeof(type), cs); \
         }                                                                                         \
-        if (he == hipSuccess) he = hipMemcpy(d, host->field, (count) * sizeof(type), hipMemcpyHostToDevice); \
+        if (he == hipSuccess) he = hipMemcpyAsync(d, host->field, (count) * sizeof(type), hipMemcpyHostToDevice, cs); \
         if (he != hipSuccess) {                                                                   \
+            hipStreamSynchronize(cs);                                                             \
             kbbq_reads_free(nullptr, dev);   /* what was allocated so far */                      \
             return fail(he == hipErrorOutOfMemory ? KBBQ_ENOMEM : KBBQ_EIO, "upload of %s: %s", #field, hipGetErrorString(he)); \
         }                                                                                         \
@@ -823,10 +933,62 @@ int kbbq_reads_upload(kbbq_engine *e, const kbbq_reads *host, kbbq_reads *dev) {
     UP(offsets, uint64_t, host->n_reads + 1, 0)
     UP(flags, uint8_t, host->n_reads, 0)
     UP(rg, uint16_t, host->n_reads, 0)
+    UP(offcase, uint64_t, host->n_bases / 64 + 1, 1)
 #undef UP
-    // the copies above are blocking null-stream copies; the engine's streams are non-blocking, so kernels of
-    // earlier batches keep running underneath an upload (no device-wide wait here)
-    HIP_TRY(hipStreamSynchronize(0));
+    HIP_TRY(hipStreamSynchronize(cs));
+    return KBBQ_OK;
+}
+
+// ---- page-locked host memory for batches, and what the host link delivers
+int kbbq_host_alloc(size_t bytes, void **out) {
+    if (!out || !bytes) return fail(KBBQ_EINVAL, "bad argument");
+    *out = nullptr;
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return KBBQ_OK;
+}
+
+int kbbq_host_free(void *p) {
+    if (p) HIP_TRY(hipHostFree(p));
+    return KBBQ_OK;
+}
+
+int kbbq_measure_host_link(int32_t device, uint64_t bytes, double *h2d_gbps, double *d2h_gbps) {
+    if (!bytes) return fail(KBBQ_EINVAL, "bad argument");
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    void *h = nullptr, *d = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t st = nullptr;
+    int rc = KBBQ_OK;
+    float ms_up = 0, ms_dn = 0;
+#define LINK_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess && rc == KBBQ_OK) rc = fail(KBBQ_EIO, "%s: %s", #x, hipGetErrorString(_e)); } while (0)
+    LINK_TRY(hipHostMalloc(&h, bytes, hipHostMallocDefault));
+    LINK_TRY(hipMalloc(&d, bytes));
+    LINK_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    LINK_TRY(hipEventCreate(&a));
+    LINK_TRY(hipEventCreate(&b));
+    if (rc == KBBQ_OK) {
+        memset(h, 1, bytes);
+        LINK_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st));      // warm-up
+        LINK_TRY(hipEventRecord(a, st));
+        LINK_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st));
+        LINK_TRY(hipEventRecord(b, st));
+        LINK_TRY(hipEventSynchronize(b));
+        LINK_TRY(hipEventElapsedTime(&ms_up, a, b));
+        LINK_TRY(hipEventRecord(a, st));
+        LINK_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, st));
+        LINK_TRY(hipEventRecord(b, st));
+        LINK_TRY(hipEventSynchronize(b));
+        LINK_TRY(hipEventElapsedTime(&ms_dn, a, b));
+    }
+#undef LINK_TRY
+    if (a) hipEventDestroy(a);
+    if (b) hipEventDestroy(b);
+    if (st) hipStreamDestroy(st);
+    hipFree(d);
+    if (h) hipHostFree(h);
+    if (rc) return rc;
+    if (h2d_gbps) *h2d_gbps = ms_up > 0 ? (double)bytes / ms_up / 1e6 : 0;
+    if (d2h_gbps) *d2h_gbps = ms_dn > 0 ? (double)bytes / ms_dn / 1e6 : 0;
     return KBBQ_OK;
 }
 
@@ -841,7 +1003,7 @@ int kbbq_reads_free(kbbq_engine *e, kbbq_reads *dev) {
         HIP_TRY(hipDeviceSynchronize());
     }
     hipFree((void *)dev->bases); hipFree((void *)dev->nmask); hipFree((void *)dev->qual);
-    hipFree((void *)dev->offsets); hipFree((void *)dev->flags); hipFree((void *)dev->rg);
+    hipFree((void *)dev->offsets); hipFree((void *)dev->flags); hipFree((void *)dev->rg); hipFree((void *)dev->offcase);
     memset(dev, 0, sizeof *dev);
     return KBBQ_OK;
 }
@@ -891,12 +1053,10 @@ int kbbq_count_kmer_positions(kbbq_engine *e, const kbbq_reads *reads, uint64_t 
     if (!e || !reads || !out) return fail(KBBQ_EINVAL, "null argument");
     HostBatchDone host_done(e, reads);
     ReadsDev R; int max_len;
-    int rc = device_view(e, reads, &R, &max_len);
+    int rc = device_view(e, reads, &R, &max_len, false);
     if (rc) return rc;
     const uint64_t *kofs;
-    rc = kmer_prefix(e, R, &kofs, out);
-    if (!rc && !reads->on_device) rc = sync_engine(e);
-    return rc;
+    return kmer_prefix(e, R, &kofs, out);      // (a ragged batch: the prefix scan has finished; a uniform one: no device work)
 }
 
 }  // extern "C"
@@ -919,24 +1079,45 @@ template <int NW> struct LaunchSample {
 };
 
 // the same reads -> (block, pattern) records for the slice-bucketed insert (bucket.h)
-template <int NW> struct LaunchEmit {
-    static int go(kbbq_engine *e, int w, ReadsDev R, const uint64_t *mask, uint64_t mask_words, const uint64_t *kofs,
-                  unsigned long long *inserted) {
-        constexpr int RPW = NW == 3 ? 4 : NW == 5 ? 2 : 1;
-        const BucketDev B = bucket_dev(e, w);
-        const uint64_t n_tiles = (R.n_reads + 8 * RPW - 1) / (8 * RPW);
-        const int grid = (int)std::min<uint64_t>(n_tiles, 256 * 2);
-        Timed t(e, w ? "k_emit_trusted" : "k_emit_sampled");
-        if (w == 0)
-            hipLaunchKernelGGL((k_emit_marked<NW, false, RPW>), dim3(grid), dim3(BK_THREADS), 0, e->stream, R, e->K, e->filt[0].dev(), B,
-                               mask, mask_words, kofs, inserted);
-        else
-            hipLaunchKernelGGL((k_emit_marked<NW, true, RPW>), dim3(grid), dim3(BK_THREADS), 0, e->stream, R, e->K, e->filt[1].dev(), B,
-                               mask, mask_words, kofs, inserted);
-        HIP_TRY(hipGetLastError());
-        return KBBQ_OK;
+template <int NW, int CH, int RPW>
+static int launch_emit(kbbq_engine *e, int w, ReadsDev R, const uint64_t *mask, uint64_t mask_words, const uint64_t *kofs,
+                       unsigned long long *inserted) {
+    const BucketDev B = bucket_dev(e, w);
+    const uint64_t n_tiles = (R.n_reads + 8 * RPW - 1) / (8 * RPW);
+    const int grid = (int)std::min<uint64_t>(n_tiles, EMIT_GRID);
+    const size_t lds = (size_t)8 * RPW * CH * 64 * 8;
+    Timed t(e, w ? "k_emit_trusted" : "k_emit_sampled");
+#define KBBQ_EMIT(BYB, PRIV)                                                                                                  \
+    do {                                                                                                                      \
+        const void *fn = (const void *)k_emit_marked<NW, CH, BYB, RPW, PRIV>;                                                  \
+        size_t &raised = e->attr_lds_correct[fn];                                                                             \
+        if (lds > 48 * 1024 && lds > raised) {                                                                                \
+            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
+            raised = lds;                                                                                                     \
+        }                                                                                                                     \
+        hipLaunchKernelGGL((k_emit_marked<NW, CH, BYB, RPW, PRIV>), dim3(grid), dim3(BK_THREADS), lds, e->stream, R, e->K,     \
+                           e->filt[w].dev(), B, mask, mask_words, kofs, inserted);                                            \
+    } while (0)
+    if (bucket_private()) { if (w == 0) KBBQ_EMIT(false, true); else KBBQ_EMIT(true, true); }
+    else                  { if (w == 0) KBBQ_EMIT(false, false); else KBBQ_EMIT(true, false); }
+#undef KBBQ_EMIT
+    HIP_TRY(hipGetLastError());
+    return KBBQ_OK;
+}
+
+// NW by the longest read, CH by the most k-mer starts a read can have
+static int dispatch_emit(kbbq_engine *e, int w, int max_len, ReadsDev R, const uint64_t *mask, uint64_t mask_words, const uint64_t *kofs,
+                         unsigned long long *inserted) {
+    const int max_nk = std::max(1, max_len - e->p.k + 1);
+    static const int rpw8 = getenv("KBBQ_EMIT_RPW") ? atoi(getenv("KBBQ_EMIT_RPW")) : 0;
+    if (max_len <= 192) {
+        if (max_nk <= 128) return rpw8 == 8 ? launch_emit<3, 2, 8>(e, w, R, mask, mask_words, kofs, inserted)
+                                            : launch_emit<3, 2, 4>(e, w, R, mask, mask_words, kofs, inserted);
+        return launch_emit<3, 3, 4>(e, w, R, mask, mask_words, kofs, inserted);
     }
-};
+    if (max_len <= 320) return launch_emit<5, 5, 2>(e, w, R, mask, mask_words, kofs, inserted);
+    return launch_emit<8, 8, 1>(e, w, R, mask, mask_words, kofs, inserted);
+}
 
 extern "C" {
 
@@ -945,7 +1126,7 @@ int kbbq_sample_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t first_km
     if (!e) return fail(KBBQ_EINVAL, "null engine");
     HostBatchDone host_done(e, reads);
     ReadsDev R; int max_len;
-    int rc = device_view(e, reads, &R, &max_len);
+    int rc = device_view(e, reads, &R, &max_len, false);      // pass 1 reads bases only
     if (rc) return rc;
     const uint64_t *kofs; uint64_t n_draws;
     if ((rc = kmer_prefix(e, R, &kofs, &n_draws))) return rc;
@@ -980,7 +1161,7 @@ int kbbq_sample_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t first_km
     if (bucket_on(e, 0)) {
         // deferred: the k-mers become records now and reach the filter at the next flush (bucket.h)
         if ((rc = bucket_reserve(e, 0, (double)n_draws * std::min(1.0, e->p.alpha) * 1.01 + 4096.0, R.n_bases))) return rc;
-        rc = dispatch_nw<LaunchEmit>(max_len, e, 0, R, (const uint64_t *)mask, n_draws / 64 + 2, kofs, e->filt[0].d_inserted);
+        rc = dispatch_emit(e, 0, max_len, R, (const uint64_t *)mask, n_draws / 64 + 2, kofs, e->filt[0].d_inserted);
     } else {
         rc = dispatch_nw<LaunchSample>(max_len, e, R, (const uint64_t *)mask, n_draws / 64 + 2, kofs);
     }
@@ -988,9 +1169,7 @@ int kbbq_sample_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t first_km
         HIP_TRY(hipEventRecord(e->ev_ins[turn], e->stream));
         e->ins_pending[turn] = true;
     }
-    // a host batch is the caller's again when the call returns (its memory may be page-locked: the copies are then
-    // truly asynchronous), and the engine's copies of it are freed
-    if (!rc && !reads->on_device) rc = sync_engine(e);
+    // (a host batch is the caller's again when the call returns: host_done waits for its copy, not for the kernels)
     return rc;
 }
 
@@ -1039,7 +1218,7 @@ int kbbq_set_thresholds(kbbq_engine *e, const int32_t *thresholds, int32_t n) {
 }  // extern "C"
 
 template <int NW> struct LaunchTrusted {
-    static int go(kbbq_engine *e, ReadsDev R, uint32_t *take_bits, uint32_t *err_out) {
+    static int go(kbbq_engine *e, ReadsDev R, uint32_t *take_bits, uint32_t *err_out, int max_len) {
         Thresholds thr;
         memset(&thr, 0, sizeof thr);
         for (size_t i = 0; i < e->thresholds.size() && i <= KBBQ_MAX_KMER; ++i) thr.v[i] = e->thresholds[i];
@@ -1052,8 +1231,8 @@ template <int NW> struct LaunchTrusted {
         if (bucket_on(e, 1)) {
             int rc = bucket_reserve(e, 1, (double)R.n_bases * e->bk.frac_trusted + 4096.0, R.n_bases);
             if (rc) return rc;
-            return LaunchEmit<NW>::go(e, 1, R, (const uint64_t *)take_bits, R.n_bases / 64 + 2, (const uint64_t *)nullptr,
-                                      (unsigned long long *)nullptr);
+            return dispatch_emit(e, 1, max_len, R, (const uint64_t *)take_bits, R.n_bases / 64 + 2, (const uint64_t *)nullptr,
+                                 (unsigned long long *)nullptr);
         }
         {
             Timed t(e, "k_insert_trusted");
@@ -1107,9 +1286,9 @@ int kbbq_trusted_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *infer_
         take_bits = (uint32_t *)e->scratch[8];
         HIP_TRY(hipMemsetAsync(take_bits, 0, (R.n_bases / 64 + 2) * 8, e->stream));
     }
-    if ((rc = dispatch_nw<LaunchTrusted>(max_len, e, R, take_bits, d_err))) return rc;
+    if ((rc = dispatch_nw<LaunchTrusted>(max_len, e, R, take_bits, d_err, max_len))) return rc;
     if ((rc = bit_out_end(e, reads, infer_errors_out, d_err))) return rc;
-    return reads->on_device ? KBBQ_OK : sync_engine(e);      // host batches complete before the call returns
+    return KBBQ_OK;      // device batches are queued; a host batch has been copied (host_done), its kernels are queued too
 }
 
 int kbbq_trusted_finish(kbbq_engine *e, uint64_t *inserted) {
@@ -1141,7 +1320,7 @@ template <int NW> struct LaunchScan {
 };
 
 template <int MAXL, int BLOCK>
-static int launch_correct(kbbq_engine *e, ReadsDev R, const uint32_t *list, const uint64_t *tmask, int tw,
+static int launch_correct(kbbq_engine *e, ReadsDev R, const uint32_t *list, const unsigned long long *n_list, const uint64_t *tmask, int tw,
                           uint32_t *err_bits, uint32_t *patch) {
     typedef Corrector<MAXL> C;
     const size_t lds = (size_t)C::WORDS * BLOCK * 4;
@@ -1154,7 +1333,7 @@ static int launch_correct(kbbq_engine *e, ReadsDev R, const uint32_t *list, cons
     // the work-list length is only known on the device: size the grid for the batch and let lanes stride
     const int blocks = (int)std::min<uint64_t>((R.n_reads + BLOCK - 1) / BLOCK, 256 * 8);
     hipLaunchKernelGGL((k_correct<MAXL, BLOCK>), dim3(blocks), dim3(BLOCK), lds, e->cur, R, e->K, e->filt[1].dev(), list,
-                       (const unsigned long long *)e->cur_cnt, tmask, tw, err_bits, patch, e->cur_cnt);
+                       n_list, tmask, tw, err_bits, patch, e->cur_cnt);
     HIP_TRY(hipGetLastError());
     return KBBQ_OK;
 }
@@ -1246,18 +1425,19 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
     { int frc = bucket_flush_all(e); if (frc) return frc; }      // deferred inserts reach the filters first (bucket.h)
     if (!e || !reads) return fail(KBBQ_EINVAL, "null argument");
     const bool own_err = !(errors_out && reads->on_device);
-    // A device-resident batch stays put after this call returns, so it may still be in flight while the next one
-    // is submitted: such batches alternate between the two sides.  Host batches are staged in buffers the next
-    // call reuses, and a caller's error array is the caller's again on return: those run alone, in order.
+    // A batch whose flags stay inside the engine may still be in flight while the next one is submitted: such
+    // batches alternate between the two sides (a device-resident batch stays put by contract, a host batch sits in
+    // a staging slot that is not reused before its kernels have finished).  A call that returns the flags runs
+    // alone, in order: the caller's array is the caller's again on return.
     static const bool no_overlap = getenv("KBBQ_NO_OVERLAP") != nullptr;
-    const bool overlap = reads->on_device && own_err && !no_overlap;
+    const bool overlap = own_err && !(errors_out && !reads->on_device) && !no_overlap;
     int side = 0, rc;
     if (overlap) {
         side = e->side_turn;
         e->side_turn ^= 1;
         if ((rc = collect_side(e, side))) return rc;       // waits for the batch that last used this side
     } else {
-        if ((rc = sync_engine(e))) return rc;              // (before the batch is staged: this frees staging buffers)
+        if ((rc = sync_engine(e))) return rc;              // both sides' scratch is free
     }
     HostBatchDone host_done(e, reads);
     ReadsDev R; int max_len;
@@ -1300,20 +1480,35 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
         HIP_TRY(hipEventRecord(e->ev_main, e->stream));
         HIP_TRY(hipStreamWaitEvent(e->stream2, e->ev_main, 0));
         e->cur = e->stream2;
+        e->cur_slot_side = true;      // (a host batch: its staging slot is read on the side stream as well)
     }
     // one read per wavefront (correct_wave.h); the one-read-per-lane form (correct.h) serves k < 3
     // and KBBQ_CORRECT=lane (A/B checks)
     static const bool lane_form = getenv("KBBQ_CORRECT") && !strcmp(getenv("KBBQ_CORRECT"), "lane");
     if (lane_form || e->p.k < 3) {
-        if (max_len <= 160) rc = launch_correct<160, 256>(e, R, list, tmask, NW, d_err, patch);
-        else if (max_len <= 320) rc = launch_correct<320, 128>(e, R, list, tmask, NW, d_err, patch);
-        else rc = launch_correct<512, 64>(e, R, list, tmask, NW, d_err, patch);
+        if (max_len <= 160) rc = launch_correct<160, 256>(e, R, list, e->cur_cnt, tmask, NW, d_err, patch);
+        else if (max_len <= 320) rc = launch_correct<320, 128>(e, R, list, e->cur_cnt, tmask, NW, d_err, patch);
+        else rc = launch_correct<512, 64>(e, R, list, e->cur_cnt, tmask, NW, d_err, patch);
     } else {
         if (max_len <= 160) rc = launch_correct_wave<5, 3>(e, R, list, tmask, NW, d_err, patch);
         else if (max_len <= 320) rc = launch_correct_wave<10, 5>(e, R, list, tmask, NW, d_err, patch);
         else rc = launch_correct_wave<16, 8>(e, R, list, tmask, NW, d_err, patch);
     }
     if (rc) return rc;
+    if (R.offcase) {
+        // reads with off-case bases (scan state 3) follow the reference's raw-character comparisons: the one-read-per-lane
+        // walk carries the case bits (correct.h); a second, usually empty, work list
+        if ((rc = ensure_scratch(e, side ? 18 : 17, R.n_reads * 4))) return rc;
+        uint32_t *list3 = (uint32_t *)e->scratch[side ? 18 : 17];
+        unsigned long long *cnt3 = e->d_counters + 6 + side;
+        HIP_TRY(hipMemsetAsync(cnt3, 0, 8, e->cur));
+        hipLaunchKernelGGL(k_compact, dim3((unsigned)((R.n_reads + 1023) / 1024)), dim3(1024), 0, e->cur, dirty, R.n_reads, list3, cnt3, 3);
+        HIP_TRY(hipGetLastError());
+        if (max_len <= 160) rc = launch_correct<160, 256>(e, R, list3, cnt3, tmask, NW, d_err, patch);
+        else if (max_len <= 320) rc = launch_correct<320, 128>(e, R, list3, cnt3, tmask, NW, d_err, patch);
+        else rc = launch_correct<512, 64>(e, R, list3, cnt3, tmask, NW, d_err, patch);
+        if (rc) return rc;
+    }
     if ((rc = run_tally(e, R, d_err, patch, max_len, e->cur))) return rc;
     HIP_TRY(hipEventRecord(e->ev_side[side], e->cur));
     e->side_busy[side] = true;
@@ -1335,13 +1530,15 @@ int kbbq_tally_batch(kbbq_engine *e, const kbbq_reads *reads, const uint64_t *er
     int rc = device_view(e, reads, &R, &max_len);
     if (rc) return rc;
     const uint32_t *d_err = (const uint32_t *)errors;
-    if (!reads->on_device) {
-        const uint64_t *tmp;
-        if ((rc = stage_array(e, errors, reads->n_bases / 64 + 1, 1, &tmp))) return rc;
-        d_err = (const uint32_t *)tmp;
+    if (!reads->on_device) {      // --fixed mode with host batches: the caller's flags go through a scratch array
+        const size_t bytes = (reads->n_bases / 64 + 1) * 8;
+        if ((rc = ensure_scratch(e, 16, bytes + 8))) return rc;
+        HIP_TRY(hipMemsetAsync((char *)e->scratch[16] + bytes, 0, 8, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->scratch[16], errors, bytes, hipMemcpyHostToDevice, e->stream));
+        d_err = (const uint32_t *)e->scratch[16];
     }
     if ((rc = run_tally(e, R, d_err, nullptr, max_len))) return rc;
-    return reads->on_device ? KBBQ_OK : sync_engine(e);      // host batches complete before the call returns
+    return reads->on_device ? KBBQ_OK : sync_engine(e);      // the caller's flag array is free again on return
 }
 
 void *kbbq_covariates_device(kbbq_engine *e, uint64_t *n_words) {

@@ -185,7 +185,7 @@ struct Batch {
     std::vector<BamRecord> bam_recs;
     std::vector<uint8_t> seq, qual, flags;
     std::vector<uint16_t> rg;
-    std::vector<uint64_t> off, bases, nmask;
+    std::vector<uint64_t> off, bases, nmask, offcase;
     kbbq_reads c;
     bool stop_at_empty = false;   // next_str() != "" loops end at the first empty read (kbbq.cc:234, htsiter.cc:95)
     bool fatal = false;
@@ -221,8 +221,14 @@ struct Batch {
         bases.assign(seq.size() / 32 + 2, 0);
         nmask.assign(seq.size() / 64 + 2, 0);
         qual.resize(seq.size() + 16, 0);
-        kbbq_pack_bases(seq.data(), seq.size(), bases.data(), nmask.data());
+        // FASTQ text may be soft-masked: the raw case of a base matters to three comparisons of the reference
+        // (include/kbbq_engine.h: kbbq_reads.offcase); the bit array only travels when some base is off-case.
+        // BAM sequences come out of bam_seq_str upper-case (readutils.hh:30-42).
+        offcase.assign(seq.size() / 64 + 2, 0);
+        uint64_t n_offcase = 0;
+        kbbq_pack_bases_case(seq.data(), seq.size(), bases.data(), nmask.data(), offcase.data(), &n_offcase);
         memset(&c, 0, sizeof c);
+        c.offcase = n_offcase ? offcase.data() : nullptr;
         c.n_reads = rg.size();
         c.n_bases = seq.size();
         c.bases = bases.data();

@@ -502,9 +502,10 @@ __global__ void __launch_bounds__(256) k_scan_trusted(ReadsDev R, KParams K, Fil
     unsigned long long q_total = 0;
     uint64_t off = 0, word = 0;
     uint32_t len = 0;
+    const uint64_t oc_max = R.n_bases / 64 + 1;
     if (wave < R.n_reads) {
         read_span(R, wave, off, len);
-        word = stage_fetch<NW>(R, hint, nullptr, 0, 0, off, lane);
+        word = stage_fetch<NW>(R, hint, R.offcase, off, oc_max, off, lane);
     }
     for (uint64_t r = wave; r < R.n_reads; r += n_waves) {
         __builtin_amdgcn_wave_barrier();
@@ -512,12 +513,20 @@ __global__ void __launch_bounds__(256) k_scan_trusted(ReadsDev R, KParams K, Fil
         __builtin_amdgcn_wave_barrier();
         const uint64_t cur = off;
         const int o31 = (int)(off & 31), o63 = (int)(off & 63);
-        const int nk = (int)len - k + 1;
+        const int Lr = (int)len, nk = Lr - k + 1;
         if (r + n_waves < R.n_reads) {   // the next read's words travel while this one is processed
             read_span(R, r + n_waves, off, len);
-            word = stage_fetch<NW>(R, hint, nullptr, 0, 0, off, lane);
+            word = stage_fetch<NW>(R, hint, R.offcase, off, oc_max, off, lane);
         }
         if (nk <= 0) { if (lane == 0) dirty[r] = 0; continue; }
+        // a read with off-case bases (soft-masked FASTQ) follows the reference's raw-character comparisons: it takes
+        // the one-read-per-lane walk (correct.h), which carries the case bits (state 3)
+        bool odd = false;
+        if (R.offcase) {
+#pragma unroll
+            for (int c = 0; c < NW; ++c)
+                if (c * 64 < Lr) odd = odd || __ballot(c * 64 + lane < Lr && lds_bit(L32 + 2 * S::X, o63 + c * 64 + lane)) != 0;
+        }
         uint64_t M[NW];
         int trusted = 0;
         bool valid[NW], known[NW];
@@ -550,8 +559,8 @@ __global__ void __launch_bounds__(256) k_scan_trusted(ReadsDev R, KParams K, Fil
         }
         // 0 = every k-mer trusted, nothing to do; 2 = settled by the fast path right here (the read is still staged:
         // waves in their lookup rounds and waves streaming through clean reads share the CU); 1 = needs the walk
-        int state = trusted != nk ? 1 : 0;
-        if (state && fast) {
+        int state = trusted != nk ? (odd ? 3 : 1) : 0;
+        if (state == 1 && fast) {
             uint64_t Z[NW];
 #pragma unroll
             for (int c = 0; c < NW; ++c) {
@@ -561,18 +570,19 @@ __global__ void __launch_bounds__(256) k_scan_trusted(ReadsDev R, KParams K, Fil
             if (fast_path<NW>(L32, K, T, Z, nk - trusted, cur, nk, o31, o63, err_bits, lane, q_total)) state = 2;
         }
         if (lane == 0) dirty[r] = (uint8_t)state;
-        if (state == 1 && lane < NW) tmask[r * NW + lane] = sel_word<NW>(M, lane);
+        if ((state & 1) && lane < NW) tmask[r * NW + lane] = sel_word<NW>(M, lane);
     }
     if (lane == 0 && q_total) atomicAdd(&stats[1], q_total);
 }
 
+// match = 0: every read with a non-zero flag; otherwise the reads whose flag equals `match`
 __global__ void __launch_bounds__(1024) k_compact(const uint8_t *dirty, uint64_t n, uint32_t *list,
-                                                   unsigned long long *count, int only_one) {
+                                                   unsigned long long *count, int match) {
     // one global atomic per 1024-lane block: wave counts -> LDS scan -> block base
     __shared__ unsigned int wave_cnt[16];
     __shared__ unsigned long long block_base;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool d = i < n && (only_one ? dirty[i] == 1 : dirty[i] != 0);
+    const bool d = i < n && (match ? dirty[i] == match : dirty[i] != 0);
     const unsigned long long bal = __ballot(d);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) wave_cnt[w] = (unsigned int)__popcll(bal);
@@ -591,7 +601,7 @@ template <int MAXL, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_correct(ReadsDev R, KParams K, FiltDev T, const uint32_t *list,
                                                     const unsigned long long *n_list, const uint64_t *tmask,
                                                     int tmask_words, uint32_t *err_bits, uint32_t *patch,
-                                                    unsigned long long *stats) {
+                                                    unsigned long long *stats) {      // stats[1] += Bloom queries
     typedef Corrector<MAXL> C;
     extern __shared__ uint32_t lds[];
     const uint64_t n = *n_list;
@@ -614,12 +624,13 @@ __global__ void __launch_bounds__(BLOCK) k_correct(ReadsDev R, KParams K, FiltDe
             cx.word(C::OFF_W, w) = w * 16 < len ? (uint32_t)window64(R.bases, 2 * (off + (uint64_t)w * 16)) : 0u;
         for (int w = 0; w < C::NWN; ++w) {
             cx.word(C::OFF_NM, w) = w * 32 < len ? (uint32_t)window64(R.nmask, off + (uint64_t)w * 32) : 0u;
+            cx.word(C::OFF_LC, w) = (R.offcase && w * 32 < len) ? (uint32_t)window64(R.offcase, off + (uint64_t)w * 32) : 0u;
             cx.word(C::OFF_E, w) = 0;
             const int tw = w >> 1;
             cx.word(C::OFF_T, w) = tw < tmask_words ? (uint32_t)(tmask[r * tmask_words + tw] >> (32 * (w & 1))) : 0u;
         }
         // bits past the read end must not look like bases
-        if (len & 31) cx.word(C::OFF_NM, len >> 5) &= (1u << (len & 31)) - 1;
+        if (len & 31) { cx.word(C::OFF_NM, len >> 5) &= (1u << (len & 31)) - 1; cx.word(C::OFF_LC, len >> 5) &= (1u << (len & 31)) - 1; }
         if (len & 15) cx.word(C::OFF_W, len >> 4) &= (1u << ((len & 15) * 2)) - 1;
 
         const int k = K.k;

@@ -79,6 +79,7 @@ class DeviceReads:
         v.on_device = 1
         v.hint_sampled = (self.c.hint_sampled + b0 // 8) if self.c.hint_sampled else None
         v.hint_trusted = (self.c.hint_trusted + b0 // 8) if self.c.hint_trusted else None
+        v.offcase = (self.c.offcase + b0 // 8) if self.c.offcase else None
         d = DeviceReads(self.engine, v, self.max_len)
         d.free = lambda: None
         return d

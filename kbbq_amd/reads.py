@@ -34,8 +34,13 @@ class ReadBatch:
         self.qual[:self.n_bases] = qual
         self.bases = np.zeros(self.n_bases // 32 + 2, dtype=np.uint64)
         self.nmask = np.zeros(self.n_bases // 64 + 2, dtype=np.uint64)
-        _lib.check(L.kbbq_pack_bases(self.seq.ctypes.data_as(_lib.c_u8p), self.n_bases,
-                                     self.bases.ctypes.data_as(_lib.c_u64p), self.nmask.ctypes.data_as(_lib.c_u64p)))
+        # the case bits travel only when some base is off-case (a soft-masked FASTQ): kbbq_reads.offcase stays NULL otherwise
+        self.offcase = np.zeros(self.n_bases // 64 + 2, dtype=np.uint64)
+        n_off = ctypes.c_uint64()
+        _lib.check(L.kbbq_pack_bases_case(self.seq.ctypes.data_as(_lib.c_u8p), self.n_bases,
+                                          self.bases.ctypes.data_as(_lib.c_u64p), self.nmask.ctypes.data_as(_lib.c_u64p),
+                                          self.offcase.ctypes.data_as(_lib.c_u64p), ctypes.byref(n_off)))
+        self.n_offcase = n_off.value
         lens = np.diff(self.off.astype(np.int64))
         self.max_len = int(lens.max()) if self.n_reads else 0
         if uniform is None:
@@ -56,6 +61,7 @@ class ReadBatch:
         self.c.rg = None if self.rg is None else self.rg.ctypes.data
         self.c.read_len = int(lens[0]) if self.uniform else 0
         self.c.on_device = 0
+        self.c.offcase = self.offcase.ctypes.data if self.n_offcase else None
 
     def n_kmer_positions(self, k):
         lens = np.diff(self.off.astype(np.int64))

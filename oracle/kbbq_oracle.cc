@@ -45,14 +45,14 @@ enum {
     C_GET_ERRORS, C_NO_ANCHOR, C_CORRECT_ONE_FIXED, C_EARLY_PATCH_RETURN, C_ADJUST, C_ADJUST_FIRST_TRY,
     C_ADJUST_MOVED, C_ADJUST_STAYED, C_FIX_CALLS, C_EXTENSION_STEPS, C_TIE_STOP, C_TIE_CONTINUE, C_UNFIXABLE,
     C_PREFIX_RECURSION, C_SUFFIX_RECURSION, C_VETO, C_OVERCORRECTED, C_UNFLAG_BACKJUMP, C_FIX_ON_N, C_LEFT_FIX,
-    C_RIGHT_FIX, C_COUNT
+    C_RIGHT_FIX, C_OFFCASE_FIX_CAND, C_OFFCASE_FIX_WON, C_OFFCASE_ADJUST_CAND, C_OFFCASE_ADJUST_MULTIPLE, C_COUNT
 };
 uint64_t g_count[C_COUNT];
 const char *const g_count_names[C_COUNT] = {
     "get_errors", "no_anchor", "correct_one_fixed", "early_patch_return", "adjust", "adjust_first_try",
     "adjust_moved", "adjust_stayed", "fix_calls", "extension_steps", "tie_stop", "tie_continue", "unfixable",
     "prefix_recursion", "suffix_recursion", "veto", "overcorrected", "unflag_backjump", "fix_on_n", "left_fix",
-    "right_fix"};
+    "right_fix", "offcase_fix_candidate", "offcase_fix_won", "offcase_adjust_candidate", "offcase_adjust_multiple"};
 
 constexpr size_t NPOS = static_cast<size_t>(-1);
 constexpr int MAXQ = 93;            // covariateutils.hh:3  KBBQ_MAXQ
@@ -419,6 +419,14 @@ typedef std::vector<uint8_t> Codes;
 
 struct Read {
     Codes seq;                  // base codes 0..4
+    // 1 where the raw character is an ACGT base but not the upper-case letter itself ('a', 'c', 'g', 't', and the
+    // digits '0'..'3' that seq_nt16_table also maps to bases).  K-mers, covariates and the apply step fold such
+    // characters, but three loops of the reference compare the RAW character with the candidates 'A','C','G','T'
+    // (bloom.cc:142 `c == unfixed_char`, bloom.cc:218,249 `seq[modified_idx] == c`, readutils.cc:202
+    // `this->seq[i] == c`), so there the candidate that equals an off-case base is NOT skipped.  A fix writes the
+    // upper-case letter (readutils.cc:327, :232), which clears the flag.  Only this->seq carries raw characters:
+    // the left-hand walk runs on `revcomped`, which seq_nt16_str makes upper-case (readutils.cc:351-353).
+    std::vector<uint8_t> offcase;
     std::vector<uint8_t> qual;
     std::vector<uint8_t> err;   // 0/1 per base (CReadData::errors)
     int rg = 0;
@@ -428,6 +436,7 @@ struct Read {
         r.rg = rg; r.second = second;
         size_t end = (count == NPOS || pos + count > seq.size()) ? seq.size() : pos + count;
         r.seq.assign(seq.begin() + pos, seq.begin() + end);
+        r.offcase.assign(offcase.begin() + pos, offcase.begin() + end);
         r.qual.assign(qual.begin() + pos, qual.begin() + end);
         r.err.assign(err.begin() + pos, err.begin() + end);
         return r;
@@ -502,7 +511,7 @@ void longest_trusted_seq(const Codes &seq, const Filter &t, int k, size_t &a_sta
 
 // bloom.cc:130-188.  `sub` is the read from (error position - k + 1) to its end.
 struct Fix { std::vector<uint8_t> best; size_t stop; bool multiple; };
-Fix longest_fix(Codes sub, const Filter &t, int k, bool reverse_order) {
+Fix longest_fix(Codes sub, const Filter &t, int k, bool reverse_order, bool unfixed_offcase = false) {
     Kmer km(k);
     ++g_count[C_FIX_CALLS];
     Fix out; out.stop = 0; out.multiple = false;
@@ -510,7 +519,8 @@ Fix longest_fix(Codes sub, const Filter &t, int k, bool reverse_order) {
     const uint8_t unfixed = sub[k - 1];
     for (int jj = 0; jj < 4; ++jj) {
         const uint8_t c = (uint8_t)(reverse_order ? 3 - jj : jj);
-        if (c == unfixed) continue;
+        if (c == unfixed && !unfixed_offcase) continue;      // bloom.cc:142 compares raw characters
+        if (c == unfixed) ++g_count[C_OFFCASE_FIX_CAND];
         sub[k - 1] = c;
         km.clear();
         size_t i;
@@ -536,18 +546,20 @@ Fix longest_fix(Codes sub, const Filter &t, int k, bool reverse_order) {
         if (i > out.stop) { out.best.clear(); out.best.push_back(c); out.stop = i; }
         else if (i == out.stop) out.best.push_back(c);
     }
+    if (unfixed_offcase && std::find(out.best.begin(), out.best.end(), unfixed) != out.best.end()) ++g_count[C_OFFCASE_FIX_WON];
     return out;
 }
 
 // bloom.cc:208-277
-std::pair<size_t, bool> adjust_right_anchor(size_t anchor, const Codes &seq, const Filter &t, int k) {
+std::pair<size_t, bool> adjust_right_anchor(size_t anchor, const Codes &seq, const Filter &t, int k,
+                                            const std::vector<uint8_t> *offcase = nullptr) {
     Kmer km(k);
     ++g_count[C_ADJUST];
     bool multiple = false;
     size_t mod = anchor + 1;
     for (size_t i = mod - k + 1; i < mod; ++i) km.push(seq[i]);
     for (uint8_t c = 0; c < 4; ++c) {
-        if (seq[mod] == c) continue;
+        if (seq[mod] == c && !(offcase && (*offcase)[mod])) continue;      // bloom.cc:218, raw characters
         Kmer nk = km;
         nk.push(c);
         for (size_t i = 0; i <= (size_t)k; ++i) {
@@ -561,10 +573,12 @@ std::pair<size_t, bool> adjust_right_anchor(size_t anchor, const Codes &seq, con
         mod = anchor - i;
         for (size_t j = mod - k + 1; j < mod; ++j) km.push(seq[j]);
         for (uint8_t c = 0; c < 4; ++c) {
-            if (seq[mod] == c) continue;
+            if (seq[mod] == c && !(offcase && (*offcase)[mod])) continue;      // bloom.cc:249
+            if (seq[mod] == c) ++g_count[C_OFFCASE_ADJUST_CAND];
             Kmer nk = km;
             nk.push(c);
             if (nk.valid() && t.query(nk)) {
+                if (seq[mod] == c) ++g_count[C_OFFCASE_ADJUST_MULTIPLE];
                 multiple = true;
                 for (size_t j = 0; nk.valid() && t.query(nk) && mod + 1 + j < seq.size() && j <= (size_t)(k / 2); ++j) {
                     nk.push(seq[mod + 1 + j]);
@@ -607,7 +621,7 @@ size_t correct_one(Read &rd, const Filter &t, int k) {
     for (size_t i = 0; i < len; ++i) {
         Codes work(rd.seq);
         for (uint8_t c = 0; c < 4; ++c) {
-            if (rd.seq[i] == c) continue;
+            if (rd.seq[i] == c && !rd.offcase[i]) continue;      // readutils.cc:202, raw characters
             work[i] = c;
             const size_t start = i > (size_t)(k - 1) ? i - k + 1 : 0;
             const size_t magic_start = i > (size_t)(k / 2 - 1) ? std::min(i - k / 2 + 1, len - k) : 0;
@@ -625,7 +639,7 @@ size_t correct_one(Read &rd, const Filter &t, int k) {
             }
         }
     }
-    if (best_len > 0) rd.seq[best_pos] = best_base;
+    if (best_len > 0) { rd.seq[best_pos] = best_base; rd.offcase[best_pos] = 0; }
     return best_pos;
 }
 
@@ -633,6 +647,7 @@ size_t correct_one(Read &rd, const Filter &t, int k) {
 // original EXCEPT on the two early returns (:254, :264), as in the reference.
 void get_errors(Read &rd, const Filter &t, int k, int minqual, bool first_call) {
     const Codes original(rd.seq);
+    const std::vector<uint8_t> original_case(rd.offcase);
     const size_t len = rd.seq.size();
     if (len < (size_t)k) return;    // reference: UB (size_t underflow in correct_one); engine-defined: untouched
     size_t bad_prefix = 0;
@@ -658,13 +673,13 @@ void get_errors(Read &rd, const Filter &t, int k, int minqual, bool first_call) 
     // right side, :271-346
     if (anchor[1] != NPOS) {
         if (anchor_len - k + 1 >= (size_t)k) {
-            std::pair<size_t, bool> adj = adjust_right_anchor(anchor[1], rd.seq, t, k);
+            std::pair<size_t, bool> adj = adjust_right_anchor(anchor[1], rd.seq, t, k, &rd.offcase);
             anchor[1] = adj.first;
             multiple = multiple || adj.second;
         }
         for (size_t i = anchor[1] + 1; i < len;) {
             const size_t start = i - k + 1;
-            Fix fx = longest_fix(Codes(rd.seq.begin() + start, rd.seq.end()), t, k, false);
+            Fix fx = longest_fix(Codes(rd.seq.begin() + start, rd.seq.end()), t, k, false, rd.offcase[i] != 0);
             multiple = multiple || fx.multiple;
             const size_t next_untrusted = start + fx.stop;
             if (next_untrusted > i) {
@@ -681,6 +696,7 @@ void get_errors(Read &rd, const Filter &t, int k, int minqual, bool first_call) 
                     if (rd.seq[i] > 3) ++g_count[C_FIX_ON_N];
                     ++g_count[C_RIGHT_FIX];
                     rd.seq[i] = fx.best[0];
+                    rd.offcase[i] = 0;
                     rd.err[i] = 1;
                 }
                 corrected = true;
@@ -806,6 +822,7 @@ void get_errors(Read &rd, const Filter &t, int k, int minqual, bool first_call) 
         std::copy(sub.err.begin(), sub.err.end(), rd.err.begin() + bad_suffix);
     }
     rd.seq = original;
+    rd.offcase = original_case;
 }
 
 // ---------------------------------------------------------------------------
@@ -964,7 +981,12 @@ Read make_read(const Batch &b, uint64_t r) {
     Read rd;
     const uint64_t s = b.off[r], e = b.off[r + 1];
     rd.seq.resize(e - s);
-    for (uint64_t i = s; i < e; ++i) rd.seq[i - s] = base_code(b.seq[i]);
+    rd.offcase.resize(e - s);
+    for (uint64_t i = s; i < e; ++i) {
+        const uint8_t c = base_code(b.seq[i]);
+        rd.seq[i - s] = c;
+        rd.offcase[i - s] = c < 4 && b.seq[i] != (uint8_t)"ACGT"[c];
+    }
     rd.qual.assign(b.qual + s, b.qual + e);
     rd.err.assign(e - s, 0);
     rd.rg = b.rg ? b.rg[r] : 0;

@@ -123,6 +123,32 @@ def make_wide_quality_dataset(seed=40, **kw):
     return d
 
 
+def make_softmasked_dataset(seed=707, frac=0.04, stretches=120, digits=30, **kw):
+    """Soft-masked FASTQ text: scattered lower-case bases, whole lower-case stretches (masked repeats), and a few of
+    the digits '0'..'3' that seq_nt16_table also folds to bases.  K-mers and covariates fold case, but the reference
+    compares raw characters in find_longest_fix, adjust_right_anchor and correct_one (bloom.cc:142,218,249;
+    readutils.cc:202): for such a base the candidate equal to it is tried too."""
+    d = make_dataset(seed=seed, **kw)
+    rng = np.random.RandomState(seed)
+    seq = d["seq"].copy()
+    off = d["off"].astype(np.int64)
+    acgt = np.isin(seq, np.frombuffer(b"ACGT", dtype=np.uint8))
+    low = (rng.rand(len(seq)) < frac) & acgt
+    n = len(off) - 1
+    for r in rng.choice(n, size=min(stretches, n), replace=False):
+        a, b = off[r], off[r + 1]
+        if b - a < 20:
+            continue
+        s = rng.randint(a, b - 10)
+        low[s:min(b, s + rng.randint(10, 80))] = True
+    low &= acgt
+    seq[low] = seq[low] + 32                      # 'A' -> 'a'
+    idx = rng.choice(np.nonzero(acgt & ~low)[0], size=digits, replace=False)
+    seq[idx] = np.frombuffer(b"0123", dtype=np.uint8)[np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), seq[idx])]
+    d["seq"] = np.ascontiguousarray(seq)
+    return d
+
+
 # The seeded inputs of the GPU parity suite: name -> (dataset builder, dataset kwargs, run kwargs, engine kwargs).
 # tests/test_coverage_cpu.py proves on the CPU that together they reach every branch of get_errors.
 PARITY_CASES = {
@@ -151,6 +177,11 @@ PARITY_CASES = {
                            dict(uniform=True, n_batches=3)),
     "wide_qualities_6rg_250": (make_wide_quality_dataset, dict(genome_len=15000, coverage=24, read_len=250, n_rg=6, paired=True,
                                                               extra_errors=40), dict(n_rg=6), dict(uniform=True, n_batches=2)),
+    # soft-masked text (lower-case bases and digits): raw-character comparisons of the reference, see make_softmasked_dataset
+    "softmasked": (make_softmasked_dataset, dict(seed=606, frac=0.5, genome_len=30000, coverage=25, clusters=400, extra_errors=100), dict(),
+                   dict(uniform=True, n_batches=2)),
+    "softmasked_k9_ragged": (make_softmasked_dataset, dict(seed=9, frac=0.3, genome_len=3000, coverage=30, read_len=100, extra_errors=100,
+                                                          ragged=True, n_rg=2, paired=True), dict(k=9, n_rg=2), dict(uniform=False, n_batches=3)),
     "reads_400": (make_dataset, dict(seed=400, genome_len=20000, coverage=20, read_len=400, n_per_million=500,
                                      extra_errors=60), dict(), dict(uniform=True)),
 }

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 def test_bench_prints_one_contract_line():
     out = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--genome-len", "30000000",
-                          "--cpu-genome-len", "300000"], cwd=common.ROOT, capture_output=True, text=True, timeout=900)
+                          "--cpu-genome-len", "300000", "--pcie-genome-len", "10000000"], cwd=common.ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
@@ -34,13 +34,19 @@ def test_bench_prints_one_contract_line():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Gbases/s" and c["value"] > 0 and "sample" in c
     assert d["result"]["recal_qual_sum"] > 0 and d["result"]["trusted_inserted"] > d["result"]["sampled_inserted"] > 0
+    # the boundary's host-batch mode, PCIe inclusive: never the headline, always beside it
+    p = d["pcie_inclusive"]
+    assert p["host_link"]["h2d_GBps"] > 1 and p["host_link"]["d2h_GBps"] > 1
+    for mode in ("resubmit", "upload_once"):
+        assert 0 < p[mode]["value"] <= p[mode]["bound_Gbases_per_s"] * 1.05 and len(p[mode]["pass_seconds"]) == 4
+    assert r["useful_bytes"] is None or r["useful_bytes"] < r["algorithmic_bytes_per_launch"]
 
 
 def test_bench_two_ranks_reproduce_one_rank():
     """The N > 1 path of bench.py launched the plain way -- `python bench.py --gpus 2`, no torchrun: the script
     spawns its own ranks before it touches a GPU -- here with both ranks on the one GPU of the box and gloo instead
     of RCCL: shards, ordinals, the three exchange steps and the digest must give the N = 1 answer."""
-    common_args = ["--steps", "1", "--warmup", "0", "--genome-len", "30000000", "--no-cpu-baseline"]
+    common_args = ["--steps", "1", "--warmup", "0", "--genome-len", "30000000", "--no-cpu-baseline", "--no-pcie"]
     one = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common_args, cwd=common.ROOT, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-2000:]
     env = dict(os.environ, KBBQ_BENCH_BACKEND="gloo", KBBQ_BENCH_ONE_GPU="1")

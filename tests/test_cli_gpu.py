@@ -81,6 +81,32 @@ def test_cli_recalibrates_fastq_like_the_reference_pipeline(tmp_path):
     assert (ora["recal"] != d["qual"]).any()
 
 
+def test_cli_keeps_the_case_of_a_soft_masked_fastq(tmp_path):
+    """Lower-case bases: written back as they came, and recalibrated as the reference does (its raw-character
+    comparisons included) -- resident and streaming modes alike."""
+    kw = dict(seed=608, genome_len=30000, coverage=25, clusters=400, extra_errors=100)
+    d, names, n_rg = named_dataset(**kw)
+    folded = d["seq"]
+    d["seq"] = common.make_softmasked_dataset(frac=0.5, **kw)["seq"]
+    assert (d["seq"] >= ord("a")).sum() > 1000
+    fq = tmp_path / "soft.fq.gz"
+    write_fastq(fq, d, names)
+    coverage = int(d["off"][-1]) // d["genome_len"]
+    ora = common.run_oracle(dict(d, coverage=coverage), seed=99, n_rg=n_rg)
+    plain = common.run_oracle(dict(d, seq=folded, coverage=coverage), seed=99, n_rg=n_rg)
+    assert (ora["recal"] != plain["recal"]).any()          # the case of the bases does change the reference's answer
+    want_q = (ora["recal"] + 33).astype(np.uint8).tobytes().decode()
+    seq = d["seq"].tobytes().decode()
+    off = d["off"].astype(np.int64)
+    for env in ({"KBBQ_SEED": "99"}, {"KBBQ_SEED": "99", "KBBQ_RESIDENT": "0"}):
+        rc, out, err = run_cli(["-g", d["genome_len"], fq], env)
+        assert rc == 0, err
+        recs = read_fastq_text(gzip.decompress(out))
+        assert len(recs) == len(names)
+        for r, (h, s_, plus, q) in enumerate(recs):
+            assert s_ == seq[off[r]:off[r + 1]] and q == want_q[off[r]:off[r + 1]], "read %d" % r
+
+
 def test_cli_streaming_and_resident_modes_agree(tmp_path):
     """Default: the packed reads stay in GPU memory between the passes; KBBQ_RESIDENT=0: every pass decodes the
     file again like the reference.  Same bytes either way, also with a single compression thread."""
