@@ -37,7 +37,8 @@ extern "C" {
 #define KBBQ_MAX_KMER 32        /* bloom.hh:15 */
 #define KBBQ_MAXQ 93            /* covariateutils.hh:3 */
 #define KBBQ_NQ 94
-#define KBBQ_MAX_READ_LEN 512   /* device kernels keep per-read bit masks in registers/LDS */
+#define KBBQ_MAX_READ_LEN 65535 /* a read's positions travel in 16 bits (the reference has no limit: covariateutils.cc:102-116);
+                                 * reads of up to 512 bases take the staged fast kernels, longer ones the windowed forms */
 #define KBBQ_DEFAULT_BLOOM_SEED 0xA5A5A5A55A5A5A5AULL   /* bloom.hh:389 */
 
 #define KBBQ_SAMPLED 0

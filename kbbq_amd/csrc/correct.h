@@ -42,20 +42,23 @@ struct CallResult {
 
 template <int MAXL>
 struct Corrector {
-    static constexpr int NWB = MAXL / 16;   // 2-bit words
-    static constexpr int NWN = MAXL / 32;   // 1-bit words
-    static constexpr int OFF_W = 0;                     // working sequence
-    static constexpr int OFF_NM = NWB;                  // its non-ACGT mask
-    static constexpr int OFF_O = NWB + NWN;             // sequence at entry of the current call
-    static constexpr int OFF_ON = 2 * NWB + NWN;        // its non-ACGT mask
-    static constexpr int OFF_E = 2 * NWB + 2 * NWN;     // error flags
-    static constexpr int OFF_T = 2 * NWB + 3 * NWN;     // trusted k-mer mask of the original read
+    // MAXL = 0: sized at run time (reads longer than 512 bases; the lane's words then live in global memory)
+    int dyn_len;        // MAXL == 0 only: the capacity in bases, a multiple of 32
+    __device__ __forceinline__ int NWB() const { return (MAXL ? MAXL : dyn_len) / 16; }   // 2-bit words
+    __device__ __forceinline__ int NWN() const { return (MAXL ? MAXL : dyn_len) / 32; }   // 1-bit words
+    __device__ __forceinline__ int OFF_W() const { return 0; }                            // working sequence
+    __device__ __forceinline__ int OFF_NM() const { return NWB(); }                       // its non-ACGT mask
+    __device__ __forceinline__ int OFF_O() const { return NWB() + NWN(); }                // sequence at entry of the current call
+    __device__ __forceinline__ int OFF_ON() const { return 2 * NWB() + NWN(); }           // its non-ACGT mask
+    __device__ __forceinline__ int OFF_E() const { return 2 * NWB() + 2 * NWN(); }        // error flags
+    __device__ __forceinline__ int OFF_T() const { return 2 * NWB() + 3 * NWN(); }        // trusted k-mer mask of the original read
     // Off-case bases ('a','c','g','t' and the digits seq_nt16_table folds to bases): three loops of the reference
     // compare RAW characters with the candidates 'A','C','G','T' (bloom.cc:142,218,249; readutils.cc:202), so for
     // such a base the candidate equal to it is tried as well -- on this->seq only; the left-hand walk runs on the
     // upper-case `revcomped` string (readutils.cc:351-353).  A fix writes an upper-case letter: the bit is cleared.
-    static constexpr int OFF_LC = 2 * NWB + 4 * NWN;
-    static constexpr int WORDS = 2 * NWB + 5 * NWN;
+    __device__ __forceinline__ int OFF_LC() const { return 2 * NWB() + 4 * NWN(); }
+    static constexpr int words_for(int maxl) { return 2 * (maxl / 16) + 5 * (maxl / 32); }
+    static constexpr int WORDS = words_for(MAXL);
 
     uint32_t *L;        // this lane's first LDS word
     int stride;         // distance between consecutive words of one lane
@@ -75,12 +78,12 @@ struct Corrector {
         if (bit(offn, i)) return 4;
         return (word(offb, i >> 4) >> ((i & 15) * 2)) & 3u;
     }
-    __device__ __forceinline__ int code(int i) { return code_in(OFF_W, OFF_NM, i); }
+    __device__ __forceinline__ int code(int i) { return code_in(OFF_W(), OFF_NM(), i); }
     __device__ __forceinline__ void setcode(int i, int c) {   // c in 0..4
-        uint32_t &w = word(OFF_W, i >> 4);
+        uint32_t &w = word(OFF_W(), i >> 4);
         const int sh = (i & 15) * 2;
         w = (w & ~(3u << sh)) | ((uint32_t)(c & 3) << sh);
-        setbit(OFF_NM, i, c > 3);
+        setbit(OFF_NM(), i, c > 3);
         if (c > 3) w &= ~(3u << sh);
     }
     // virtual string: forward, or reverse-complemented (the `revcomped` string of readutils.cc:351-353)
@@ -130,7 +133,7 @@ struct Corrector {
             // T bit s <=> the k-mer starting at base s of the original read is trusted
             const int last = n - k;   // last k-mer start inside the range
             for (int s = 0; s <= last; ++s) {
-                if (bit(OFF_T, lo + s)) {
+                if (bit(OFF_T(), lo + s)) {
                     ++cur;
                 } else {
                     if (cur > best) { best = cur; a1 = s + k - 2; a0 = s - cur; }
@@ -172,7 +175,7 @@ struct Corrector {
         kreset(head);
         for (int i = 0; i < k - 1; ++i) kpush(head, vcode(lo, n, dir, start + i));
         const int unfixed = vcode(lo, n, dir, start + k - 1);
-        const bool raw_differs = dir > 0 && bit(OFF_LC, lo + start + k - 1);      // bloom.cc:142 on an off-case base
+        const bool raw_differs = dir > 0 && bit(OFF_LC(), lo + start + k - 1);      // bloom.cc:142 on an off-case base
         for (int jj = 0; jj < 4; ++jj) {
             const int cand = dir > 0 ? jj : 3 - jj;
             if (cand == unfixed && !raw_differs) continue;
@@ -213,7 +216,7 @@ struct Corrector {
         for (int i = mod - k + 1; i < mod; ++i) kpush(m, vcode(lo, n, dir, i));
         const int at_mod = vcode(lo, n, dir, mod);
         for (int c = 0; c < 4; ++c) {
-            if (at_mod == c && !(dir > 0 && bit(OFF_LC, lo + mod))) continue;
+            if (at_mod == c && !(dir > 0 && bit(OFF_LC(), lo + mod))) continue;
             Km nk = m;
             kpush(nk, c);
             for (int i = 0; i <= k; ++i) {
@@ -228,7 +231,7 @@ struct Corrector {
             for (int j = mod - k + 1; j < mod; ++j) kpush(m, vcode(lo, n, dir, j));
             const int here = vcode(lo, n, dir, mod);
             for (int c = 0; c < 4; ++c) {
-                if (here == c && !(dir > 0 && bit(OFF_LC, lo + mod))) continue;
+                if (here == c && !(dir > 0 && bit(OFF_LC(), lo + mod))) continue;
                 Km nk = m;
                 kpush(nk, c);
                 if (kvalid(nk) && query(nk)) {
@@ -275,7 +278,7 @@ struct Corrector {
         for (int i = 0; i < n; ++i) {
             const int orig = code(lo + i);
             for (int c = 0; c < 4; ++c) {
-                if (orig == c && !bit(OFF_LC, lo + i)) continue;
+                if (orig == c && !bit(OFF_LC(), lo + i)) continue;
                 setcode(lo + i, c);
                 const int start = i > k - 1 ? i - k + 1 : 0;
                 const int magic = i > k / 2 - 1 ? min(i - k / 2 + 1, n - k) : 0;
@@ -293,7 +296,7 @@ struct Corrector {
             }
             setcode(lo + i, orig);
         }
-        if (best_len > 0) { setcode(lo + best_pos, best_base); setbit(OFF_LC, lo + best_pos, false); }
+        if (best_len > 0) { setcode(lo + best_pos, best_base); setbit(OFF_LC(), lo + best_pos, false); }
         fixed_base = best_base;
         return best_pos;
     }
@@ -307,8 +310,8 @@ struct Corrector {
         if (n < k) return res;   // engine-defined (the reference has undefined behaviour here)
         const bool entry_mask_ok = first_call || t_ok;
         // snapshot = original_seq of this activation
-        for (int i = 0; i < NWB; ++i) word(OFF_O, i) = word(OFF_W, i);
-        for (int i = 0; i < NWN; ++i) word(OFF_ON, i) = word(OFF_NM, i);
+        for (int i = 0; i < NWB(); ++i) word(OFF_O(), i) = word(OFF_W(), i);
+        for (int i = 0; i < NWN(); ++i) word(OFF_ON(), i) = word(OFF_NM(), i);
         bool multiple = false;
         int a0, a1;
         longest_trusted(lo, n, entry_mask_ok, a0, a1);
@@ -319,7 +322,7 @@ struct Corrector {
             if (patched_at < 0) return res;
             t_ok = false;
             longest_trusted(lo, n, false, a0, a1);
-            setbit(OFF_E, lo + patched_at, true);
+            setbit(OFF_E(), lo + patched_at, true);
         }
         if (a0 == 0 && a1 < 0) {
             if (patched_at >= 0) { res.patch_pos = lo + patched_at; res.patch_base = patched_base; }
@@ -346,8 +349,8 @@ struct Corrector {
                         if (next_untrusted <= largest || largest - i + 1 < k) { res.bad_suffix = i; break; }
                     } else {
                         vset(lo, n, +1, i, fx.best0);
-                        setbit(OFF_LC, lo + i, false);
-                        setbit(OFF_E, lo + i, true);
+                        setbit(OFF_LC(), lo + i, false);
+                        setbit(OFF_E(), lo + i, true);
                     }
                     corrected = true;
                     i += fx.stop - k + 1;
@@ -378,7 +381,7 @@ struct Corrector {
                         if (next_untrusted <= largest || largest - j + 1 < k) { res.bad_prefix = i; break; }
                     } else {
                         vset(lo, n, -1, j, fx.best0);
-                        setbit(OFF_E, lo + i, true);
+                        setbit(OFF_E(), lo + i, true);
                     }
                     corrected = true;
                     i -= next_untrusted - j;
@@ -396,11 +399,11 @@ struct Corrector {
                 int run0 = -1;
                 const int last = n - k;
                 for (int s = 0; s <= last && adjust; ++s) {
-                    if (bit(OFF_T, lo + s)) {
+                    if (bit(OFF_T(), lo + s)) {
                         if (run0 < 0) run0 = s;
                     } else if (run0 >= 0) {
                         for (int j = run0; j <= s - 1 + k - 1; ++j)
-                            if (bit(OFF_E, lo + j)) { adjust = false; break; }
+                            if (bit(OFF_E(), lo + j)) { adjust = false; break; }
                         run0 = -1;
                     }
                 }
@@ -409,13 +412,13 @@ struct Corrector {
                 kreset(m);
                 int ts = -1, te = -1;
                 for (int i = 0; i < n && adjust; ++i) {
-                    kpush(m, code_in(OFF_O, OFF_ON, lo + i));
+                    kpush(m, code_in(OFF_O(), OFF_ON(), lo + i));
                     if (kvalid(m) && query(m)) {
                         ts = ts < 0 ? i - k + 1 : min(ts, i - k + 1);
                         te = i;
                     } else if (te >= 0) {
                         for (int j = ts; j <= te; ++j)
-                            if (bit(OFF_E, lo + j)) { adjust = false; break; }
+                            if (bit(OFF_E(), lo + j)) { adjust = false; break; }
                         ts = te = -1;
                     }
                 }
@@ -424,25 +427,25 @@ struct Corrector {
             const int ocwindow = 20, base_threshold = 4;
             int occ2 = 0;   // twice the reference's `occount` (it only ever moves by 0.5 or 1)
             // the snapshot's base words are free now: reuse them as the overcorrected-index set
-            for (int i = 0; i < NWN; ++i) word(OFF_O, i) = 0;
+            for (int i = 0; i < NWN(); ++i) word(OFF_O(), i) = 0;
             for (int i = 0; i < n; ++i) {
-                const bool e = bit(OFF_E, lo + i);
-                if (e && !bit(OFF_ON, lo + i)) occ2 += qual[lo + i] <= minqual ? 1 : 2;
-                if (i >= ocwindow && bit(OFF_E, lo + i - ocwindow) && !bit(OFF_ON, lo + i - ocwindow))
+                const bool e = bit(OFF_E(), lo + i);
+                if (e && !bit(OFF_ON(), lo + i)) occ2 += qual[lo + i] <= minqual ? 1 : 2;
+                if (i >= ocwindow && bit(OFF_E(), lo + i - ocwindow) && !bit(OFF_ON(), lo + i - ocwindow))
                     occ2 -= qual[lo + i - ocwindow] <= minqual ? 1 : 2;
                 const int threshold = (adjust && i >= ocwindow && i + ocwindow - 1 < n) ? base_threshold + 1 : base_threshold;
-                if (occ2 > 2 * threshold && e) setbit(OFF_O, i, true);
+                if (occ2 > 2 * threshold && e) setbit(OFF_O(), i, true);
             }
             for (int oc = 0; oc < n; ++oc) {
-                if (!bit(OFF_O, oc)) continue;
-                if (!bit(OFF_E, lo + oc)) continue;
+                if (!bit(OFF_O(), oc)) continue;
+                if (!bit(OFF_E(), lo + oc)) continue;
                 int start = oc - k + 1;
                 start = start >= 0 ? start : 0;
                 int end = oc + k;
                 end = end < n ? end : n;
                 for (int i = start; i < end; ++i) {
-                    if (bit(OFF_E, lo + i)) {
-                        setbit(OFF_E, lo + i, false);
+                    if (bit(OFF_E(), lo + i)) {
+                        setbit(OFF_E(), lo + i, false);
                         if (i + k > end) end = i + k < n ? i + k : n;
                         if (i - k < start) {
                             i = i - k + 1 >= 0 ? i - k : -1;

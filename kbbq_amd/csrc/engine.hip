@@ -39,6 +39,7 @@ static int fail(int code, const char *fmt, ...) {
 
 #include "kernels.h"
 #include "bucket.h"
+#include "long_reads.h"
 
 // ============================================================ engine object
 
@@ -110,8 +111,8 @@ struct kbbq_engine {
     int8_t *d_dq_cycle = nullptr;
     int8_t *d_dq_dinuc = nullptr;
     // scratch
-    void *scratch[20] = {};
-    size_t scratch_bytes[20] = {};
+    void *scratch[22] = {};
+    size_t scratch_bytes[22] = {};
     unsigned long long *d_counters = nullptr;   // [0] work-list length, [1] correction queries, [2] scan total
     // Host batches: a ring of device staging slots owned by the engine and a copy stream.  A host batch is copied
     // into the next slot with hipMemcpyAsync on the copy stream (DMA straight from the caller's memory when that is
@@ -706,7 +707,7 @@ void kbbq_engine_destroy(kbbq_engine *e) {
     hipFree(e->d_qcum);
     hipFree(e->d_errthr);
     hipFree(e->bk.l1); hipFree(e->bk.l2); hipFree(e->bk.l1_cnt); hipFree(e->bk.l2_cnt); hipFree(e->bk.tickets); hipFree(e->bk.direct);
-    for (int i = 0; i < 20; ++i) hipFree(e->scratch[i]);
+    for (int i = 0; i < 22; ++i) hipFree(e->scratch[i]);
     if (e->stream2) { hipStreamSynchronize(e->stream2); hipStreamDestroy(e->stream2); }
     if (e->ev_main) hipEventDestroy(e->ev_main);
     if (e->ev_draw) hipEventDestroy(e->ev_draw);
@@ -1061,11 +1062,12 @@ int kbbq_count_kmer_positions(kbbq_engine *e, const kbbq_reads *reads, uint64_t 
 
 }  // extern "C"
 
+constexpr int kStagedMax = 512;      // longest read the staged kernels take (Stage<8>); longer: long_reads.h
 template <template <int> class Launcher, typename... Args>
 static int dispatch_nw(int max_len, Args... args) {
     if (max_len <= 192) return Launcher<3>::go(args...);
     if (max_len <= 320) return Launcher<5>::go(args...);
-    return Launcher<8>::go(args...);
+    return Launcher<8>::go(args...);      // (reads longer than 512 bases: the callers branch to long_reads.h first)
 }
 
 template <int NW> struct LaunchSample {
@@ -1158,7 +1160,13 @@ int kbbq_sample_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t first_km
         HIP_TRY(hipEventRecord(e->ev_draw, ds));
         HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_draw, 0));
     }
-    if (bucket_on(e, 0)) {
+    if (max_len > kStagedMax) {
+        Timed t(e, "k_insert_sampled_long");
+        hipLaunchKernelGGL(k_insert_marked_long<false>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K, e->filt[0].dev(),
+                           (const uint64_t *)mask, n_draws / 64 + 2, kofs, e->filt[0].d_inserted);
+        HIP_TRY(hipGetLastError());
+        rc = KBBQ_OK;
+    } else if (bucket_on(e, 0)) {
         // deferred: the k-mers become records now and reach the filter at the next flush (bucket.h)
         if ((rc = bucket_reserve(e, 0, (double)n_draws * std::min(1.0, e->p.alpha) * 1.01 + 4096.0, R.n_bases))) return rc;
         rc = dispatch_emit(e, 0, max_len, R, (const uint64_t *)mask, n_draws / 64 + 2, kofs, e->filt[0].d_inserted);
@@ -1286,7 +1294,21 @@ int kbbq_trusted_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *infer_
         take_bits = (uint32_t *)e->scratch[8];
         HIP_TRY(hipMemsetAsync(take_bits, 0, (R.n_bases / 64 + 2) * 8, e->stream));
     }
-    if ((rc = dispatch_nw<LaunchTrusted>(max_len, e, R, take_bits, d_err, max_len))) return rc;
+    if (max_len > kStagedMax) {
+        Thresholds thr;
+        memset(&thr, 0, sizeof thr);
+        for (size_t i = 0; i < e->thresholds.size() && i <= KBBQ_MAX_KMER; ++i) thr.v[i] = e->thresholds[i];
+        {
+            Timed t(e, "k_infer_long");
+            hipLaunchKernelGGL(k_infer_long, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K, e->filt[0].dev(), thr, take_bits,
+                               e->filt[1].d_inserted, d_err, e->d_qpresent, e->d_counters + 3);
+            HIP_TRY(hipGetLastError());
+        }
+        Timed t(e, "k_insert_trusted_long");
+        hipLaunchKernelGGL(k_insert_marked_long<true>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K, e->filt[1].dev(),
+                           (const uint64_t *)take_bits, R.n_bases / 64 + 2, (const uint64_t *)nullptr, (unsigned long long *)nullptr);
+        HIP_TRY(hipGetLastError());
+    } else if ((rc = dispatch_nw<LaunchTrusted>(max_len, e, R, take_bits, d_err, max_len))) return rc;
     if ((rc = bit_out_end(e, reads, infer_errors_out, d_err))) return rc;
     return KBBQ_OK;      // device batches are queued; a host batch has been copied (host_done), its kernels are queued too
 }
@@ -1321,8 +1343,24 @@ template <int NW> struct LaunchScan {
 
 template <int MAXL, int BLOCK>
 static int launch_correct(kbbq_engine *e, ReadsDev R, const uint32_t *list, const unsigned long long *n_list, const uint64_t *tmask, int tw,
-                          uint32_t *err_bits, uint32_t *patch) {
+                          uint32_t *err_bits, uint32_t *patch, int max_len = 0, int side = 0) {
     typedef Corrector<MAXL> C;
+    if (MAXL == 0) {
+        // reads longer than 512 bases: the lane's working words (C::words_for(len) of them) live in a global scratch
+        // array, one slice per lane of the grid; at most 1 GiB of it
+        const int dyn_len = ((max_len + 31) / 32) * 32;
+        const size_t words = (size_t)C::words_for(dyn_len);
+        const uint64_t fit = std::max<uint64_t>(1, ((uint64_t)1 << 30) / (words * 4 * BLOCK));
+        const int blocks = (int)std::min<uint64_t>(std::min<uint64_t>((R.n_reads + BLOCK - 1) / BLOCK, 256 * 4), fit);
+        const int slot = side ? 21 : 20;
+        int rc = ensure_scratch(e, slot, (size_t)blocks * BLOCK * words * 4);
+        if (rc) return rc;
+        Timed t(e, "k_correct_long", e->cur);
+        hipLaunchKernelGGL((k_correct<MAXL, BLOCK>), dim3(blocks), dim3(BLOCK), 0, e->cur, R, e->K, e->filt[1].dev(), list,
+                           n_list, tmask, tw, err_bits, patch, e->cur_cnt, dyn_len, (uint32_t *)e->scratch[slot]);
+        HIP_TRY(hipGetLastError());
+        return KBBQ_OK;
+    }
     const size_t lds = (size_t)C::WORDS * BLOCK * 4;
     size_t &raised = e->attr_lds_correct[(const void *)k_correct<MAXL, BLOCK>];
     if (lds > raised) {
@@ -1333,7 +1371,7 @@ static int launch_correct(kbbq_engine *e, ReadsDev R, const uint32_t *list, cons
     // the work-list length is only known on the device: size the grid for the batch and let lanes stride
     const int blocks = (int)std::min<uint64_t>((R.n_reads + BLOCK - 1) / BLOCK, 256 * 8);
     hipLaunchKernelGGL((k_correct<MAXL, BLOCK>), dim3(blocks), dim3(BLOCK), lds, e->cur, R, e->K, e->filt[1].dev(), list,
-                       n_list, tmask, tw, err_bits, patch, e->cur_cnt);
+                       n_list, tmask, tw, err_bits, patch, e->cur_cnt, 0, (uint32_t *)nullptr);
     HIP_TRY(hipGetLastError());
     return KBBQ_OK;
 }
@@ -1442,7 +1480,9 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
     HostBatchDone host_done(e, reads);
     ReadsDev R; int max_len;
     if ((rc = device_view(e, reads, &R, &max_len))) return rc;
-    const int NW = max_len <= 192 ? 3 : max_len <= 320 ? 5 : 8;
+    const bool long_reads = max_len > kStagedMax;
+    // words of trusted mask per read: the staged kernels' NW; long reads: 8 per window of 512 k-mer starts
+    const int NW = max_len <= 192 ? 3 : max_len <= 320 ? 5 : !long_reads ? 8 : 8 * ((std::max(1, max_len - e->p.k + 1) + 511) / 512);
     // scratch per side: trusted masks, dirty flags, work list, error bits, seq patches
     const int s_tmask = side ? 10 : 3, s_dirty = side ? 11 : 4, s_list = side ? 12 : 5, s_err = side ? 8 : 6, s_patch = side ? 9 : 7;
     if ((rc = ensure_scratch(e, s_tmask, R.n_reads * NW * 8))) return rc;
@@ -1468,10 +1508,16 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
     uint32_t *patch = (uint32_t *)e->scratch[s_patch];
     // isolated single errors are settled inside the scan (fast_path); the walk gets what is left (dirty == 1)
     static const bool no_fast = getenv("KBBQ_NO_FASTPATH") != nullptr;
-    if ((rc = dispatch_nw<LaunchScan>(max_len, e, R, tmask, dirty, d_err, (!no_fast && e->p.k >= 3) ? 1 : 0))) return rc;
+    if (long_reads) {
+        Timed t(e, "k_scan_trusted_long", e->cur);
+        hipLaunchKernelGGL(k_scan_trusted_long, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->cur, R, e->K, e->filt[1].dev(), tmask, NW, dirty);
+        HIP_TRY(hipGetLastError());
+    } else if ((rc = dispatch_nw<LaunchScan>(max_len, e, R, tmask, dirty, d_err, (!no_fast && e->p.k >= 3) ? 1 : 0))) return rc;
     {
         Timed t(e, "k_compact", e->cur);
-        hipLaunchKernelGGL(k_compact, dim3((unsigned)((R.n_reads + 1023) / 1024)), dim3(1024), 0, e->cur, dirty, R.n_reads, list, e->cur_cnt, 1);
+        // (long reads: every read that is not clean takes the run-time-sized lane-form walk, off-case or not)
+        hipLaunchKernelGGL(k_compact, dim3((unsigned)((R.n_reads + 1023) / 1024)), dim3(1024), 0, e->cur, dirty, R.n_reads, list, e->cur_cnt,
+                           long_reads ? 0 : 1);
         HIP_TRY(hipGetLastError());
     }
     // The scan and the fast path of every batch run on the engine's stream; the walk and the tally of a
@@ -1485,7 +1531,9 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
     // one read per wavefront (correct_wave.h); the one-read-per-lane form (correct.h) serves k < 3
     // and KBBQ_CORRECT=lane (A/B checks)
     static const bool lane_form = getenv("KBBQ_CORRECT") && !strcmp(getenv("KBBQ_CORRECT"), "lane");
-    if (lane_form || e->p.k < 3) {
+    if (long_reads) {
+        rc = launch_correct<0, 64>(e, R, list, e->cur_cnt, tmask, NW, d_err, patch, max_len, side);
+    } else if (lane_form || e->p.k < 3) {
         if (max_len <= 160) rc = launch_correct<160, 256>(e, R, list, e->cur_cnt, tmask, NW, d_err, patch);
         else if (max_len <= 320) rc = launch_correct<320, 128>(e, R, list, e->cur_cnt, tmask, NW, d_err, patch);
         else rc = launch_correct<512, 64>(e, R, list, e->cur_cnt, tmask, NW, d_err, patch);
@@ -1495,7 +1543,7 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
         else rc = launch_correct_wave<16, 8>(e, R, list, tmask, NW, d_err, patch);
     }
     if (rc) return rc;
-    if (R.offcase) {
+    if (R.offcase && !long_reads) {
         // reads with off-case bases (scan state 3) follow the reference's raw-character comparisons: the one-read-per-lane
         // walk carries the case bits (correct.h); a second, usually empty, work list
         if ((rc = ensure_scratch(e, side ? 18 : 17, R.n_reads * 4))) return rc;

@@ -601,7 +601,8 @@ template <int MAXL, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_correct(ReadsDev R, KParams K, FiltDev T, const uint32_t *list,
                                                     const unsigned long long *n_list, const uint64_t *tmask,
                                                     int tmask_words, uint32_t *err_bits, uint32_t *patch,
-                                                    unsigned long long *stats) {      // stats[1] += Bloom queries
+                                                    unsigned long long *stats,        // stats[1] += Bloom queries
+                                                    int dyn_len, uint32_t *dyn_words) {
     typedef Corrector<MAXL> C;
     extern __shared__ uint32_t lds[];
     const uint64_t n = *n_list;
@@ -612,26 +613,28 @@ __global__ void __launch_bounds__(BLOCK) k_correct(ReadsDev R, KParams K, FiltDe
         read_span(R, r, off, len32);
         const int len = (int)len32;
         C cx;
-        cx.L = lds + threadIdx.x;
-        cx.stride = BLOCK;
+        cx.dyn_len = dyn_len;
+        // MAXL = 0: the lane's words live in global scratch (one slice per lane of the grid), not in LDS
+        cx.L = MAXL ? lds + threadIdx.x : dyn_words + ((size_t)blockIdx.x * BLOCK + threadIdx.x);
+        cx.stride = MAXL ? BLOCK : (int)(gridDim.x * BLOCK);
         cx.f = T;
         cx.K = K;
         cx.qual = R.qual + off;
         cx.t_ok = true;
         cx.queries = 0;
         // stage the read: 2-bit bases, non-ACGT mask, trusted mask; clear flags
-        for (int w = 0; w < C::NWB; ++w)
-            cx.word(C::OFF_W, w) = w * 16 < len ? (uint32_t)window64(R.bases, 2 * (off + (uint64_t)w * 16)) : 0u;
-        for (int w = 0; w < C::NWN; ++w) {
-            cx.word(C::OFF_NM, w) = w * 32 < len ? (uint32_t)window64(R.nmask, off + (uint64_t)w * 32) : 0u;
-            cx.word(C::OFF_LC, w) = (R.offcase && w * 32 < len) ? (uint32_t)window64(R.offcase, off + (uint64_t)w * 32) : 0u;
-            cx.word(C::OFF_E, w) = 0;
+        for (int w = 0; w < cx.NWB(); ++w)
+            cx.word(cx.OFF_W(), w) = w * 16 < len ? (uint32_t)window64(R.bases, 2 * (off + (uint64_t)w * 16)) : 0u;
+        for (int w = 0; w < cx.NWN(); ++w) {
+            cx.word(cx.OFF_NM(), w) = w * 32 < len ? (uint32_t)window64(R.nmask, off + (uint64_t)w * 32) : 0u;
+            cx.word(cx.OFF_LC(), w) = (R.offcase && w * 32 < len) ? (uint32_t)window64(R.offcase, off + (uint64_t)w * 32) : 0u;
+            cx.word(cx.OFF_E(), w) = 0;
             const int tw = w >> 1;
-            cx.word(C::OFF_T, w) = tw < tmask_words ? (uint32_t)(tmask[r * tmask_words + tw] >> (32 * (w & 1))) : 0u;
+            cx.word(cx.OFF_T(), w) = tw < tmask_words ? (uint32_t)(tmask[r * tmask_words + tw] >> (32 * (w & 1))) : 0u;
         }
         // bits past the read end must not look like bases
-        if (len & 31) { cx.word(C::OFF_NM, len >> 5) &= (1u << (len & 31)) - 1; cx.word(C::OFF_LC, len >> 5) &= (1u << (len & 31)) - 1; }
-        if (len & 15) cx.word(C::OFF_W, len >> 4) &= (1u << ((len & 15) * 2)) - 1;
+        if (len & 31) { cx.word(cx.OFF_NM(), len >> 5) &= (1u << (len & 31)) - 1; cx.word(cx.OFF_LC(), len >> 5) &= (1u << (len & 31)) - 1; }
+        if (len & 15) cx.word(cx.OFF_W(), len >> 4) &= (1u << ((len & 15) * 2)) - 1;
 
         const int k = K.k;
         const CallResult top = cx.run_call(0, len, true, 6);
@@ -644,7 +647,7 @@ __global__ void __launch_bounds__(BLOCK) k_correct(ReadsDev R, KParams K, FiltDe
             cx.run_call(top.bad_suffix, len - top.bad_suffix, false, 6);
         // publish the flags into the batch-wide bit array
         for (int w = 0; w * 32 < len; ++w) {
-            const uint32_t v = cx.word(C::OFF_E, w);
+            const uint32_t v = cx.word(cx.OFF_E(), w);
             if (!v) continue;
             const uint64_t g = off + (uint64_t)w * 32;
             atomicOr(&err_bits[g >> 5], v << (g & 31));

@@ -226,18 +226,25 @@ __global__ void __launch_bounds__(256) k_scan_trusted_long(ReadsDev R, KParams K
                     }
                     M[c] = __ballot(ok);
                     trusted += __popcll(M[c]);
-                    // (the bases of this window that no later window starts at: the last window also covers the tail)
-                    if (R.offcase) odd = odd || __ballot(s < wnk + (w0 + wnk == nk ? k - 1 : 0) && s < NW * 64 && lds_bit(L32 + 2 * S::X, o63 + s)) != 0;
                 }
             }
-            if (R.offcase && w0 + wnk == nk) {      // the k-1 bases behind the last k-mer start
-                for (int s = wnk + lane; s < wnk + k - 1; s += 64) {
-                    const uint64_t g = woff + (uint64_t)s;
-                    if ((R.offcase[g >> 6] >> (g & 63)) & 1) odd = true;
+            if (R.offcase) {      // off-case bases among the (up to 512) bases staged for this window
+                const int wb = min(NW * 64, (int)len - w0);
+                for (int c = 0; c * 64 < wb; ++c) {
+                    const int s = c * 64 + lane;
+                    odd = odd || __ballot(s < wb && lds_bit(L32 + 2 * S::X, o63 + s)) != 0;
                 }
-                odd = __ballot(odd) != 0;
             }
             if (lane < NW) tmask[r * (uint64_t)tw + (uint64_t)(w0 / 64) + lane] = sel_word<NW>(M, lane);
+        }
+        if (R.offcase) {          // the bases behind the last window's 512 (fewer than k)
+            const int seen = ((nk + NW * 64 - 1) / (NW * 64)) * (NW * 64);
+            bool tail = false;
+            for (int s = seen + lane; s < (int)len; s += 64) {
+                const uint64_t g = off + (uint64_t)s;
+                tail = tail || ((R.offcase[g >> 6] >> (g & 63)) & 1);
+            }
+            odd = odd || __ballot(tail) != 0;
         }
         if (lane == 0) dirty[r] = (uint8_t)(trusted != nk ? (odd ? 3 : 1) : 0);
     }

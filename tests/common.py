@@ -17,7 +17,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def make_dataset(seed=12345, genome_len=20000, coverage=20, read_len=150, n_rg=1, paired=False, n_per_million=200,
-                 ragged=False, short_reads=0, mid_reads=0, extra_errors=0, clusters=0):
+                 ragged=False, short_reads=0, mid_reads=0, extra_errors=0, clusters=0, ragged_min=None):
     """Seeded synthetic reads; optionally trimmed to ragged lengths and with a few reads shorter than k."""
     n_reads = genome_len * coverage // read_len
     sp = synth.synth_params(seed, genome_len, n_reads, read_len, n_rg=n_rg, paired=paired, n_per_million=n_per_million)
@@ -44,7 +44,7 @@ def make_dataset(seed=12345, genome_len=20000, coverage=20, read_len=150, n_rg=1
     if ragged or short_reads or mid_reads:
         lens = np.full(n_reads, read_len, dtype=np.int64)
         if ragged:
-            lens = rng.randint(read_len * 2 // 3, read_len + 1, size=n_reads)
+            lens = rng.randint(read_len * 2 // 3 if ragged_min is None else ragged_min, read_len + 1, size=n_reads)
         if short_reads:
             idx = rng.choice(n_reads, size=short_reads, replace=False)
             lens[idx] = rng.randint(1, 31, size=short_reads)
@@ -182,6 +182,12 @@ PARITY_CASES = {
                    dict(uniform=True, n_batches=2)),
     "softmasked_k9_ragged": (make_softmasked_dataset, dict(seed=9, frac=0.3, genome_len=3000, coverage=30, read_len=100, extra_errors=100,
                                                           ragged=True, n_rg=2, paired=True), dict(k=9, n_rg=2), dict(uniform=False, n_batches=3)),
+    # reads longer than the 512 bases the staged kernels hold: windowed kernels, run-time-sized walk (long_reads.h)
+    "long_ragged_600_3000": (make_dataset, dict(seed=3000, genome_len=60000, coverage=24, read_len=3000, ragged=True, ragged_min=600,
+                                                n_per_million=1500, extra_errors=150, clusters=60, n_rg=2, paired=True),
+                             dict(n_rg=2), dict(uniform=False, n_batches=2)),
+    "long_uniform_1000_softmasked_k25": (make_softmasked_dataset, dict(seed=1000, frac=0.3, genome_len=40000, coverage=24, read_len=1000,
+                                                                      extra_errors=80, clusters=40), dict(k=25), dict(uniform=True, n_batches=3)),
     "reads_400": (make_dataset, dict(seed=400, genome_len=20000, coverage=20, read_len=400, n_per_million=500,
                                      extra_errors=60), dict(), dict(uniform=True)),
 }

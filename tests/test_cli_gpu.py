@@ -107,6 +107,22 @@ def test_cli_keeps_the_case_of_a_soft_masked_fastq(tmp_path):
             assert s_ == seq[off[r]:off[r + 1]] and q == want_q[off[r]:off[r + 1]], "read %d" % r
 
 
+def test_cli_takes_reads_longer_than_the_staged_kernels_hold(tmp_path):
+    """600-2500-base reads (the reference has no length limit: covariateutils.cc:102-116, readutils.cc:238): windowed
+    kernels and the run-time-sized walk, resident and streaming."""
+    d, names, n_rg = named_dataset(seed=77, genome_len=50000, coverage=24, read_len=2500, ragged=True, ragged_min=600, n_per_million=1500,
+                                   extra_errors=100, clusters=40)
+    fq = tmp_path / "long.fq.gz"
+    write_fastq(fq, d, names)
+    coverage = int(d["off"][-1]) // d["genome_len"]
+    ora = common.run_oracle(dict(d, coverage=coverage), seed=4, n_rg=n_rg)
+    want = (ora["recal"] + 33).astype(np.uint8).tobytes().decode()
+    for env in ({"KBBQ_SEED": "4"}, {"KBBQ_SEED": "4", "KBBQ_RESIDENT": "0"}):
+        rc, out, err = run_cli(["-g", d["genome_len"], fq], env)
+        assert rc == 0, err
+        assert "".join(q for _, _, _, q in read_fastq_text(gzip.decompress(out))) == want
+
+
 def test_cli_streaming_and_resident_modes_agree(tmp_path):
     """Default: the packed reads stay in GPU memory between the passes; KBBQ_RESIDENT=0: every pass decodes the
     file again like the reference.  Same bytes either way, also with a single compression thread."""
