@@ -57,7 +57,11 @@ def log(*a):
 
 # kernels that share the chip with a kernel of the neighbouring batch on the other stream (pass 1: draw beside insert;
 # pass 3: walk + tally beside scan): their event durations are not exclusive costs
-PASS3_KERNELS = ("k_draw_mask", "k_insert_sampled", "k_scan_trusted", "k_compact", "k_correct_wave", "k_correct", "k_tally")
+PASS3_KERNELS = ("k_draw_mask", "k_insert_sampled", "k_emit_sampled", "k_scan_trusted", "k_compact", "k_correct_wave", "k_correct", "k_tally",
+                 "k_emit_trusted", "k_split_trusted", "k_apply_trusted")
+# k_infer (main stream) shares the chip with the insert side of pass 2 (k_emit/k_split/k_apply_trusted on the side stream: ALU-,
+# streaming- and L2-bound work beside its random HBM lines); its event duration is an upper bound of its exclusive cost and it stays
+# the kernel the roofline is quoted for
 
 
 def run_step(e, xch, batches, ordinals, out_buf, hints):
@@ -154,6 +158,9 @@ def kernel_model(name, bases, nk, alpha, f_t, walk_queries=0.0):
         "k_correct": walk_queries * 64.0,
         "k_draw_mask": nk / 8.0,
         "k_insert_sampled": bases * 0.25 + nk / 8.0 + nk * alpha * 128.0,
+        # slice-bucketed inserts (bucket.h): the emit kernels write one 8-byte record per insert
+        "k_emit_sampled": bases * 0.25 + nk / 8.0 + nk * alpha * 8.0,
+        "k_emit_trusted": bases * 0.25 + bases / 8.0 + nk * f_t * 8.0,
         "k_infer": bases * 1.25 + nk * 64.0,
         "k_insert_trusted": bases * 0.25 + nk * f_t * 128.0,
         "k_scan_trusted": bases * 0.25 + nk * 64.0,

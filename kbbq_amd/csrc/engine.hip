@@ -111,8 +111,8 @@ struct kbbq_engine {
     int8_t *d_dq_cycle = nullptr;
     int8_t *d_dq_dinuc = nullptr;
     // scratch
-    void *scratch[22] = {};
-    size_t scratch_bytes[22] = {};
+    void *scratch[24] = {};
+    size_t scratch_bytes[24] = {};
     unsigned long long *d_counters = nullptr;   // [0] work-list length, [1] correction queries, [2] scan total
     // Host batches: a ring of device staging slots owned by the engine and a copy stream.  A host batch is copied
     // into the next slot with hipMemcpyAsync on the copy stream (DMA straight from the caller's memory when that is
@@ -145,9 +145,24 @@ struct kbbq_engine {
         bool pending[2] = {false, false};
         double pending_est[2] = {0, 0};  // estimated records since the last flush
         double frac_trusted = 0.75;      // trusted inserts per base, learnt at every flush
+        double frac_used = 0.75;         // ... as used for the estimate of the batch being reserved
         uint64_t bases_since[2] = {0, 0}, inserted_at_flush[2] = {0, 0};
         uint64_t flushes[2] = {0, 0};
+        // the stream filter w's emits and flushes are queued on: the engine's, or -- pass 2 -- the side stream, where the
+        // whole insert side of the pass (emit, split, apply) runs beside the next batches' k_infer
+        hipStream_t stream[2] = {nullptr, nullptr};
+        hipEvent_t ev_flush = nullptr;       // a flush on the side stream has finished (pass boundaries wait for it)
+        // the learnt estimate is read back without stopping either stream: copy into page-locked memory + event
+        unsigned long long *h_inserted = nullptr;
+        hipEvent_t ev_est = nullptr;
+        bool est_pending = false, est_known = false;
+        uint64_t est_bases = 0, est_prev = 0, cur_bases = 0;
     } bk;
+    // pass 2: insert decisions of k_infer for batches that bring no hint array: two buffers, so that the side stream
+    // can still read batch i's while k_infer writes batch i+1's
+    hipEvent_t ev_infer = nullptr, ev_take[2] = {nullptr, nullptr};
+    bool take_pending[2] = {false, false};
+    int take_turn = 0;
     // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: what this engine has raised on ITS device
     size_t attr_lds_tally = 0, attr_lds_recal = 0;
     std::map<const void *, size_t> attr_lds_correct;
@@ -529,33 +544,74 @@ bool bucket_on(kbbq_engine *e, int w) {
 }
 
 // Partition the gathered records of filter w by subslice and OR them into the filter (k_split, k_apply).
-int bucket_flush(kbbq_engine *e, int w) {
+hipStream_t bucket_stream(kbbq_engine *e, int w) { return e->bk.stream[w] ? e->bk.stream[w] : e->stream; }
+
+// the learnt trusted-inserts-per-base figure, once its copy has landed
+void bucket_poll_estimate(kbbq_engine *e) {
+    kbbq_engine::Buckets &b = e->bk;
+    if (!b.est_pending || hipEventQuery(b.ev_est) != hipSuccess) return;
+    const unsigned long long now = *b.h_inserted;
+    if (b.est_bases > 0 && now >= b.est_prev)
+        b.frac_trusted = std::min(1.0, 1.03 * (double)(now - b.est_prev) / (double)b.est_bases + 0.005);
+    b.inserted_at_flush[1] = now;
+    b.est_pending = false;
+    static const bool debug = getenv("KBBQ_DEBUG_BUCKET") != nullptr;
+    if (debug) fprintf(stderr, "[bucket] inserted %llu (before %llu) over %llu bases -> %.4f trusted inserts per base\n", now,
+                       (unsigned long long)b.est_prev, (unsigned long long)b.est_bases, b.frac_trusted);
+}
+
+// Partition the gathered records of filter w by subslice and OR them into the filter (k_split, k_apply), on the stream
+// the filter's emits run on.  barrier: the engine's main stream waits for it (pass boundaries: the next pass reads the
+// filter there); a flush in the middle of pass 2 leaves the main stream alone.
+int bucket_flush(kbbq_engine *e, int w, bool barrier = true) {
     kbbq_engine::Buckets &b = e->bk;
     if (!b.pending[w]) return KBBQ_OK;
     const BucketDev B = bucket_dev(e, w);
     const FiltDev F = e->filt[w].dev();
-    HIP_TRY(hipMemsetAsync(b.tickets, 0, kTicketBytes, e->stream));
+    hipStream_t st = bucket_stream(e, w);
+    HIP_TRY(hipMemsetAsync(b.tickets, 0, kTicketBytes, st));
     {
-        Timed t(e, w ? "k_split_trusted" : "k_split_sampled");
+        Timed t(e, w ? "k_split_trusted" : "k_split_sampled", st);
         const uint32_t chunks = (B.cap1 + SPLIT_TILE - 1) / SPLIT_TILE;
-        hipLaunchKernelGGL(k_split, dim3(256 * 3), dim3(BK_THREADS), 0, e->stream, F, B, chunks);
+        hipLaunchKernelGGL(k_split, dim3(256 * 3), dim3(BK_THREADS), 0, st, F, B, chunks);
         HIP_TRY(hipGetLastError());
     }
     {
-        Timed t(e, w ? "k_apply_trusted" : "k_apply_sampled");
-        hipLaunchKernelGGL(k_apply, dim3(B.n_sub), dim3(APPLY_THREADS), 0, e->stream, F, B);
+        Timed t(e, w ? "k_apply_trusted" : "k_apply_sampled", st);
+        hipLaunchKernelGGL(k_apply, dim3(B.n_sub), dim3(APPLY_THREADS), 0, st, F, B);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipMemsetAsync(b.l1_cnt, 0, kL1CntBytes, e->stream));
-    HIP_TRY(hipMemsetAsync(b.l2_cnt, 0, (size_t)B.nb1 * NB2 * 4, e->stream));
-    // how many records that was (the insert counter counts every one): the estimate that times the next flush
-    if (w == 1) {
-        unsigned long long now = 0;
-        HIP_TRY(hipMemcpyAsync(&now, e->filt[1].d_inserted, 8, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        if (b.bases_since[1] > 0 && now >= b.inserted_at_flush[1])
-            b.frac_trusted = std::min(1.0, 1.03 * (double)(now - b.inserted_at_flush[1]) / (double)b.bases_since[1] + 0.005);
-        b.inserted_at_flush[1] = now;
+    HIP_TRY(hipMemsetAsync(b.l1_cnt, 0, kL1CntBytes, st));
+    HIP_TRY(hipMemsetAsync(b.l2_cnt, 0, (size_t)B.nb1 * NB2 * 4, st));
+    if (st != e->stream && barrier) {
+        HIP_TRY(hipEventRecord(b.ev_flush, st));
+        HIP_TRY(hipStreamWaitEvent(e->stream, b.ev_flush, 0));
+    }
+    // how many records that was (k_infer counts every insert it decides, on the main stream): the estimate that times
+    // the next flush, fetched without stopping a stream
+    if (w == 1 && !barrier) {
+        bucket_poll_estimate(e);
+        if (!b.est_pending && b.h_inserted) {
+            // (k_infer of the batch that triggered this flush has been queued already: its bases count)
+            HIP_TRY(hipMemcpyAsync(b.h_inserted, e->filt[1].d_inserted, 8, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipEventRecord(b.ev_est, e->stream));
+            b.est_pending = true;
+            b.est_bases = b.bases_since[1] + b.cur_bases;
+            b.est_prev = b.inserted_at_flush[1];
+            if (!b.est_known) {
+                // the first flush of a run: the host has queued the whole pass ahead of the GPU, so a poll would never
+                // see this copy in time -- wait for it once (the main stream has just been drained up to here; the side
+                // stream keeps working); later flushes refine the figure when their copy happens to have landed
+                HIP_TRY(hipEventSynchronize(b.ev_est));
+                bucket_poll_estimate(e);
+                b.est_known = true;
+            }
+        }
+    }
+    {
+        static const bool debug = getenv("KBBQ_DEBUG_BUCKET") != nullptr;
+        if (debug) fprintf(stderr, "[bucket] flush %d of filter %d: estimate %.3g records over %llu bases (%.4f per base), barrier %d\n",
+                           (int)b.flushes[w], w, b.pending_est[w], (unsigned long long)b.bases_since[w], w ? b.frac_trusted : 0.0, (int)barrier);
     }
     b.bases_since[w] = 0;
     b.pending[w] = false;
@@ -578,7 +634,12 @@ int bucket_reserve(kbbq_engine *e, int w, double est, uint64_t bases) {
     kbbq_engine::Buckets &b = e->bk;
     int rc = bucket_flush(e, 1 - w);
     if (rc) return rc;
-    if (b.pending[w] && b.pending_est[w] + est > 0.93 * (double)b.capacity && (rc = bucket_flush(e, w))) return rc;
+    b.cur_bases = bases;
+    if (b.pending[w] && b.pending_est[w] + est > 0.93 * (double)b.capacity) {
+        if ((rc = bucket_flush(e, w, false))) return rc;
+        if (w == 1) est = (est - 4096.0) / std::max(1e-9, b.frac_used) * b.frac_trusted + 4096.0;      // the figure may just have been learnt
+    }
+    b.cur_bases = 0;
     b.pending[w] = true;
     b.pending_est[w] += est;
     b.bases_since[w] += bases;
@@ -625,6 +686,11 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_side[0], hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_side[1], hipEventDisableTiming);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->copy, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->bk.ev_flush, hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->bk.ev_est, hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_infer, hipEventDisableTiming);
+    for (int t = 0; t < 2 && he == hipSuccess; ++t) he = hipEventCreateWithFlags(&e->ev_take[t], hipEventDisableTiming);
+    if (he == hipSuccess) he = hipHostMalloc((void **)&e->bk.h_inserted, 64, hipHostMallocDefault);
     for (int i = 0; i < 3 && he == hipSuccess; ++i) {
         he = hipEventCreateWithFlags(&e->slot[i].h2d, hipEventDisableTiming);
         for (int t = 0; t < 2 && he == hipSuccess; ++t) he = hipEventCreateWithFlags(&e->slot[i].done[t], hipEventDisableTiming);
@@ -690,6 +756,11 @@ void kbbq_engine_destroy(kbbq_engine *e) {
         for (int t = 0; t < 2; ++t) if (e->slot[i].done[t]) hipEventDestroy(e->slot[i].done[t]);
     }
     if (e->copy) hipStreamDestroy(e->copy);
+    if (e->bk.ev_flush) hipEventDestroy(e->bk.ev_flush);
+    if (e->bk.ev_est) hipEventDestroy(e->bk.ev_est);
+    if (e->ev_infer) hipEventDestroy(e->ev_infer);
+    for (int t = 0; t < 2; ++t) if (e->ev_take[t]) hipEventDestroy(e->ev_take[t]);
+    if (e->bk.h_inserted) hipHostFree(e->bk.h_inserted);
     for (int w = 0; w < 2; ++w) {
         hipFree(e->filt[w].d_table);
         hipFree(e->filt[w].d_patterns);
@@ -707,7 +778,7 @@ void kbbq_engine_destroy(kbbq_engine *e) {
     hipFree(e->d_qcum);
     hipFree(e->d_errthr);
     hipFree(e->bk.l1); hipFree(e->bk.l2); hipFree(e->bk.l1_cnt); hipFree(e->bk.l2_cnt); hipFree(e->bk.tickets); hipFree(e->bk.direct);
-    for (int i = 0; i < 22; ++i) hipFree(e->scratch[i]);
+    for (int i = 0; i < 24; ++i) hipFree(e->scratch[i]);
     if (e->stream2) { hipStreamSynchronize(e->stream2); hipStreamDestroy(e->stream2); }
     if (e->ev_main) hipEventDestroy(e->ev_main);
     if (e->ev_draw) hipEventDestroy(e->ev_draw);
@@ -734,6 +805,10 @@ int kbbq_engine_reset(kbbq_engine *e) {
         HIP_TRY(hipMemsetAsync(e->bk.l2_cnt, 0, kL2CntBytes, e->stream));
         HIP_TRY(hipMemsetAsync(e->bk.direct, 0, 8, e->stream));
     }
+    e->bk.est_pending = false;
+    e->bk.est_known = false;
+    e->bk.frac_trusted = 0.75;
+    e->bk.stream[0] = e->bk.stream[1] = nullptr;
     for (int w = 0; w < 2; ++w) { e->bk.pending[w] = false; e->bk.pending_est[w] = 0; e->bk.bases_since[w] = 0; e->bk.inserted_at_flush[w] = 0; e->bk.flushes[w] = 0; }
     {
         const uint32_t none[3] = {0, 0, 0};
@@ -1088,7 +1163,8 @@ static int launch_emit(kbbq_engine *e, int w, ReadsDev R, const uint64_t *mask, 
     const uint64_t n_tiles = (R.n_reads + 8 * RPW - 1) / (8 * RPW);
     const int grid = (int)std::min<uint64_t>(n_tiles, EMIT_GRID);
     const size_t lds = (size_t)8 * RPW * CH * 64 * 8;
-    Timed t(e, w ? "k_emit_trusted" : "k_emit_sampled");
+    hipStream_t st = bucket_stream(e, w);
+    Timed t(e, w ? "k_emit_trusted" : "k_emit_sampled", st);
 #define KBBQ_EMIT(BYB, PRIV)                                                                                                  \
     do {                                                                                                                      \
         const void *fn = (const void *)k_emit_marked<NW, CH, BYB, RPW, PRIV>;                                                  \
@@ -1097,7 +1173,7 @@ static int launch_emit(kbbq_engine *e, int w, ReadsDev R, const uint64_t *mask, 
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
             raised = lds;                                                                                                     \
         }                                                                                                                     \
-        hipLaunchKernelGGL((k_emit_marked<NW, CH, BYB, RPW, PRIV>), dim3(grid), dim3(BK_THREADS), lds, e->stream, R, e->K,     \
+        hipLaunchKernelGGL((k_emit_marked<NW, CH, BYB, RPW, PRIV>), dim3(grid), dim3(BK_THREADS), lds, st, R, e->K,            \
                            e->filt[w].dev(), B, mask, mask_words, kofs, inserted);                                            \
     } while (0)
     if (bucket_private()) { if (w == 0) KBBQ_EMIT(false, true); else KBBQ_EMIT(true, true); }
@@ -1237,6 +1313,20 @@ template <int NW> struct LaunchTrusted {
             HIP_TRY(hipGetLastError());
         }
         if (bucket_on(e, 1)) {
+            // The insert side of pass 2 -- emit, and split + apply whenever the record buffers fill -- runs on the
+            // side stream: it is ALU-, streaming- and L2-bound, k_infer is bound by random HBM lines, so batch i's
+            // inserts run beside batch i+1's k_infer.  (Overflow records are inserted directly by the emit kernel:
+            // on the same stream as k_apply, so the two never touch the trusted filter at the same time.)
+            static const bool no_overlap = getenv("KBBQ_NO_OVERLAP") != nullptr || getenv("KBBQ_NO_SIDE2") != nullptr;
+            const bool side = !no_overlap;
+            e->bk.stream[1] = side ? e->stream2 : e->stream;
+            if (side) {
+                HIP_TRY(hipEventRecord(e->ev_infer, e->stream));
+                HIP_TRY(hipStreamWaitEvent(e->stream2, e->ev_infer, 0));
+                e->cur_slot_side = true;      // (a host batch: its staging slot is read on the side stream as well)
+            }
+            bucket_poll_estimate(e);
+            e->bk.frac_used = e->bk.frac_trusted;
             int rc = bucket_reserve(e, 1, (double)R.n_bases * e->bk.frac_trusted + 4096.0, R.n_bases);
             if (rc) return rc;
             return dispatch_emit(e, 1, max_len, R, (const uint64_t *)take_bits, R.n_bases / 64 + 2, (const uint64_t *)nullptr,
@@ -1289,9 +1379,18 @@ int kbbq_trusted_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *infer_
     // the insert decisions of k_infer: the caller's hint array when there is one (pass 3 then reuses
     // them), a scratch bit array otherwise
     uint32_t *take_bits = R.hint_trusted;
+    int take_slot = -1;
     if (!take_bits) {
-        if ((rc = ensure_scratch(e, 8, (R.n_bases / 64 + 2) * 8))) return rc;
-        take_bits = (uint32_t *)e->scratch[8];
+        // two scratch arrays in turn: the side stream may still be reading the one before last (ev_take)
+        take_slot = e->take_turn;
+        e->take_turn ^= 1;
+        const int sl = take_slot ? 22 : 8;
+        if (e->take_pending[take_slot]) {
+            HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_take[take_slot], 0));
+            e->take_pending[take_slot] = false;
+        }
+        if ((rc = ensure_scratch(e, sl, (R.n_bases / 64 + 2) * 8))) return rc;
+        take_bits = (uint32_t *)e->scratch[sl];
         HIP_TRY(hipMemsetAsync(take_bits, 0, (R.n_bases / 64 + 2) * 8, e->stream));
     }
     if (max_len > kStagedMax) {
@@ -1309,6 +1408,10 @@ int kbbq_trusted_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *infer_
                            (const uint64_t *)take_bits, R.n_bases / 64 + 2, (const uint64_t *)nullptr, (unsigned long long *)nullptr);
         HIP_TRY(hipGetLastError());
     } else if ((rc = dispatch_nw<LaunchTrusted>(max_len, e, R, take_bits, d_err, max_len))) return rc;
+    if (take_slot >= 0 && bucket_stream(e, 1) != e->stream && e->bk.mode[1] == 1 && max_len <= kStagedMax) {
+        HIP_TRY(hipEventRecord(e->ev_take[take_slot], bucket_stream(e, 1)));      // the emit has read this scratch array
+        e->take_pending[take_slot] = true;
+    }
     if ((rc = bit_out_end(e, reads, infer_errors_out, d_err))) return rc;
     return KBBQ_OK;      // device batches are queued; a host batch has been copied (host_done), its kernels are queued too
 }
