@@ -57,11 +57,10 @@ def log(*a):
 
 # kernels that share the chip with a kernel of the neighbouring batch on the other stream (pass 1: draw beside insert;
 # pass 3: walk + tally beside scan): their event durations are not exclusive costs
-PASS3_KERNELS = ("k_draw_mask", "k_insert_sampled", "k_emit_sampled", "k_scan_trusted", "k_compact", "k_correct_wave", "k_correct", "k_tally",
-                 "k_emit_trusted", "k_split_trusted", "k_apply_trusted")
-# k_infer (main stream) shares the chip with the insert side of pass 2 (k_emit/k_split/k_apply_trusted on the side stream: ALU-,
-# streaming- and L2-bound work beside its random HBM lines); its event duration is an upper bound of its exclusive cost and it stays
-# the kernel the roofline is quoted for
+PASS3_KERNELS = ("k_draw_mask", "k_insert_sampled", "k_emit_sampled", "k_scan_trusted", "k_compact", "k_correct_wave", "k_correct", "k_tally")
+# with KBBQ_PASS2_SIDE=1 the insert side of pass 2 runs on the side stream beside k_infer: then pass 2's durations are shared too
+if os.environ.get("KBBQ_PASS2_SIDE", "0") not in ("", "0"):
+    PASS3_KERNELS += ("k_infer", "k_emit_trusted", "k_split_trusted", "k_apply_trusted")
 
 
 def run_step(e, xch, batches, ordinals, out_buf, hints):

@@ -142,18 +142,16 @@ __global__ void __launch_bounds__(BK_THREADS) k_emit_marked(ReadsDev R, KParams 
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
                     if (c * 64 < nk) {
+                        // straight-line for every lane (the staged words cover the whole chunk): only the counter's
+                        // atomic is predicated -- a lane's hash costs nothing when its neighbours need theirs anyway
                         const int s = c * 64 + lane;
-                        bool take = false;
-                        if (s < nk && lds_bit(L32 + 2 * S::X, x63 + s)) {
-                            const bool valid = (lds_window32(L32 + 2 * S::M, o63 + s) & K.nmask_bits) == 0;
-                            take = BY_BASE || valid;
-                        }
-                        if (take) {
-                            const uint64_t key = canon_key(lds_window64(L32 + 2 * S::B, 2 * (o31 + s)), K);
-                            const uint32_t blk = block_of(F, key);
-                            rec[rr * CH + c] = ((unsigned long long)blk << 16) | pattern_of(F, key);
-                            rk[rr * CH + c] = (int)atomicAdd(&hist[blk >> L1_SHIFT], 1u);
-                        }
+                        const bool marked = lds_bit(L32 + 2 * S::X, x63 + s) != 0;
+                        const bool valid = (lds_window32(L32 + 2 * S::M, o63 + s) & K.nmask_bits) == 0;
+                        const bool take = s < nk && marked && (BY_BASE || valid);
+                        const uint64_t key = canon_key(lds_window64(L32 + 2 * S::B, 2 * (o31 + s)), K);
+                        const uint32_t blk = block_of(F, key);
+                        rec[rr * CH + c] = ((unsigned long long)blk << 16) | pattern_of(F, key);
+                        if (take) rk[rr * CH + c] = (int)atomicAdd(&hist[blk >> L1_SHIFT], 1u);
                         const unsigned long long bal = __ballot(take);
                         if (!BY_BASE && R.hint_sampled) or_bits64(R.hint_sampled, off[rr] + (uint64_t)c * 64, bal, lane);
                         mine += __popcll(bal);

@@ -1317,8 +1317,11 @@ template <int NW> struct LaunchTrusted {
             // side stream: it is ALU-, streaming- and L2-bound, k_infer is bound by random HBM lines, so batch i's
             // inserts run beside batch i+1's k_infer.  (Overflow records are inserted directly by the emit kernel:
             // on the same stream as k_apply, so the two never touch the trusted filter at the same time.)
-            static const bool no_overlap = getenv("KBBQ_NO_OVERLAP") != nullptr || getenv("KBBQ_NO_SIDE2") != nullptr;
-            const bool side = !no_overlap;
+            // Off by default: measured +2.4 % on the 30x workload (profiles/r02_bench_full_i_{side,noside}.json) -- the side
+            // kernels mostly take turns with k_infer's waves rather than run beside them -- at the price of kernel durations
+            // that are no longer exclusive in pass 2 (k_infer is the kernel the roofline is quoted for).  KBBQ_PASS2_SIDE=1.
+            static const bool want_side = getenv("KBBQ_PASS2_SIDE") && atoi(getenv("KBBQ_PASS2_SIDE")) != 0 && !getenv("KBBQ_NO_OVERLAP");
+            const bool side = want_side;
             e->bk.stream[1] = side ? e->stream2 : e->stream;
             if (side) {
                 HIP_TRY(hipEventRecord(e->ev_infer, e->stream));
