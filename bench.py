@@ -48,6 +48,7 @@ READ_LEN = 150
 SEED_DATA = 12345
 SEED_SAMPLER = 777
 BATCH_READS = int(os.environ.get("KBBQ_BENCH_BATCH", 1 << 22))   # reads per engine call
+PCIE_BATCH_READS = 1 << 20     # host batches of the PCIe-inclusive leg: what the command line hands over (kbbq_cli.cc)
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -219,8 +220,9 @@ def pcie_inclusive(genome_len, coverage, local_rank):
     sp = synth.synth_params(SEED_DATA, genome_len, n_reads, READ_LEN, n_rg=1, paired=False, n_per_million=100)
     dev = e.synth_reads(sp, 0, n_reads)
     host, ordinals = [], []
-    for s in range(0, n_reads, BATCH_READS):
-        n = min(BATCH_READS, n_reads - s)
+    PB = PCIE_BATCH_READS
+    for s in range(0, n_reads, PB):
+        n = min(PB, n_reads - s)
         host.append(HostPacked(e, dev.view(s, n)))
         ordinals.append(s * (READ_LEN - K + 1))
     nb = n_reads * READ_LEN
@@ -240,15 +242,15 @@ def pcie_inclusive(genome_len, coverage, local_rank):
     hint_bytes = (nb // 64 + 2) * 8
     hints = torch.zeros(2 * hint_bytes, dtype=torch.uint8, device="cuda")
     dev.set_hints(hints.data_ptr(), hints.data_ptr() + hint_bytes)
-    res = [dev.view(s, min(BATCH_READS, n_reads - s)) for s in range(0, n_reads, BATCH_READS)]
-    out_dev = torch.empty(BATCH_READS * READ_LEN + 16, dtype=torch.uint8, device="cuda")
+    res = [dev.view(s, min(PB, n_reads - s)) for s in range(0, n_reads, PB)]
+    out_dev = torch.empty(PB * READ_LEN + 16, dtype=torch.uint8, device="cuda")
     t_res = passes([lambda: ([e.subsample_kmers(b, o) for b, o in zip(res, ordinals)], e.sample_finish(), e.compute_thresholds()),
                     lambda: ([e.find_trusted_kmers(b) for b in res], e.trusted_finish()),
                     lambda: ([e.get_covariatedata(b) for b in res], e.get_dqs()),
                     lambda: [e.recalibrate(b, out_dev.data_ptr()) for b in res]])
     dev.free()
     del hints
-    out_pin = _lib.PinnedArray(BATCH_READS * READ_LEN + 16, np.uint8)
+    out_pin = _lib.PinnedArray(PB * READ_LEN + 16, np.uint8)
     out = out_pin.array
     _lib.check(e.L.kbbq_engine_reset(e.h))
     t_sub = passes([lambda: ([e.subsample_kmers(b, o) for b, o in zip(host, ordinals)], e.sample_finish(), e.compute_thresholds()),
@@ -294,7 +296,7 @@ def pcie_inclusive(genome_len, coverage, local_rank):
                     bound_Gbases_per_s=round(nb / b / 1e9, 4), fraction_of_bound=round(b / sum(t), 3), traffic=text)
 
     return dict(host_link=dict(h2d_GBps=round(up.value, 2), d2h_GBps=round(dn.value, 2), how="one 1 GiB copy each way, page-locked host memory"),
-                sample="%d reads x %d bp = %.3g bases as page-locked host batches of %d reads" % (n_reads, READ_LEN, nb, BATCH_READS),
+                sample="%d reads x %d bp = %.3g bases as page-locked host batches of %d reads (the command line's batch size)" % (n_reads, READ_LEN, nb, PB),
                 resident_pass_seconds=[round(x, 3) for x in t_res],
                 bound="per mode: sum over the four passes of max(bytes / measured link rate, the pass's resident time)",
                 resubmit=mode(t_sub, sub_bytes, "4.5 B/base H2D (pass 1 sends no qualities), 1 B/base D2H"),
@@ -538,7 +540,7 @@ def main():
         # is the committed rocprofv3 --pmc summary of this same command at the same launch size
         traffic, traffic_note = None, "no PMC summary for this launch size"
         try:
-            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_latest.json")))
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_latest.json")))
             k = pmc["kernels"].get(dom)
             launches_per_step = kernels[dom]["launches"] // args.steps
             full_launches = (n_local // BATCH_READS) >= 1 and READ_LEN == 150 and BATCH_READS == 1 << 22
