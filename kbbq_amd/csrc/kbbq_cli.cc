@@ -23,6 +23,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -171,6 +172,24 @@ public:
 private:
     BamReader in_;
     bool use_oq_;
+};
+
+// KBBQ_TIMING=1: wall-clock per phase on stderr at the end ("[timing] scan 12.3 s ..."): where an end-to-end run goes
+struct PhaseClock {
+    std::vector<std::pair<std::string, double>> phases;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    bool on = getenv("KBBQ_TIMING") != nullptr;
+    void mark(const char *name) {
+        const auto t1 = std::chrono::steady_clock::now();
+        phases.emplace_back(name, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    }
+    ~PhaseClock() {
+        if (!on) return;
+        std::cerr << "[timing]";
+        for (auto &p : phases) std::cerr << " " << p.first << " " << p.second << " s";
+        std::cerr << std::endl;
+    }
 };
 
 static int g_io_threads = 1;   // inflate pool of BGZF inputs (hts_set_thread_pool on the input handle, htsiter.hh:64-66,110-112)
@@ -403,6 +422,7 @@ int main(int argc, char *argv[]) {
     // more, for the output pass.  Falls back to re-reading per pass if the batches do not fit (or with
     // KBBQ_RESIDENT=0), and for the rare inputs where the passes would not see the same reads (an empty read
     // ends the reference's sampling and coverage loops but not the others).
+    PhaseClock clock;
     ReadGroups groups;
     uint64_t seqlen = 0, n_reads = 0;
     size_t longest = 0;
@@ -482,6 +502,7 @@ int main(int argc, char *argv[]) {
         return 1;
     }
 
+    clock.mark("scan+pack+upload");
     kbbq_engine *e = nullptr;
     if (resident.on)
         std::cerr << put_now << " Reads are resident on the GPU: " << resident.dev.size() << " batches"
@@ -591,6 +612,7 @@ int main(int argc, char *argv[]) {
             std::cerr << "]" << std::endl;
         }
         // pass 2, kbbq.cc:333-337
+        clock.mark("pass1");
         std::cerr << put_now << " Finding trusted kmers" << std::endl;
         {
             if (resident.on) {
@@ -605,6 +627,7 @@ int main(int argc, char *argv[]) {
             if (kbbq_trusted_finish(e, nullptr) < 0) return fail_engine("finding trusted kmers");
         }
         // pass 3, kbbq.cc:363-366
+        clock.mark("pass2");
         std::cerr << put_now << " Finding errors" << std::endl;
         {
             if (resident.on) {
@@ -653,10 +676,12 @@ int main(int argc, char *argv[]) {
     }
 
     // kbbq.cc:405-407
+    clock.mark("pass3");
     std::cerr << put_now << " Training model" << std::endl;
     if (kbbq_train(e) < 0) return fail_engine("training");
 
     // pass 4, kbbq.cc:455-457: recalibrate_and_write(file, dqs, "-")
+    clock.mark("model");
     std::cerr << put_now << " Recalibrating file" << std::endl;
     {
         BgzfWriter out(stdout, out_threads);
@@ -745,6 +770,7 @@ int main(int argc, char *argv[]) {
         }
         if (!out.close()) return 1;
     }
+    clock.mark("pass4+format+deflate+write");
     resident.drop();
     kbbq_engine_destroy(e);
     return 0;

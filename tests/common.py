@@ -27,7 +27,7 @@ def make_dataset(seed=12345, genome_len=20000, coverage=20, read_len=150, n_rg=1
         # substitutions at quality 37, spaced closer than k in some reads: leaves reads without any trusted
         # k-mer (correct_one) and ties / unfixable stretches (bad prefix / suffix recursion)
         seq = d["seq"].reshape(n_reads, read_len)
-        for r in rng.choice(n_reads, size=extra_errors, replace=False):
+        for r in rng.choice(n_reads, size=min(extra_errors, n_reads), replace=False):
             step = rng.randint(8, 60)
             for p in range(rng.randint(0, step), read_len, step):
                 seq[r, p] = ord("ACGT"[("ACGT".find(chr(seq[r, p])) + 1 + rng.randint(0, 3)) % 4]) if chr(seq[r, p]) in "ACGT" else seq[r, p]
@@ -35,7 +35,7 @@ def make_dataset(seed=12345, genome_len=20000, coverage=20, read_len=150, n_rg=1
         # 6-9 substitutions 2-4 bases apart: each is fixable in turn, so the over-correction window
         # (more than 4 fixes in 20 bases, readutils.cc:479-546) fires
         seq = d["seq"].reshape(n_reads, read_len)
-        for r in rng.choice(n_reads, size=clusters, replace=False):
+        for r in rng.choice(n_reads, size=min(clusters, n_reads), replace=False):
             p = rng.randint(35, read_len - 60)
             for _ in range(rng.randint(6, 10)):
                 if chr(seq[r, p]) in "ACGT":
@@ -143,7 +143,8 @@ def make_softmasked_dataset(seed=707, frac=0.04, stretches=120, digits=30, **kw)
         low[s:min(b, s + rng.randint(10, 80))] = True
     low &= acgt
     seq[low] = seq[low] + 32                      # 'A' -> 'a'
-    idx = rng.choice(np.nonzero(acgt & ~low)[0], size=digits, replace=False)
+    cand = np.nonzero(acgt & ~low)[0]
+    idx = rng.choice(cand, size=min(digits, len(cand)), replace=False)
     seq[idx] = np.frombuffer(b"0123", dtype=np.uint8)[np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), seq[idx])]
     d["seq"] = np.ascontiguousarray(seq)
     return d

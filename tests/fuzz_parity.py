@@ -68,7 +68,7 @@ def run_cases(n_cases, seed0, verbose=True):
     failures = []
     for case in range(n_cases):
         k = int(rng.choice([3, 5, 8, 11, 15, 16, 17, 21, 24, 27, 31, 32]))
-        read_len = int(rng.choice([max(k + 3, 36), 50, 76, 100, 101, 150, 151, 193, 250, 300, 321, 400, 512]))
+        read_len = int(rng.choice([max(k + 3, 36), 50, 76, 100, 101, 150, 151, 193, 250, 300, 321, 400, 512, 513, 600, 777, 1100]))
         read_len = max(read_len, k + 2)
         n_rg = int(rng.choice([1, 1, 2, 3, 7]))
         paired = bool(rng.randint(0, 2))
@@ -82,9 +82,19 @@ def run_cases(n_cases, seed0, verbose=True):
                   mid_reads=int(rng.choice([0, 20])) if ragged and read_len > 70 else 0,
                   extra_errors=int(rng.choice([0, 30])), clusters=int(rng.choice([0, 10])) if read_len >= 150 else 0)
         nb = int(rng.choice([1, 2, 5]))
-        desc = "case %d k=%d %s alpha=%s batches=%d" % (case, k, kw, alpha, nb)
+        # slice-bucketed inserts forced onto these small filters in half of the cases, with a record capacity far below
+        # a batch in some (every batch flushes, most records overflow into the direct path); soft-masked text in a quarter
+        bucket = [None, "1"][rng.randint(0, 2)]
+        records = [None, "2000", "60000"][rng.randint(0, 3)] if bucket else None
+        soft = rng.randint(0, 4) == 0
+        for name, val in (("KBBQ_BUCKET", bucket), ("KBBQ_BUCKET_RECORDS", records)):
+            if val is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = val
+        desc = "case %d k=%d %s alpha=%s batches=%d bucket=%s/%s soft=%d" % (case, k, kw, alpha, nb, bucket, records, soft)
         try:
-            d = common.make_dataset(**kw)
+            d = common.make_softmasked_dataset(frac=float(rng.choice([0.1, 0.5])), stretches=10, digits=5, **kw) if soft else common.make_dataset(**kw)
             if rng.randint(0, 3) == 0:
                 d = dict(d)
                 q = d["qual"].copy()
@@ -106,6 +116,8 @@ def run_cases(n_cases, seed0, verbose=True):
             print("FAIL", desc, flush=True)
             traceback.print_exc()
 
+    os.environ.pop("KBBQ_BUCKET", None)
+    os.environ.pop("KBBQ_BUCKET_RECORDS", None)
     return failures
 
 

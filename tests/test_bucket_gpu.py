@@ -91,3 +91,22 @@ def test_bucketed_equals_direct_on_a_filter_of_many_level1_buckets(records, monk
     assert int(b[2].ne(0).sum()) > 0
     if records:
         assert b[5]["bucket_flushes"][1] >= 2
+
+
+def test_level1_regions_per_xcd_give_the_same_filters():
+    """KBBQ_BUCKET_SHARED=1: one level-1 region per (XCD, bucket) filled through global atomics instead of one per
+    emitting workgroup (bucket.h) -- read once per process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, 'tests'); import common\n"
+            "for name in ('uniform_150', 'ragged_2rg_paired', 'reads_400'):\n"
+            "    build, dkw, rkw, ekw = common.PARITY_CASES[name]\n"
+            "    d = build(**dkw)\n"
+            "    eng = common.run_engine(d, **rkw, **dict(ekw, n_batches=3))\n"
+            "    common.assert_same_run(eng, common.run_oracle(d, **rkw))\n"
+            "    assert eng['stats']['bucket_capacity'] > 0\n"
+            "print('shared regions ok')\n")
+    env = dict(os.environ, KBBQ_BUCKET="1", KBBQ_BUCKET_SHARED="1")
+    out = subprocess.run([sys.executable, "-c", code], cwd=common.ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "shared regions ok" in out.stdout, out.stdout + out.stderr
