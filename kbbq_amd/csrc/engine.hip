@@ -1308,6 +1308,18 @@ template <int NW> struct LaunchTrusted {
         for (size_t i = 0; i < e->thresholds.size() && i <= KBBQ_MAX_KMER; ++i) thr.v[i] = e->thresholds[i];
         {
             Timed t(e, "k_infer");
+            static const int occ = getenv("KBBQ_INFER_OCC") ? atoi(getenv("KBBQ_INFER_OCC")) : 0;
+            static const int per_cu = getenv("KBBQ_INFER_BLOCKS") ? atoi(getenv("KBBQ_INFER_BLOCKS")) : 0;
+            if (per_cu > 0)
+                hipLaunchKernelGGL(k_infer<NW>, dim3(std::min(wave_grid(R.n_reads), 256 * per_cu)), dim3(256), 0, e->stream, R, e->K,
+                                   e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3);
+            else if (occ == 8)
+                hipLaunchKernelGGL((k_infer<NW, 8>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
+                                   e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3);
+            else if (occ == 7)
+                hipLaunchKernelGGL((k_infer<NW, 7>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
+                                   e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3);
+            else
             hipLaunchKernelGGL(k_infer<NW>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
                                e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3);
             HIP_TRY(hipGetLastError());
@@ -1440,6 +1452,15 @@ int kbbq_trusted_finish(kbbq_engine *e, uint64_t *inserted) {
 template <int NW> struct LaunchScan {
     static int go(kbbq_engine *e, ReadsDev R, uint64_t *tmask, uint8_t *dirty, uint32_t *err_bits, int fast) {
         Timed t(e, "k_scan_trusted", e->cur);
+        static const int occ = getenv("KBBQ_SCAN_OCC") ? atoi(getenv("KBBQ_SCAN_OCC")) : 0;
+        static const int per_cu = getenv("KBBQ_SCAN_BLOCKS") ? atoi(getenv("KBBQ_SCAN_BLOCKS")) : 0;
+        if (per_cu > 0)
+            hipLaunchKernelGGL(k_scan_trusted<NW>, dim3(std::min(wave_grid(R.n_reads), 256 * per_cu)), dim3(256), 0, e->cur, R, e->K,
+                               e->filt[1].dev(), tmask, dirty, err_bits, e->cur_cnt, fast);
+        else if (occ == 8)
+            hipLaunchKernelGGL((k_scan_trusted<NW, 8>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->cur, R, e->K,
+                               e->filt[1].dev(), tmask, dirty, err_bits, e->cur_cnt, fast);
+        else
         hipLaunchKernelGGL(k_scan_trusted<NW>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->cur, R, e->K,
                            e->filt[1].dev(), tmask, dirty, err_bits, e->cur_cnt, fast);
         HIP_TRY(hipGetLastError());

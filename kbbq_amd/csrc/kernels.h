@@ -249,8 +249,10 @@ __global__ void __launch_bounds__(256) k_insert_marked(ReadsDev R, KParams K, Fi
 // window become range pop-counts on those words.
 struct Thresholds { int v[KBBQ_MAX_KMER + 1]; };
 
-template <int NW>
-__global__ void __launch_bounds__(256) k_infer(ReadsDev R, KParams K, FiltDev S, Thresholds thr, uint32_t *take_bits,
+// MINW: waves per SIMD the register allocation must leave room for (the kernel waits on random HBM lines three
+// quarters of the time: more resident waves keep more lookups in flight)
+template <int NW, int MINW = 1>
+__global__ void __launch_bounds__(256, MINW) k_infer(ReadsDev R, KParams K, FiltDev S, Thresholds thr, uint32_t *take_bits,
                                                 unsigned long long *inserted, uint32_t *err_out, uint32_t *qpresent,
                                                 unsigned long long *lookups) {
     using St = Stage<NW>;
@@ -487,8 +489,8 @@ __device__ __forceinline__ bool fast_path(const uint32_t *L32, const KParams &K,
 // Wave per read.  A read whose k-mers are all trusted has no errors
 // (readutils.cc:263-265) and needs nothing more than the tally; the others get
 // their mask stored and a flag for the correction kernel.
-template <int NW>
-__global__ void __launch_bounds__(256) k_scan_trusted(ReadsDev R, KParams K, FiltDev T, uint64_t *tmask,
+template <int NW, int MINW = 1>
+__global__ void __launch_bounds__(256, MINW) k_scan_trusted(ReadsDev R, KParams K, FiltDev T, uint64_t *tmask,
                                                        uint8_t *dirty, uint32_t *err_bits, unsigned long long *stats,
                                                        int fast) {
     using S = Stage<NW>;

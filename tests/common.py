@@ -46,11 +46,11 @@ def make_dataset(seed=12345, genome_len=20000, coverage=20, read_len=150, n_rg=1
         if ragged:
             lens = rng.randint(read_len * 2 // 3 if ragged_min is None else ragged_min, read_len + 1, size=n_reads)
         if short_reads:
-            idx = rng.choice(n_reads, size=short_reads, replace=False)
-            lens[idx] = rng.randint(1, 31, size=short_reads)
+            idx = rng.choice(n_reads, size=min(short_reads, n_reads), replace=False)
+            lens[idx] = rng.randint(1, 31, size=len(idx))
         if mid_reads:
-            idx = rng.choice(n_reads, size=mid_reads, replace=False)
-            lens[idx] = rng.randint(32, 64, size=mid_reads)
+            idx = rng.choice(n_reads, size=min(mid_reads, n_reads), replace=False)
+            lens[idx] = rng.randint(32, 64, size=len(idx))
         keep = (np.arange(read_len)[None, :] < lens[:, None]).reshape(-1)
         d["seq"] = np.ascontiguousarray(d["seq"][keep])
         d["qual"] = np.ascontiguousarray(d["qual"][keep])
