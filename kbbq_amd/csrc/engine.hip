@@ -1555,6 +1555,7 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
     if (lds > e->attr_lds_tally) {
         HIP_TRY(hipFuncSetAttribute((const void *)k_tally<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void *)k_tally<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_tally_uniform, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         e->attr_lds_tally = lds;
     }
     // 16 wavefronts share one set of LDS tables: one 1024-lane block per CU, two when the tables leave room
@@ -1572,6 +1573,16 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
         present = pr;
     }
     const int n_windows = (max_len + ccap - 1) / ccap;
+    // the common shape -- equally long reads, one read group, every cycle in one table -- has a kernel of its own
+    static const bool general_only = getenv("KBBQ_TALLY_GENERAL") != nullptr;
+    if (!general_only && !R.offsets && !compact && n_windows == 1 && R.read_len >= 16 && (int)R.read_len <= ccap && R.n_bases < (1ULL << 32) && vec_ok &&
+        e->p.n_rg == 1) {
+        const unsigned long long inv_len = ~0ULL / R.read_len + 1;      // ceil(2^64 / read_len): read_len is no power of two times... exact below
+        Timed t(e, "k_tally", stream);
+        hipLaunchKernelGGL(k_tally_uniform, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, inv_len);
+        HIP_TRY(hipGetLastError());
+        return KBBQ_OK;
+    }
     Timed t(e, "k_tally", stream);
     for (int g = 0; g < n_rg; g += per_launch)
         for (int w = 0; w < n_windows; ++w) {

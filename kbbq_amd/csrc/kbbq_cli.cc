@@ -256,6 +256,14 @@ struct Batch {
         c.offsets = off.data();
         c.flags = flags.data();
         c.rg = rg.data();
+        // equally long reads (the usual Illumina file): the batch goes over as a uniform one -- no offsets array, the
+        // engine's kernels for that shape (results do not depend on which form a batch takes)
+        bool uniform = longest > 0;
+        for (size_t r = 0; uniform && r + 1 < off.size(); ++r) uniform = off[r + 1] - off[r] == longest;
+        if (uniform && longest <= 0xFFFFFFFFu) {
+            c.offsets = nullptr;
+            c.read_len = (uint32_t)longest;
+        }
         return true;
     }
 };

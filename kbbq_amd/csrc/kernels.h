@@ -992,6 +992,129 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
     }
 }
 
+// ---- pass 3c, the common shape: uniform read length, one read group, one cycle window ------------------------
+// k_tally's general loop spends 1 700 VALU + 1 700 SALU instructions per 16 bases on bookkeeping that a batch of
+// equally long reads of one read group does not need (read boundaries from an offsets array, read-group slots,
+// quality slots, cycle windows).  Here: the read of a 16-base group is one 64-bit multiply-high (inv_len =
+// ceil(2^64 / read_len), exact for the 32-bit base offsets of a batch), a group lies in one read or straddles one
+// boundary (read_len >= 16), every quality value is its own slot and every cycle is in the table.  Same LDS
+// tables (packed 16-bit counters, cycle slots permuted against bank conflicts) and same result as k_tally<false>.
+__global__ void __launch_bounds__(1024) k_tally_uniform(ReadsDev R, HistDev H, const uint32_t *err_bits, const uint32_t *patch,
+                                                         int ccap, int minscore, unsigned long long inv_len) {
+    extern __shared__ uint32_t lds[];
+    constexpr int ns = KBBQ_NQ;
+    const int L = (int)R.read_len;
+    const int cyc_words = (2 * ccap * ns + 1) / 2, cstep = ccap >> 4;
+    uint32_t *t_err = lds + cyc_words, *t_di = lds + 2 * cyc_words, *t_die = t_di + ns * 16;
+    const int lds_words = 2 * cyc_words + 2 * ns * 16;
+    for (int i = threadIdx.x; i < lds_words; i += blockDim.x) lds[i] = 0;
+    __syncthreads();
+    auto count = [&](int tb, int q, int cyc, int er, bool dinuc_ok, int d) {
+        const int idx = tb + q * ccap + (cyc & 15) * cstep + (cyc >> 4);
+        const uint32_t one = 1u << (16 * (idx & 1));
+        atomicAdd(&lds[idx >> 1], one);
+        if (er) atomicAdd(&t_err[idx >> 1], one);
+        if (dinuc_ok) {
+            atomicAdd(&t_di[q * 16 + d], 1u);
+            if (er) atomicAdd(&t_die[q * 16 + d], 1u);
+        }
+    };
+    auto flush = [&]() {
+        for (int w = threadIdx.x; w < cyc_words; w += blockDim.x) {
+            const uint32_t v = lds[w], ve = t_err[w];
+            if (!v) continue;
+            lds[w] = 0;
+            t_err[w] = 0;
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t cnt = (v >> (16 * h)) & 0xFFFFu, cne = (ve >> (16 * h)) & 0xFFFFu;
+                if (!cnt) continue;
+                const int idx = 2 * w + h;
+                const int slot = idx % ccap, rest = idx / ccap;
+                const int q = rest % ns, sec = rest / ns;
+                const int c = (slot % cstep) * 16 + slot / cstep;
+                if (c < H.n_cycle) {
+                    atomicAdd(&H.cycle[cyc_index(H, 0, q, sec, c) + 1], (unsigned long long)cnt);
+                    if (cne) atomicAdd(&H.cycle[cyc_index(H, 0, q, sec, c)], (unsigned long long)cne);
+                }
+            }
+        }
+        for (int w = threadIdx.x; w < ns * 16; w += blockDim.x) {
+            const uint32_t v = t_di[w], ve = t_die[w];
+            if (v) { t_di[w] = 0; atomicAdd(&H.dinuc[(uint64_t)w * 2 + 1], (unsigned long long)v); }
+            if (ve) { t_die[w] = 0; atomicAdd(&H.dinuc[(uint64_t)w * 2], (unsigned long long)ve); }
+        }
+    };
+    const uint64_t n_groups = (R.n_bases + 15) / 16;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t iters = (n_groups + stride - 1) / stride;
+    // a read adds at most one to a 16-bit counter; a block touches at most 16384 / L + 2 reads per iteration
+    const uint64_t flush_every = max((uint64_t)1, (uint64_t)40000 / ((uint64_t)16384 / (uint64_t)L + 2));
+    for (uint64_t it = 0; it < iters; ++it) {
+        const uint64_t g0 = (it * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+        if (g0 + 16 <= R.n_bases) {
+            const uint32_t r = (uint32_t)__umul64hi((unsigned long long)g0, inv_len);
+            const int c0 = (int)(g0 - (uint64_t)r * (uint64_t)L);
+            const int bpos = L - c0 < 16 ? L - c0 : 16;      // first base of the next read inside the group
+            const uint4 qv4 = *reinterpret_cast<const uint4 *>(R.qual + g0);
+            uint8_t qv[16];
+            memcpy(qv, &qv4, 16);
+            const uint32_t bw = (uint32_t)(R.bases[g0 >> 5] >> ((g0 & 31) * 2));
+            const uint32_t nw = (uint32_t)(R.nmask[g0 >> 6] >> (g0 & 63)) & 0xFFFFu;
+            const uint32_t ew = (err_bits[g0 >> 5] >> (g0 & 31)) & 0xFFFFu;
+            int prev_b = 0, prev_n = 1;
+            if (g0 > 0) {
+                const uint64_t gp = g0 - 1;
+                prev_b = (int)((R.bases[gp >> 5] >> ((gp & 31) * 2)) & 3);
+                prev_n = (int)((R.nmask[gp >> 6] >> (gp & 63)) & 1);
+            }
+            const bool two = bpos < 16;
+            const bool mine1 = !R.rg || R.rg[r] == 0, mine2 = !two || !R.rg || R.rg[r + 1] == 0;
+            const int tb1 = (R.flags ? (R.flags[r] & 1) : 0) * ns * ccap;
+            const int tb2 = (two && R.flags ? (R.flags[r + 1] & 1) : 0) * ns * ccap;
+            const uint32_t pt1 = patch ? patch[r] : 0u, pt2 = two && patch ? patch[r + 1] : 0u;
+            const int pp1 = (pt1 >> 31) ? (int)((pt1 >> 8) & 0xFFFF) : -2, pp2 = (pt2 >> 31) ? (int)((pt2 >> 8) & 0xFFFF) : -2;
+            if (pp1 >= 0 && pp1 == c0 - 1) { prev_b = (int)(pt1 & 3); prev_n = 0; }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const bool in2 = i >= bpos;
+                const int cyc = c0 + i - (in2 ? L : 0);
+                int b = (int)((bw >> (2 * i)) & 3), nn = (int)((nw >> i) & 1);
+                if (cyc == (in2 ? pp2 : pp1)) { b = (int)((in2 ? pt2 : pt1) & 3); nn = 0; }
+                const int q = qv[i];
+                if (q < KBBQ_NQ && (in2 ? mine2 : mine1))
+                    count(in2 ? tb2 : tb1, q, cyc, (int)((ew >> i) & 1u), cyc >= 1 && q >= minscore && !(nn | prev_n), (prev_b << 2) | b);
+                prev_b = b;
+                prev_n = nn;
+            }
+        } else if (g0 < R.n_bases) {
+            // the batch's last, partial group: base by base, everything looked up afresh
+            for (uint64_t g = g0; g < R.n_bases; ++g) {
+                const uint64_t r = g / (uint64_t)L;
+                const int cyc = (int)(g - r * (uint64_t)L);
+                const uint32_t pt = patch ? patch[r] : 0u;
+                const int pp = (pt >> 31) ? (int)((pt >> 8) & 0xFFFF) : -2;
+                auto base_at = [&](uint64_t x, int cx, int &bb, int &nb) {
+                    bb = (int)((R.bases[x >> 5] >> ((x & 31) * 2)) & 3);
+                    nb = (int)((R.nmask[x >> 6] >> (x & 63)) & 1);
+                    if (cx == pp) { bb = (int)(pt & 3); nb = 0; }
+                };
+                int b, nn, pb = 0, pn = 1;
+                base_at(g, cyc, b, nn);
+                if (cyc >= 1) base_at(g - 1, cyc - 1, pb, pn);
+                const int q = R.qual[g];
+                const int er = (int)((err_bits[g >> 5] >> (g & 31)) & 1u);
+                if (q < KBBQ_NQ && (!R.rg || R.rg[r] == 0))
+                    count((R.flags ? (R.flags[r] & 1) : 0) * ns * ccap, q, cyc, er, cyc >= 1 && q >= minscore && !(nn | pn), (pb << 2) | b);
+            }
+        }
+        if ((it + 1) % flush_every == 0 || it + 1 == iters) {      // block-uniform
+            __syncthreads();
+            flush();
+            __syncthreads();
+        }
+    }
+}
+
 // ---- pass 4: delta-Q apply -------------------------------------------------------
 // CReadData::recalibrate (readutils.cc:572-595).  One lane per 16 consecutive
 // bases of the batch: 16-byte quality load and store, 4-byte base load.
