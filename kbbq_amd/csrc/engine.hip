@@ -10,6 +10,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/kbbq_engine.h"
@@ -241,10 +242,10 @@ void drain_profile(kbbq_engine *e) {
 int collect_side(kbbq_engine *e, int t) {
     if (!e->side_busy[t]) return KBBQ_OK;
     HIP_TRY(hipEventSynchronize(e->ev_side[t]));
-    unsigned long long c[2], c3 = 0;
-    HIP_TRY(hipMemcpy(c, e->d_counters + 4 * t, 16, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&c3, e->d_counters + 6 + t, 8, hipMemcpyDeviceToHost));      // reads with off-case bases (lane-form walk)
-    e->stats[0] += c[0] + c3;
+    // (the side's counters were copied into page-locked memory behind its kernels: no blocking copy here -- a blocking
+    // hipMemcpy waits for the whole device, which would serialise the copy of the next host batch behind this one's kernels)
+    const unsigned long long *c = e->bk.h_inserted + 2 + 3 * t;      // work-list length, Bloom queries, off-case work-list length
+    e->stats[0] += c[0] + c[2];
     e->stats[1] += c[1];
     e->stats[2] += e->side_reads[t];
     e->side_busy[t] = false;
@@ -934,38 +935,73 @@ int kbbq_filter_set_inserted(kbbq_engine *e, int which, uint64_t inserted) {
 }
 
 // ---- staging
-int kbbq_pack_bases(const uint8_t *seq, uint64_t n_bases, uint64_t *bases_out, uint64_t *nmask_out) {
-    if (!seq || !bases_out || !nmask_out) return fail(KBBQ_EINVAL, "null argument");
-    // seq_nt16_int[seq_nt16_table[ch]] (bloom.hh:351): A/a=0 C/c=1 G/g=2 T/t=3 and '0'..'3'; all else non-ACGT
+// One pass over the text, 64 bases per step with the three bit streams accumulated in registers; large batches are
+// packed by a few threads (the ranges are independent 64-base words).
+static void pack_words(const uint8_t *seq, uint64_t n_bases, uint64_t w_lo, uint64_t w_hi, uint64_t *bases, uint64_t *nmask,
+                       uint64_t *offcase, uint64_t *n_off) {
+    // seq_nt16_int[seq_nt16_table[ch]] (bloom.hh:351): A/a=0 C/c=1 G/g=2 T/t=3 and '0'..'3'; all else non-ACGT (bit 2);
+    // bit 3: an ACGT base whose raw character is not the upper-case letter (kbbq_reads.offcase)
     uint8_t lut[256];
     memset(lut, 4, sizeof lut);
-    lut['A'] = lut['a'] = 0; lut['C'] = lut['c'] = 1; lut['G'] = lut['g'] = 2; lut['T'] = lut['t'] = 3;
-    lut['0'] = 0; lut['1'] = 1; lut['2'] = 2; lut['3'] = 3;
-    memset(bases_out, 0, (n_bases / 32 + 2) * 8);
-    memset(nmask_out, 0, (n_bases / 64 + 2) * 8);
-    for (uint64_t i = 0; i < n_bases; ++i) {
-        const uint8_t c = lut[seq[i]];
-        if (c < 4) bases_out[i >> 5] |= (uint64_t)c << ((i & 31) * 2);
-        else nmask_out[i >> 6] |= 1ULL << (i & 63);
+    lut['A'] = 0; lut['C'] = 1; lut['G'] = 2; lut['T'] = 3;
+    lut['a'] = 8; lut['c'] = 9; lut['g'] = 10; lut['t'] = 11;
+    lut['0'] = 8; lut['1'] = 9; lut['2'] = 10; lut['3'] = 11;
+    uint64_t odd_total = 0;
+    for (uint64_t w = w_lo; w < w_hi; ++w) {
+        const uint64_t first = w * 64;
+        const int n = (int)std::min<uint64_t>(64, n_bases > first ? n_bases - first : 0);
+        uint64_t b0 = 0, b1 = 0, nm = 0, oc = 0;
+        for (int j = 0; j < n; ++j) {
+            const uint8_t c = lut[seq[first + j]];
+            const uint64_t code = (c & 4) ? 0 : (uint64_t)(c & 3);
+            if (j < 32) b0 |= code << (2 * j); else b1 |= code << (2 * (j - 32));
+            nm |= (uint64_t)((c >> 2) & 1) << j;
+            oc |= (uint64_t)((c >> 3) & 1) << j;
+        }
+        bases[2 * w] = b0;
+        bases[2 * w + 1] = b1;
+        nmask[w] = nm;
+        if (offcase) offcase[w] = oc;
+        odd_total += (uint64_t)__builtin_popcountll(oc);
     }
+    if (n_off) *n_off = odd_total;
+}
+
+static int pack_impl(const uint8_t *seq, uint64_t n_bases, uint64_t *bases_out, uint64_t *nmask_out, uint64_t *offcase_out, uint64_t *n_offcase) {
+    // arrays hold n/32+2 and n/64+2 words: everything up to the spare words is written
+    const uint64_t words = n_bases / 64 + 1;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned n_threads = n_bases < (1u << 22) ? 1u : std::min(8u, hw);
+    std::vector<uint64_t> odd(n_threads, 0);
+    if (n_threads == 1) {
+        pack_words(seq, n_bases, 0, words, bases_out, nmask_out, offcase_out, &odd[0]);
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < n_threads; ++t) {
+            const uint64_t lo = words * t / n_threads, hi = words * (t + 1) / n_threads;
+            pool.emplace_back(pack_words, seq, n_bases, lo, hi, bases_out, nmask_out, offcase_out, &odd[t]);
+        }
+        for (auto &th : pool) th.join();
+    }
+    // the spare words behind the data (the kernels read unaligned 64-bit windows)
+    for (uint64_t i = 2 * words; i < n_bases / 32 + 2; ++i) bases_out[i] = 0;
+    nmask_out[words] = 0;
+    if (offcase_out) offcase_out[words] = 0;
+    uint64_t total = 0;
+    for (uint64_t x : odd) total += x;
+    if (n_offcase) *n_offcase = total;
     return KBBQ_OK;
+}
+
+int kbbq_pack_bases(const uint8_t *seq, uint64_t n_bases, uint64_t *bases_out, uint64_t *nmask_out) {
+    if (!seq || !bases_out || !nmask_out) return fail(KBBQ_EINVAL, "null argument");
+    return pack_impl(seq, n_bases, bases_out, nmask_out, nullptr, nullptr);
 }
 
 int kbbq_pack_bases_case(const uint8_t *seq, uint64_t n_bases, uint64_t *bases_out, uint64_t *nmask_out, uint64_t *offcase_out,
                          uint64_t *n_offcase) {
-    if (!offcase_out) return fail(KBBQ_EINVAL, "null argument");
-    int rc = kbbq_pack_bases(seq, n_bases, bases_out, nmask_out);
-    if (rc) return rc;
-    memset(offcase_out, 0, (n_bases / 64 + 2) * 8);
-    uint64_t n = 0;
-    for (uint64_t i = 0; i < n_bases; ++i) {
-        const uint8_t ch = seq[i];
-        // an ACGT base (bloom.hh:351 folds a/c/g/t and '0'..'3' too) whose raw character is not the upper-case letter
-        const bool odd = ch == 'a' || ch == 'c' || ch == 'g' || ch == 't' || (ch >= '0' && ch <= '3');
-        if (odd) { offcase_out[i >> 6] |= 1ULL << (i & 63); ++n; }
-    }
-    if (n_offcase) *n_offcase = n;
-    return KBBQ_OK;
+    if (!seq || !bases_out || !nmask_out || !offcase_out) return fail(KBBQ_EINVAL, "null argument");
+    return pack_impl(seq, n_bases, bases_out, nmask_out, offcase_out, n_offcase);
 }
 
 int kbbq_reads_upload(kbbq_engine *e, const kbbq_reads *host, kbbq_reads *dev) {
@@ -1696,6 +1732,9 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
         if (rc) return rc;
     }
     if ((rc = run_tally(e, R, d_err, patch, max_len, e->cur))) return rc;
+    if (!(R.offcase && !long_reads)) HIP_TRY(hipMemsetAsync(e->d_counters + 6 + side, 0, 8, e->cur));
+    HIP_TRY(hipMemcpyAsync(e->bk.h_inserted + 2 + 3 * side, e->d_counters + 4 * side, 16, hipMemcpyDeviceToHost, e->cur));
+    HIP_TRY(hipMemcpyAsync(e->bk.h_inserted + 4 + 3 * side, e->d_counters + 6 + side, 8, hipMemcpyDeviceToHost, e->cur));
     HIP_TRY(hipEventRecord(e->ev_side[side], e->cur));
     e->side_busy[side] = true;
     e->side_reads[side] = R.n_reads;
