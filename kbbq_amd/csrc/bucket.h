@@ -90,18 +90,18 @@ __device__ __forceinline__ uint32_t block_scan512(uint32_t v, uint32_t *wave_tot
 // partly written tail lines per bucket instead of eight (they are completed in the L2 / the Infinity Cache before
 // they reach HBM).  !PRIV: one region per (XCD, bucket) and one global atomic per bucket and tile.
 // CH = chunks of 64 k-mer starts a read can have (<= NW).
-template <int NW, int CH, bool BY_BASE, int RPW, bool PRIV>
+template <int NW, int CH, bool BY_BASE, int RPW, bool PRIV, bool DENSE = true>
 __global__ void __launch_bounds__(BK_THREADS) k_emit_marked(ReadsDev R, KParams K, FiltDev F, BucketDev B, const uint64_t *mask,
                                                              uint64_t mask_words, const uint64_t *kofs,
                                                              unsigned long long *inserted) {
     using S = Stage<NW>;
     constexpr int SLOTS = RPW * CH;
     extern __shared__ unsigned long long sorted[];      // 8 * SLOTS * 64 records
-    __shared__ uint32_t stage[8][2 * S::WORDS];
+    __shared__ uint32_t stage[8][DENSE ? RPW : 1][2 * S::WORDS];      // DENSE: all RPW reads of the wave staged at once
     __shared__ uint32_t hist[MAX_NB1], ofs_l[MAX_NB1], gbase_l[MAX_NB1], fill_l[MAX_NB1], wave_tot[8];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t *L32 = stage[w];
+    uint32_t *L32 = stage[w][0];
     const int k = K.k;
     const int src = PRIV ? (int)blockIdx.x : xcc_id();
     const uint64_t reads_per_tile = 8 * RPW;
@@ -131,6 +131,51 @@ __global__ void __launch_bounds__(BK_THREADS) k_emit_marked(ReadsDev R, KParams 
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) { rec[s] = 0; rk[s] = -1; }
         // ---- produce and count
+        if (DENSE) {
+            // Only a part of the k-mer starts is marked (23 % in pass 1, 58 % in pass 2) and the hashes are most of this
+            // kernel's instructions: first gather the 64-bit windows of the marked starts of all RPW reads in a dense
+            // list (the wave's share of sorted[], which is idle until the tile's barrier), then hash full wavefronts.
+            unsigned long long *wlist = sorted + (size_t)w * SLOTS * 64;
+            int n_dense = 0;      // wave-uniform
+            __builtin_amdgcn_wave_barrier();
+            if (lane < S::WORDS) {
+#pragma unroll
+                for (int rr = 0; rr < RPW; ++rr) stage_store(stage[w][rr], lane, word[rr]);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int nk = (int)len[rr] - k + 1;
+                if (nk > 0) {
+                    const uint32_t *L32 = stage[w][rr];      // (no barrier between the reads: their chunks are independent instruction streams)
+                    const int o31 = (int)(off[rr] & 31), o63 = (int)(off[rr] & 63), x63 = (int)(kb[rr] & 63);
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        if (c * 64 < nk) {
+                            const int s = c * 64 + lane;
+                            const bool marked = lds_bit(L32 + 2 * S::X, x63 + s) != 0;
+                            const bool valid = (lds_window32(L32 + 2 * S::M, o63 + s) & K.nmask_bits) == 0;
+                            const bool take = s < nk && marked && (BY_BASE || valid);
+                            const unsigned long long bal = __ballot(take);
+                            if (take) wlist[n_dense + __popcll(bal & ((1ULL << lane) - 1))] = lds_window64(L32 + 2 * S::B, 2 * (o31 + s));
+                            n_dense += (int)__popcll(bal);
+                            if (!BY_BASE && R.hint_sampled) or_bits64(R.hint_sampled, off[rr] + (uint64_t)c * 64, bal, lane);
+                            mine += __popcll(bal);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i) {
+                if (i * 64 < n_dense && i * 64 + lane < n_dense) {
+                    const uint64_t key = canon_key(wlist[i * 64 + lane], K);
+                    const uint32_t blk = block_of(F, key);
+                    rec[i] = ((unsigned long long)blk << 16) | pattern_of(F, key);
+                    rk[i] = (int)atomicAdd(&hist[blk >> L1_SHIFT], 1u);
+                }
+            }
+        } else {
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
             const int nk = (int)len[rr] - k + 1;
@@ -158,6 +203,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_emit_marked(ReadsDev R, KParams 
                     }
                 }
             }
+        }
         }
         if (tile + gridDim.x < n_tiles) fetch_tile(tile + gridDim.x);      // travels while this tile is sorted and written
         __syncthreads();
@@ -192,7 +238,9 @@ __global__ void __launch_bounds__(BK_THREADS) k_emit_marked(ReadsDev R, KParams 
                 ++direct;
             }
         }
-        // (the next tile's counting only touches hist[]; ofs_l/gbase_l/sorted are rewritten behind its barriers)
+        // (the next tile's counting only touches hist[]; ofs_l/gbase_l/sorted are rewritten behind its barriers --
+        // except the dense form's window lists, which live in sorted[])
+        if (DENSE) __syncthreads();
     }
     if (PRIV && (int)threadIdx.x < B.nb1) B.l1_cnt[(size_t)src * B.nb1 + threadIdx.x] = fill_l[threadIdx.x];
     if (inserted && lane == 0 && mine) atomicAdd(inserted, mine);

@@ -40,6 +40,7 @@ static int fail(int code, const char *fmt, ...) {
 
 #include "kernels.h"
 #include "bucket.h"
+#include "lookup.h"
 #include "long_reads.h"
 
 // ============================================================ engine object
@@ -1201,20 +1202,26 @@ static int launch_emit(kbbq_engine *e, int w, ReadsDev R, const uint64_t *mask, 
     const size_t lds = (size_t)8 * RPW * CH * 64 * 8;
     hipStream_t st = bucket_stream(e, w);
     Timed t(e, w ? "k_emit_trusted" : "k_emit_sampled", st);
+    static const bool dense = !(getenv("KBBQ_EMIT_DENSE") && atoi(getenv("KBBQ_EMIT_DENSE")) == 0);      // A/B: hash every lane of every chunk
 #define KBBQ_EMIT(BYB, PRIV)                                                                                                  \
     do {                                                                                                                      \
-        const void *fn = (const void *)k_emit_marked<NW, CH, BYB, RPW, PRIV>;                                                  \
+        if (dense) KBBQ_EMIT2(BYB, PRIV, true); else KBBQ_EMIT2(BYB, PRIV, false);                                            \
+    } while (0)
+#define KBBQ_EMIT2(BYB, PRIV, DENSE)                                                                                          \
+    do {                                                                                                                      \
+        const void *fn = (const void *)k_emit_marked<NW, CH, BYB, RPW, PRIV, DENSE>;                                           \
         size_t &raised = e->attr_lds_correct[fn];                                                                             \
         if (lds > 48 * 1024 && lds > raised) {                                                                                \
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
             raised = lds;                                                                                                     \
         }                                                                                                                     \
-        hipLaunchKernelGGL((k_emit_marked<NW, CH, BYB, RPW, PRIV>), dim3(grid), dim3(BK_THREADS), lds, st, R, e->K,            \
+        hipLaunchKernelGGL((k_emit_marked<NW, CH, BYB, RPW, PRIV, DENSE>), dim3(grid), dim3(BK_THREADS), lds, st, R, e->K,     \
                            e->filt[w].dev(), B, mask, mask_words, kofs, inserted);                                            \
     } while (0)
     if (bucket_private()) { if (w == 0) KBBQ_EMIT(false, true); else KBBQ_EMIT(true, true); }
     else                  { if (w == 0) KBBQ_EMIT(false, false); else KBBQ_EMIT(true, false); }
 #undef KBBQ_EMIT
+#undef KBBQ_EMIT2
     HIP_TRY(hipGetLastError());
     return KBBQ_OK;
 }
@@ -1226,6 +1233,7 @@ static int dispatch_emit(kbbq_engine *e, int w, int max_len, ReadsDev R, const u
     static const int rpw8 = getenv("KBBQ_EMIT_RPW") ? atoi(getenv("KBBQ_EMIT_RPW")) : 0;
     if (max_len <= 192) {
         if (max_nk <= 128) return rpw8 == 8 ? launch_emit<3, 2, 8>(e, w, R, mask, mask_words, kofs, inserted)
+                                 : rpw8 == 2 ? launch_emit<3, 2, 2>(e, w, R, mask, mask_words, kofs, inserted)
                                             : launch_emit<3, 2, 4>(e, w, R, mask, mask_words, kofs, inserted);
         return launch_emit<3, 3, 4>(e, w, R, mask, mask_words, kofs, inserted);
     }
@@ -1337,6 +1345,138 @@ int kbbq_set_thresholds(kbbq_engine *e, const int32_t *thresholds, int32_t n) {
 // ---- pass 2
 }  // extern "C"
 
+
+// ---- measurement harness for slice-bucketed LOOKUPS (lookup.h): KBBQ_LOOKUP_PROBE=1 runs the whole chain for every
+// uniform short-read batch of pass 2, after the product's k_infer, into buffers of its own; nothing it computes is used
+// except -- KBBQ_LOOKUP_PROBE=2 -- to compare its insert decisions with k_infer's (a mismatch count on stderr).
+struct LookupProbe {
+    bool ready = false;
+    uint64_t for_bases = 0;
+    LookupDev B;
+    IdsDev D;
+    uint32_t *take = nullptr, *mismatch = nullptr;
+    unsigned long long *dummy = nullptr;
+    size_t l1cnt_bytes = 0, l2cnt_bytes = 0, dcnt_bytes = 0, bits_bytes = 0;
+};
+static LookupProbe g_probe;
+
+__global__ void k_count_diff(const uint32_t *a, const uint32_t *b, uint64_t n, uint32_t *out) {
+    uint32_t d = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) d += __popc(a[i] ^ b[i]);
+    if (d) atomicAdd(out, d);
+}
+
+static int lookup_probe(kbbq_engine *e, const ReadsDev &R, const Thresholds &thr, const uint32_t *take_ref, int level) {
+    LookupProbe &P = g_probe;
+    const FiltDev F = e->filt[0].dev();
+    if (!P.ready || P.for_bases < R.n_bases) {
+        if (P.ready) return KBBQ_OK;      // (sized by the first batch; a larger one later is skipped)
+        const uint64_t room_bases = R.n_bases + R.n_bases / 4;      // (later batches may be a little larger)
+        const double records = 0.8 * (double)room_bases + 65536.0;
+        const double emitters = (double)std::min<uint64_t>((R.n_reads + 31) / 32, EMIT_GRID);
+        const uint64_t n_blocks = F.n_blocks;
+        LookupDev &B = P.B;
+        B.n_sub = (uint32_t)((n_blocks + SUB_BLOCKS - 1) >> SUB_BITS);
+        B.nb1 = (int)((B.n_sub + NB2 - 1) >> NB2_BITS);
+        const double f1 = std::min(1.0, (double)(1ULL << L1_SHIFT) / (double)n_blocks), f2 = std::min(1.0, (double)SUB_BLOCKS / (double)n_blocks);
+        B.cap1 = (uint32_t)(records * 1.15 * f1 / emitters) + 64;
+        B.cap2 = (uint32_t)(records * 1.25 * f2) + 32;
+        B.cap_abs = (uint32_t)(records * 0.4 / N_XCD * 1.3) + 1024;
+        P.l1cnt_bytes = (size_t)EMIT_GRID * B.nb1 * 4;
+        P.l2cnt_bytes = (size_t)B.nb1 * NB2 * 4;
+        P.bits_bytes = (room_bases / 64 + 2) * 8;
+        IdsDev &D = P.D;
+        D.n_bins = (int)((room_bases >> IDS_BIN_BITS) + 1);
+        if (D.n_bins > 512) return KBBQ_OK;
+        D.cap = (uint32_t)(records * 0.4 / IDS_GRID / D.n_bins * 1.5) + 256;
+        P.dcnt_bytes = (size_t)IDS_GRID * D.n_bins * 4;
+        HIP_TRY(hipMalloc(&B.l1, (size_t)EMIT_GRID * B.nb1 * B.cap1 * 8));
+        HIP_TRY(hipMalloc(&B.l1id, (size_t)EMIT_GRID * B.nb1 * B.cap1 * 4));
+        HIP_TRY(hipMalloc(&B.l2, (size_t)B.nb1 * NB2 * B.cap2 * 8));
+        HIP_TRY(hipMalloc(&B.l1_cnt, P.l1cnt_bytes));
+        HIP_TRY(hipMalloc(&B.l2_cnt, P.l2cnt_bytes));
+        HIP_TRY(hipMalloc(&B.tickets, kTicketBytes));
+        HIP_TRY(hipMalloc(&B.abs_cnt, kTicketBytes));
+        HIP_TRY(hipMalloc(&B.abs_list, (size_t)N_XCD * B.cap_abs * 4));
+        HIP_TRY(hipMalloc(&B.absent_bits, P.bits_bytes));
+        HIP_TRY(hipMalloc(&B.direct, 8));
+        HIP_TRY(hipMalloc(&D.regions, (size_t)IDS_GRID * D.n_bins * D.cap * 4));
+        HIP_TRY(hipMalloc(&D.cnt, P.dcnt_bytes));
+        HIP_TRY(hipMalloc(&P.take, P.bits_bytes));
+        HIP_TRY(hipMalloc(&P.dummy, 64));
+        HIP_TRY(hipMalloc(&P.mismatch, 64));
+        HIP_TRY(hipMemsetAsync(B.direct, 0, 8, e->stream));
+        HIP_TRY(hipMemsetAsync(P.dummy, 0, 64, e->stream));
+        P.ready = true;
+        P.for_bases = room_bases;
+        fprintf(stderr, "[lookup probe] nb1 %d n_sub %u cap1 %u cap2 %u cap_abs %u bins %d cap %u\n", B.nb1, B.n_sub, B.cap1, B.cap2, B.cap_abs,
+                D.n_bins, D.cap);
+    }
+    const LookupDev &B = P.B;
+    const IdsDev &D = P.D;
+    hipStream_t st = e->stream;
+    HIP_TRY(hipMemsetAsync(B.l1_cnt, 0, P.l1cnt_bytes, st));
+    HIP_TRY(hipMemsetAsync(B.l2_cnt, 0, P.l2cnt_bytes, st));
+    HIP_TRY(hipMemsetAsync(B.tickets, 0, kTicketBytes, st));
+    HIP_TRY(hipMemsetAsync(B.abs_cnt, 0, kTicketBytes, st));
+    HIP_TRY(hipMemsetAsync(B.absent_bits, 0, P.bits_bytes, st));
+    HIP_TRY(hipMemsetAsync(D.cnt, 0, P.dcnt_bytes, st));
+    HIP_TRY(hipMemsetAsync(P.take, 0, P.bits_bytes, st));
+    {
+        Timed t(e, "probe_emit_lookup");
+        const void *fn = (const void *)k_emit_lookup<3, 2, 4>;
+        const size_t lds = (size_t)8 * 4 * 2 * 64 * 12;
+        size_t &raised = e->attr_lds_correct[fn];
+        if (lds > raised) { HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); raised = lds; }
+        const uint64_t n_tiles = (R.n_reads + 31) / 32;
+        hipLaunchKernelGGL((k_emit_lookup<3, 2, 4>), dim3((unsigned)std::min<uint64_t>(n_tiles, EMIT_GRID)), dim3(BK_THREADS), lds, st, R, e->K, F, B,
+                           0u, P.dummy);
+        HIP_TRY(hipGetLastError());
+    }
+    {
+        Timed t(e, "probe_split_lookup");
+        hipLaunchKernelGGL(k_split_lookup, dim3(256 * 2), dim3(BK_THREADS), 0, st, F, B, (B.cap1 + LSPLIT_TILE - 1) / LSPLIT_TILE);
+        HIP_TRY(hipGetLastError());
+    }
+    {
+        Timed t(e, "probe_apply_lookup");
+        hipLaunchKernelGGL(k_apply_lookup, dim3(B.n_sub), dim3(APPLY_THREADS), 0, st, F, B);
+        HIP_TRY(hipGetLastError());
+    }
+    {
+        Timed t(e, "probe_scatter_ids");
+        hipLaunchKernelGGL(k_scatter_ids, dim3(IDS_GRID), dim3(BK_THREADS), 0, st, B, D);
+        HIP_TRY(hipGetLastError());
+    }
+    {
+        Timed t(e, "probe_ids_to_bits");
+        const void *fn = (const void *)k_ids_to_bits;
+        const size_t lds = 128 * 1024;
+        size_t &raised = e->attr_lds_correct[fn];
+        if (lds > raised) { HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); raised = lds; }
+        hipLaunchKernelGGL(k_ids_to_bits, dim3(D.n_bins * 4), dim3(1024), lds, st, B, D, (uint32_t)R.n_bases);
+        HIP_TRY(hipGetLastError());
+    }
+    {
+        Timed t(e, "probe_infer_deferred");
+        hipLaunchKernelGGL((k_infer<3, 1, true>), dim3(wave_grid(R.n_reads)), dim3(256), 0, st, R, e->K, F, thr, P.take, P.dummy, (uint32_t *)nullptr,
+                           (uint32_t *)(P.dummy + 2), P.dummy + 1, (const uint64_t *)B.absent_bits);
+        HIP_TRY(hipGetLastError());
+    }
+    if (level >= 2) {
+        uint32_t h[2] = {0, 0};
+        unsigned long long direct = 0;
+        HIP_TRY(hipMemsetAsync(P.mismatch, 0, 8, st));
+        hipLaunchKernelGGL(k_count_diff, dim3(1024), dim3(256), 0, st, (const uint32_t *)P.take, take_ref, (R.n_bases / 64 + 1) * 2, P.mismatch);
+        HIP_TRY(hipMemcpyAsync(h, P.mismatch, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&direct, B.direct, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        fprintf(stderr, "[lookup probe] %llu reads: insert decisions differing from k_infer's: %u; overflow records so far %llu\n",
+                (unsigned long long)R.n_reads, h[0], direct);
+    }
+    return KBBQ_OK;
+}
+
 template <int NW> struct LaunchTrusted {
     static int go(kbbq_engine *e, ReadsDev R, uint32_t *take_bits, uint32_t *err_out, int max_len) {
         Thresholds thr;
@@ -1348,17 +1488,24 @@ template <int NW> struct LaunchTrusted {
             static const int per_cu = getenv("KBBQ_INFER_BLOCKS") ? atoi(getenv("KBBQ_INFER_BLOCKS")) : 0;
             if (per_cu > 0)
                 hipLaunchKernelGGL(k_infer<NW>, dim3(std::min(wave_grid(R.n_reads), 256 * per_cu)), dim3(256), 0, e->stream, R, e->K,
-                                   e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3);
+                                   e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3, (const uint64_t *)nullptr);
             else if (occ == 8)
                 hipLaunchKernelGGL((k_infer<NW, 8>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
-                                   e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3);
+                                   e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3, (const uint64_t *)nullptr);
             else if (occ == 7)
                 hipLaunchKernelGGL((k_infer<NW, 7>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
-                                   e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3);
+                                   e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3, (const uint64_t *)nullptr);
             else
             hipLaunchKernelGGL(k_infer<NW>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
-                               e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3);
+                               e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3, (const uint64_t *)nullptr);
             HIP_TRY(hipGetLastError());
+        }
+        {
+            static const int probe = getenv("KBBQ_LOOKUP_PROBE") ? atoi(getenv("KBBQ_LOOKUP_PROBE")) : 0;
+            if (probe && NW == 3 && !R.offsets && max_len - e->p.k + 1 <= 128 && R.n_bases < (1ull << 31)) {
+                int prc = lookup_probe(e, R, thr, take_bits, probe);
+                if (prc) return prc;
+            }
         }
         if (bucket_on(e, 1)) {
             // The insert side of pass 2 -- emit, and split + apply whenever the record buffers fill -- runs on the

@@ -251,10 +251,12 @@ struct Thresholds { int v[KBBQ_MAX_KMER + 1]; };
 
 // MINW: waves per SIMD the register allocation must leave room for (the kernel waits on random HBM lines three
 // quarters of the time: more resident waves keep more lookups in flight)
-template <int NW, int MINW = 1>
+// DEFER (lookup.h): the membership tests were made beforehand, slice by slice; `absent` holds one bit per k-mer start of
+// the batch (set = looked up and not in the filter) and the kernel touches the filter no more.
+template <int NW, int MINW = 1, bool DEFER = false>
 __global__ void __launch_bounds__(256, MINW) k_infer(ReadsDev R, KParams K, FiltDev S, Thresholds thr, uint32_t *take_bits,
                                                 unsigned long long *inserted, uint32_t *err_out, uint32_t *qpresent,
-                                                unsigned long long *lookups) {
+                                                unsigned long long *lookups, const uint64_t *absent = nullptr) {
     using St = Stage<NW>;
     __shared__ uint32_t lds[4][St::LDS_U32];
     __shared__ int thr_lds[KBBQ_MAX_KMER + 1];
@@ -272,9 +274,10 @@ __global__ void __launch_bounds__(256, MINW) k_infer(ReadsDev R, KParams K, Filt
     if (lane < St::RES) { PW[lane] = 0; EW[lane] = 0; }
     uint64_t off = 0, word = 0;
     uint32_t len = 0;
+    const uint64_t abs_max = R.n_bases / 64 + 1;
     if (wave < R.n_reads) {
         read_span(R, wave, off, len);
-        word = stage_fetch<NW>(R, hint, nullptr, 0, 0, off, lane);
+        word = stage_fetch<NW>(R, hint, DEFER ? absent : nullptr, off, abs_max, off, lane);
     }
     for (uint64_t r = wave; r < R.n_reads; r += n_waves) {
         __builtin_amdgcn_wave_barrier();
@@ -285,7 +288,7 @@ __global__ void __launch_bounds__(256, MINW) k_infer(ReadsDev R, KParams K, Filt
         const int Lr = (int)len, nk = Lr - k + 1;
         if (r + n_waves < R.n_reads) {   // the next read's words travel while this one is processed
             read_span(R, r + n_waves, off, len);
-            word = stage_fetch<NW>(R, hint, nullptr, 0, 0, off, lane);
+            word = stage_fetch<NW>(R, hint, DEFER ? absent : nullptr, off, abs_max, off, lane);
         }
         if (nk <= 0) continue;           // engine-defined: the reference underflows size_t here
         // every lane's block and pattern loads (and its quality byte) go out before the first result is needed
@@ -308,10 +311,12 @@ __global__ void __launch_bounds__(256, MINW) k_infer(ReadsDev R, KParams K, Filt
                 if (q[c] < 96 && !(qpresent[q[c] >> 5] & bit)) atomicOr(&qpresent[q[c] >> 5], bit);
             }
             if (c * 64 < nk && s < nk) {
-                const uint64_t key = canon_key(lds_window64(L32 + 2 * St::B, 2 * (o31 + s)), K);
                 valid[c] = (lds_window32(L32 + 2 * St::M, o63 + s) & K.nmask_bits) == 0;
                 known[c] = hint && lds_bit(L32 + 2 * St::H, o63 + s);
-                if (valid[c] && !known[c]) {
+                if (DEFER) {
+                    p[c].x = lds_bit(L32 + 2 * St::X, o63 + s);      // pattern bit the (empty) block lacks = absent
+                } else if (valid[c] && !known[c]) {
+                    const uint64_t key = canon_key(lds_window64(L32 + 2 * St::B, 2 * (o31 + s)), K);
                     t[c] = S.table[block_of(S, key)];
                     p[c] = S.patterns[pattern_of(S, key)];
                 }
