@@ -325,6 +325,254 @@ int FastqReader::next(FastqRecord &rec) {
     return (int)rec.seq.size();
 }
 
+// ------------------------------------------------------------ chunk parser ----
+namespace {
+constexpr size_t kChunkBytes = 32u << 20, kPieceBytes = 2u << 20;
+
+// is `p` (a position right after a newline, or 0) the start of a record as far as two lines can tell?
+// 1 yes, 0 no, -1 the lines are not all inside [p, end)
+int looks_like_record_start(const unsigned char *b, size_t p, size_t end) {
+    if (p >= end) return -1;
+    if (b[p] != '@') return 0;
+    const void *n0 = memchr(b + p, '\n', end - p);
+    if (!n0) return -1;
+    const size_t s = (size_t)((const unsigned char *)n0 - b) + 1;
+    if (s >= end) return -1;
+    const void *n1 = memchr(b + s, '\n', end - s);
+    if (!n1) return -1;
+    const size_t plus = (size_t)((const unsigned char *)n1 - b) + 1;
+    if (plus >= end) return -1;
+    return b[plus] == '+' ? 1 : 0;
+}
+}  // namespace
+
+FastqChunkParser::FastqChunkParser(const std::string &path, int io_threads, int parse_threads, bool keep_records)
+    : src_(open_bytes(path, io_threads)), keep_records_(keep_records) {
+    if (!src_) return;
+    parse_threads = std::max(1, parse_threads);
+    max_in_flight_ = (size_t)parse_threads * 6 + 16;
+    for (int i = 0; i < parse_threads; ++i) pool_.emplace_back(&FastqChunkParser::worker, this);
+    reader_ = std::thread(&FastqChunkParser::reader, this);
+}
+
+FastqChunkParser::~FastqChunkParser() {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        stop_ = true;
+    }
+    cv_todo_.notify_all();
+    cv_room_.notify_all();
+    if (reader_.joinable()) reader_.join();
+    for (auto &t : pool_) t.join();
+}
+
+void FastqChunkParser::submit(std::shared_ptr<Job> job) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_room_.wait(lk, [&] { return stop_ || in_flight_ < max_in_flight_; });
+    if (stop_) return;
+    ++in_flight_;
+    order_.push_back(job);
+    todo_.push_back(job);
+    lk.unlock();
+    cv_todo_.notify_one();
+    cv_done_.notify_all();      // (the consumer may be waiting for a first piece)
+}
+
+void FastqChunkParser::reader() {
+    std::vector<unsigned char> carry;
+    bool eof = false;
+    while (!eof) {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (stop_) break;
+        }
+        auto chunk = std::make_shared<std::vector<unsigned char>>();
+        chunk->resize(carry.size() + kChunkBytes);
+        if (!carry.empty()) memcpy(chunk->data(), carry.data(), carry.size());
+        size_t have = carry.size();
+        carry.clear();
+        bool failed = false;
+        while (have < chunk->size()) {
+            const int got = src_->read(chunk->data() + have, (unsigned)std::min<size_t>(chunk->size() - have, 1u << 30));
+            if (got < 0) failed = true;
+            if (got <= 0) { eof = true; break; }
+            have += (size_t)got;
+        }
+        chunk->resize(have);
+        if (have == 0) break;
+        const unsigned char *b = chunk->data();
+        size_t cut = have;
+        bool whole_complex = failed;      // (a read error: FastqReader decides what the passes see of such a file)
+        if (!eof) {
+            // the last record start whose first three lines are inside the chunk; what follows it waits for the next chunk
+            cut = 0;
+            for (size_t p = have; p > 1;) {
+                const void *nl = memrchr(b, '\n', p - 1);
+                if (!nl) break;
+                const size_t cand = (size_t)((const unsigned char *)nl - b) + 1;
+                if (looks_like_record_start(b, cand, have) == 1) { cut = cand; break; }
+                p = cand;      // continue before this newline
+                if (have - cand > (8u << 20)) break;      // (no record start in the last 8 MB: not the shape this parser is for)
+            }
+            if (cut == 0) whole_complex = true;
+            else carry.assign(b + cut, b + have);
+        }
+        if (whole_complex) {
+            auto job = std::make_shared<Job>();
+            job->force_complex = true;
+            submit(job);
+            break;
+        }
+        // pieces of about kPieceBytes, cut at guessed record starts
+        size_t begin = 0;
+        while (begin < cut) {
+            size_t end = cut;
+            if (cut - begin > kPieceBytes + kPieceBytes / 2) {
+                size_t p = begin + kPieceBytes;
+                for (;;) {
+                    const void *nl = memchr(b + p, '\n', cut - p);
+                    if (!nl) break;
+                    const size_t cand = (size_t)((const unsigned char *)nl - b) + 1;
+                    if (cand >= cut) break;
+                    const int v = looks_like_record_start(b, cand, cut);
+                    if (v == 1) { end = cand; break; }
+                    if (v < 0) break;
+                    p = cand;
+                }
+            }
+            auto job = std::make_shared<Job>();
+            job->chunk = chunk;
+            job->begin = begin;
+            job->end = end;
+            job->last = eof && end == cut;
+            submit(job);
+            begin = end;
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        finished_ = true;
+    }
+    cv_done_.notify_all();
+}
+
+void FastqChunkParser::worker() {
+    for (;;) {
+        std::shared_ptr<Job> job;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_todo_.wait(lk, [&] { return stop_ || !todo_.empty(); });
+            if (stop_) return;
+            job = todo_.front();
+            todo_.pop_front();
+        }
+        parse(*job, keep_records_);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job->done = true;
+        }
+        cv_done_.notify_all();
+    }
+}
+
+void FastqChunkParser::parse(Job &job, bool keep_records) {
+    auto piece = std::make_shared<FastqPiece>();
+    job.piece = piece;
+    FastqPiece &P = *piece;
+    P.off.assign(1, 0);
+    P.blob_off.assign(1, 0);
+    if (job.force_complex) { P.complex = true; return; }
+    const unsigned char *b = job.chunk->data();
+    const size_t end = job.end;
+    const size_t bytes = end - job.begin;
+    P.seq.reserve(bytes / 2);
+    P.qual.reserve(bytes / 2);
+    if (keep_records) P.blob.reserve(bytes * 2 / 3);
+    std::string name, rg, first, last_rg;
+    uint32_t last_rg_index = 0;
+    bool have_last = false;
+    size_t p = job.begin;
+    while (p < end) {
+        if (b[p] != '@') { P.complex = true; return; }
+        const unsigned char *n0 = (const unsigned char *)memchr(b + p, '\n', end - p);
+        if (!n0) { P.complex = true; return; }
+        const size_t h0 = p + 1, h1 = (size_t)(n0 - b);                     // header without '@'
+        const size_t s0 = h1 + 1;
+        if (s0 >= end) { P.complex = true; return; }
+        const unsigned char *n1 = (const unsigned char *)memchr(b + s0, '\n', end - s0);
+        if (!n1) { P.complex = true; return; }
+        const size_t s1 = (size_t)(n1 - b);                                  // sequence [s0, s1)
+        const size_t plus = s1 + 1;
+        if (plus >= end || b[plus] != '+') { P.complex = true; return; }
+        const unsigned char *n2 = (const unsigned char *)memchr(b + plus, '\n', end - plus);
+        if (!n2) { P.complex = true; return; }
+        const size_t q0 = (size_t)(n2 - b) + 1;
+        const unsigned char *n3 = q0 < end ? (const unsigned char *)memchr(b + q0, '\n', end - q0) : nullptr;
+        if (!n3 && !job.last) { P.complex = true; return; }
+        const size_t q1 = n3 ? (size_t)(n3 - b) : end;                       // quality [q0, q1)
+        const size_t sl = s1 - s0;
+        if (sl == 0 || q1 - q0 != sl || q0 > end) { P.complex = true; return; }
+        const unsigned char c0 = b[s0];
+        if (c0 == '+' || c0 == '@' || c0 == '>') { P.complex = true; return; }
+        if ((h1 > h0 && b[h1 - 1] == '\r') || b[s1 - 1] == '\r' || b[q1 - 1] == '\r' || b[q0 - 2] == '\r') { P.complex = true; return; }
+        // name = up to the first blank or tab, comment = the rest of the line (FastqReader::next)
+        size_t blank = h0;
+        while (blank < h1 && b[blank] != ' ' && b[blank] != '\t') ++blank;
+        name.assign((const char *)b + h0, blank - h0);
+        bool second = false;
+        if (!parse_read_name(name, rg, second, first)) {
+            P.fatal_at = (long)P.n();
+            P.fatal_name = name;
+            return;
+        }
+        if (!have_last || rg != last_rg) {
+            size_t i = 0;
+            while (i < P.rg_names.size() && P.rg_names[i] != rg) ++i;
+            if (i == P.rg_names.size()) P.rg_names.push_back(rg);
+            last_rg = rg;
+            last_rg_index = (uint32_t)i;
+            have_last = true;
+        }
+        P.rg.push_back(last_rg_index);
+        P.second.push_back(second ? 1 : 0);
+        P.seq.insert(P.seq.end(), b + s0, b + s1);
+        const size_t qa = P.qual.size();
+        P.qual.resize(qa + sl);
+        for (size_t i = 0; i < sl; ++i) P.qual[qa + i] = (uint8_t)(b[q0 + i] - 33);
+        P.off.push_back(P.seq.size());
+        P.longest = std::max(P.longest, sl);
+        if (keep_records) {
+            const size_t cl = blank < h1 ? h1 - blank - 1 : 0;
+            P.blob.append((const char *)b + h0, blank - h0);
+            if (cl) P.blob.append((const char *)b + blank + 1, cl);
+            P.blob.append((const char *)b + s0, sl);
+            P.lens.push_back((uint32_t)(blank - h0));
+            P.lens.push_back((uint32_t)cl);
+            P.lens.push_back((uint32_t)sl);
+            P.blob_off.push_back(P.blob.size());
+        }
+        p = n3 ? q1 + 1 : end;
+    }
+    // (p == end: the piece ended exactly where the next one starts, which proves that cut)
+}
+
+std::shared_ptr<FastqPiece> FastqChunkParser::next() {
+    if (!src_ || ended_) return nullptr;
+    std::shared_ptr<Job> job;
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] { return !order_.empty() || finished_; });
+        if (order_.empty()) { ended_ = true; return nullptr; }
+        job = order_.front();
+        cv_done_.wait(lk, [&] { return job->done; });
+        order_.pop_front();
+        --in_flight_;
+    }
+    cv_room_.notify_one();
+    if (job->piece->complex || job->piece->fatal_at >= 0) ended_ = true;
+    return job->piece;
+}
+
 // -------------------------------------------------------------- read names ----
 bool parse_read_name(const std::string &name, std::string &rg, bool &second, std::string &first_name) {
     std::string fullname(name);

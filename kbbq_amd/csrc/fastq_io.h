@@ -57,6 +57,62 @@ private:
     bool eof_ = false;
 };
 
+// ---- block-parallel FASTQ parse ---------------------------------------------------------------------------------
+// The usual FASTQ file is a run of strictly four-line records ("@header\nSEQ\n+...\nQUAL\n", |SEQ| = |QUAL| > 0,
+// no carriage returns, nothing between records).  For such a stream the work of FastqReader + parse_read_name can be
+// done by a pool: a reader thread cuts the decompressed bytes into pieces at record starts, workers parse the pieces,
+// the consumer gets them back in file order.  A cut is a GUESS ("\n@" whose line after next starts with '+'); it is
+// proved by the piece before it, whose strict parse -- started at a proven record start -- must end exactly there.
+// Anything that is not strictly of that shape (multi-line records, FASTA records, empty reads, '\r', blank lines, a
+// truncated tail) marks the piece `complex`: the caller then starts over with FastqReader, which is the definition.
+struct FastqPiece {
+    std::vector<uint8_t> seq, qual;        // bases as text, qualities minus 33 (readutils.cc:70-71), concatenated
+    std::vector<uint64_t> off;             // n + 1 offsets into seq / qual
+    std::vector<uint8_t> second;           // per read: second in pair (parse_read_name)
+    std::vector<std::string> rg_names;     // read groups in order of first appearance in this piece
+    std::vector<uint32_t> rg;              // per read: index into rg_names
+    std::string blob;                      // name, comment, sequence text of every record, back to back
+    std::vector<uint32_t> lens;            // three lengths per record
+    std::vector<uint64_t> blob_off;        // n + 1 offsets into blob
+    size_t longest = 0;
+    bool complex = false;
+    long fatal_at = -1;                    // parse_read_name failed on this record (std::out_of_range in the reference)
+    std::string fatal_name;
+    size_t n() const { return off.empty() ? 0 : off.size() - 1; }
+};
+
+class FastqChunkParser {
+public:
+    FastqChunkParser(const std::string &path, int io_threads, int parse_threads, bool keep_records);
+    ~FastqChunkParser();
+    bool ok() const { return src_ != nullptr; }
+    // the next piece in file order; null at the end of the stream (and after a complex piece has been handed out)
+    std::shared_ptr<FastqPiece> next();
+
+private:
+    struct Job {
+        std::shared_ptr<std::vector<unsigned char>> chunk;
+        size_t begin = 0, end = 0;
+        bool last = false;                 // the stream ends with this piece (its last line may lack the newline)
+        bool force_complex = false;
+        std::shared_ptr<FastqPiece> piece;
+        bool done = false;
+    };
+    void reader();
+    void worker();
+    void submit(std::shared_ptr<Job> job);
+    static void parse(Job &job, bool keep_records);
+    std::unique_ptr<ByteSource> src_;
+    bool keep_records_;
+    std::vector<std::thread> pool_;
+    std::deque<std::shared_ptr<Job>> order_, todo_;      // guarded by mu_
+    std::mutex mu_;
+    std::condition_variable cv_todo_, cv_done_, cv_room_;
+    size_t in_flight_ = 0, max_in_flight_ = 64;
+    bool stop_ = false, finished_ = false, ended_ = false;
+    std::thread reader_;                   // last member: starts when everything above exists
+};
+
 // The dense read-group index in order of first appearance (CReadData::rg_to_int, readutils.cc:10-11,100-103).
 class ReadGroups {
 public:

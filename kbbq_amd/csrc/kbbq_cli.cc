@@ -198,6 +198,23 @@ static std::unique_ptr<Source> open_source(const std::string &path, bool is_bam,
     return std::unique_ptr<Source>(new FastqSource(path, g_io_threads));
 }
 
+// What the output pass needs of one batch besides the new qualities, kept from the first scan when it fits in
+// host memory, so that the input is decoded once instead of twice: FASTQ name / comment / sequence text, or
+// the BAM alignment blocks.
+struct RecordStore {
+    std::string blob;
+    std::vector<uint32_t> lens;     // FASTQ: name, comment, sequence length per record; BAM: block length
+    size_t bytes() const { return blob.capacity() + lens.capacity() * 4; }
+    void add(const FastqRecord &r) {
+        blob += r.name; blob += r.comment; blob += r.seq;
+        lens.push_back((uint32_t)r.name.size()); lens.push_back((uint32_t)r.comment.size()); lens.push_back((uint32_t)r.seq.size());
+    }
+    void add(const BamRecord &r) {
+        blob.append((const char *)r.data.data(), r.data.size());
+        lens.push_back((uint32_t)r.data.size());
+    }
+};
+
 // One batch of reads in the engine's layout, plus the records themselves for the output pass.
 struct Batch {
     std::vector<FastqRecord> fq_recs;
@@ -236,6 +253,61 @@ struct Batch {
                 if (is_bam) bam_recs.push_back(it.bam); else fq_recs.push_back(it.fq);
             }
         }
+        return finish();
+    }
+
+    // The same batch from the block-parallel parser (fastq_io.h: FastqChunkParser), strictly four-line FASTQ only.
+    // Returns false when no read was collected; `complex` says the stream is not of that shape and the scan has to
+    // start over with the serial reader.  The records go straight into `store` (when given).
+    struct Fast {
+        std::unique_ptr<FastqChunkParser> parser;
+        std::shared_ptr<FastqPiece> cur;
+        size_t at = 0;
+        std::vector<int> rg_map;
+        bool complex = false;
+    };
+    bool fill_fast(Fast &f, ReadGroups &groups, size_t max_reads, RecordStore *store) {
+        fq_recs.clear(); bam_recs.clear(); seq.clear(); qual.clear(); flags.clear(); rg.clear();
+        off.assign(1, 0);
+        saw_empty = false;
+        longest = 0;
+        while (rg.size() < max_reads) {
+            if (f.cur && f.at == f.cur->n() && f.cur->fatal_at >= 0) {      // (the piece's parse stopped at that record)
+                std::cerr << put_now << " Error: read name '" << f.cur->fatal_name << "' is shorter than 2 characters before the first '_'." << std::endl;
+                fatal = true;
+                return false;
+            }
+            if (!f.cur || f.at == f.cur->n()) {
+                f.cur = f.parser->next();
+                f.at = 0;
+                if (!f.cur) break;
+                if (f.cur->complex) { f.complex = true; return false; }
+                f.rg_map.clear();
+                for (auto &name : f.cur->rg_names) f.rg_map.push_back(groups.index_of(name));
+                continue;
+            }
+            const FastqPiece &P = *f.cur;
+            const size_t take = std::min(P.n() - f.at, max_reads - rg.size());
+            const size_t a = f.at, b = f.at + take;
+            const uint64_t base = seq.size() - P.off[a];
+            seq.insert(seq.end(), P.seq.begin() + P.off[a], P.seq.begin() + P.off[b]);
+            qual.insert(qual.end(), P.qual.begin() + P.off[a], P.qual.begin() + P.off[b]);
+            for (size_t r = a; r < b; ++r) {
+                off.push_back(base + P.off[r + 1]);
+                longest = std::max<size_t>(longest, P.off[r + 1] - P.off[r]);
+                rg.push_back((uint16_t)f.rg_map[P.rg[r]]);
+            }
+            flags.insert(flags.end(), P.second.begin() + a, P.second.begin() + b);
+            if (store) {
+                store->blob.append(P.blob, P.blob_off[a], P.blob_off[b] - P.blob_off[a]);
+                store->lens.insert(store->lens.end(), P.lens.begin() + 3 * a, P.lens.begin() + 3 * b);
+            }
+            f.at = b;
+        }
+        return finish();
+    }
+
+    bool finish() {
         if (rg.empty()) return false;
         bases.assign(seq.size() / 32 + 2, 0);
         nmask.assign(seq.size() / 64 + 2, 0);
@@ -265,23 +337,6 @@ struct Batch {
             c.read_len = (uint32_t)longest;
         }
         return true;
-    }
-};
-
-// What the output pass needs of one batch besides the new qualities, kept from the first scan when it fits in
-// host memory, so that the input is decoded once instead of twice: FASTQ name / comment / sequence text, or
-// the BAM alignment blocks.
-struct RecordStore {
-    std::string blob;
-    std::vector<uint32_t> lens;     // FASTQ: name, comment, sequence length per record; BAM: block length
-    size_t bytes() const { return blob.capacity() + lens.capacity() * 4; }
-    void add(const FastqRecord &r) {
-        blob += r.name; blob += r.comment; blob += r.seq;
-        lens.push_back((uint32_t)r.name.size()); lens.push_back((uint32_t)r.comment.size()); lens.push_back((uint32_t)r.seq.size());
-    }
-    void add(const BamRecord &r) {
-        blob.append((const char *)r.data.data(), r.data.size());
-        lens.push_back((uint32_t)r.data.size());
     }
 };
 
@@ -316,6 +371,35 @@ static int io_test(int argc, char *argv[]) {
                    (int)second, first.c_str(), r.seq.c_str(), r.qual.c_str());
         }
         printf("#end %d\n", rc);
+        return 0;
+    }
+    if (what == "parse-fast" && argc > 3) {     // the block-parallel parser on the same file, same lines; "#complex" = not its shape
+        FastqChunkParser in(argv[3], std::max(2, io_threads), argc > 4 ? atoi(argv[4]) : 4, true);
+        if (!in.ok()) return 2;
+        ReadGroups groups;
+        while (auto piece = in.next()) {
+            const FastqPiece &P = *piece;
+            if (P.complex) { printf("#complex\n"); return 0; }
+            std::vector<int> map;
+            for (auto &n : P.rg_names) map.push_back(groups.index_of(n));
+            for (size_t r = 0; r < P.n(); ++r) {
+                const char *b = P.blob.data() + P.blob_off[r];
+                const uint32_t nl = P.lens[3 * r], cl = P.lens[3 * r + 1], sl = P.lens[3 * r + 2];
+                const std::string name(b, nl), comment(b + nl, cl), seq(b + nl + cl, sl);
+                std::string rg, first, q(sl, ' ');
+                bool second = false;
+                parse_read_name(name, rg, second, first);
+                for (uint32_t i = 0; i < sl; ++i) q[i] = (char)(P.qual[P.off[r] + i] + 33);
+                if (seq != std::string((const char *)P.seq.data() + P.off[r], sl) || rg != P.rg_names[P.rg[r]] || second != (P.second[r] != 0)) return 3;
+                printf("%s\t%s\t%s\t%d\t%d\t%s\t%s\t%s\n", name.c_str(), comment.c_str(), rg.c_str(), map[P.rg[r]], (int)second, first.c_str(),
+                       seq.c_str(), q.c_str());
+            }
+            if (P.fatal_at >= 0) {
+                printf("%s\t%s\t%s\t%d\n", P.fatal_name.c_str(), "?", "!", -1);
+                break;
+            }
+        }
+        printf("#end -1\n");
         return 0;
     }
     if (what == "bam" && argc > 3) {     // what the passes see of a BAM: --io-test bam FILE [use-oq]
@@ -455,23 +539,50 @@ int main(int argc, char *argv[]) {
         }
     } resident;
     const bool fixed_mode = !fixedinput.empty();
-    {
+    auto init_resident = [&]() {
+        resident.on = true;
+        resident.keep_recs = true;
+        resident.bytes = resident.rec_bytes = 0;
         const char *env = getenv("KBBQ_RESIDENT");
         uint64_t free_b = 0, total_b = 0;
         if ((env && !strcmp(env, "0")) || fixed_mode || kbbq_device_memory(-1, &free_b, &total_b) < 0) resident.on = false;
         resident.budget = (uint64_t)(0.6 * (double)free_b);
         resident.rec_budget = host_cache_budget();
         if (!resident.on || !resident.rec_budget) resident.keep_recs = false;
-    }
-    {
-        std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
-        if (!in->ok()) {
-            std::cerr << put_now << " Error opening file " << filename << std::endl;
-            return 1;
+    };
+    init_resident();
+    // FASTQ input is parsed by a pool when it is strictly four-line (fastq_io.h: FastqChunkParser); anything else -- found
+    // out while parsing -- starts the scan over with the serial reader.  KBBQ_SERIAL_PARSE=1: the serial reader at once.
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool fast = attempt == 0 && !is_bam && g_io_threads > 1 && !(getenv("KBBQ_SERIAL_PARSE") && atoi(getenv("KBBQ_SERIAL_PARSE")));
+        if (attempt == 1) {
+            groups = ReadGroups();
+            seqlen = n_reads = 0;
+            longest = 0;
+            resident.drop();
+            init_resident();
         }
-        if (is_bam) bam_header = static_cast<BamSource *>(in.get())->header();
+        std::unique_ptr<Source> in;
+        Batch::Fast ff;
+        if (fast) {
+            ff.parser.reset(new FastqChunkParser(filename, g_io_threads, out_threads, resident.on && resident.keep_recs));
+            if (!ff.parser->ok()) {
+                std::cerr << put_now << " Error opening file " << filename << std::endl;
+                return 1;
+            }
+        } else {
+            in = open_source(filename, is_bam, use_oq);
+            if (!in->ok()) {
+                std::cerr << put_now << " Error opening file " << filename << std::endl;
+                return 1;
+            }
+            if (is_bam) bam_header = static_cast<BamSource *>(in.get())->header();
+        }
         bool counting = true;    // the coverage pass stops at the first empty read; the other passes do not
-        while (batch.fill(*in, groups, batch_reads, resident.on && resident.keep_recs, is_bam)) {
+        for (;;) {
+            const bool keep = resident.on && resident.keep_recs;
+            RecordStore st;
+            if (!(fast ? batch.fill_fast(ff, groups, batch_reads, keep ? &st : nullptr) : batch.fill(*in, groups, batch_reads, keep, is_bam))) break;
             for (size_t r = 0; r < batch.c.n_reads && counting; ++r) {
                 const uint64_t l = batch.off[r + 1] - batch.off[r];
                 if (l == 0) counting = false; else seqlen += l;
@@ -494,16 +605,19 @@ int main(int argc, char *argv[]) {
                 }
             }
             if (resident.on && resident.keep_recs) {
-                RecordStore st;
-                st.lens.reserve(batch.c.n_reads * (is_bam ? 1 : 3));
-                if (is_bam) for (auto &b : batch.bam_recs) st.add(b);
-                else for (auto &f : batch.fq_recs) st.add(f);
+                if (!fast) {
+                    st.lens.reserve(batch.c.n_reads * (is_bam ? 1 : 3));
+                    if (is_bam) for (auto &b : batch.bam_recs) st.add(b);
+                    else for (auto &f : batch.fq_recs) st.add(f);
+                }
                 resident.rec_bytes += st.bytes();
                 if (resident.rec_bytes > resident.rec_budget) resident.drop_recs();
                 else resident.recs.push_back(std::move(st));
             }
         }
         if (batch.fatal) return 1;
+        if (fast && ff.complex) continue;
+        break;
     }
     if (longest > KBBQ_MAX_READ_LEN) {
         std::cerr << put_now << " Error: reads longer than " << KBBQ_MAX_READ_LEN << " bases are not supported by the GPU engine." << std::endl;

@@ -384,3 +384,31 @@ def test_cli_output_does_not_depend_on_the_batch_size(tmp_path):
         rc, out, err = run_cli(["--set-oq", path], dict(env, KBBQ_SEED="7"))
         assert rc == 0, err
         assert bamutil.bgzf_decompress(out) == one_b, env
+
+
+def test_cli_block_parallel_and_serial_fastq_parse_agree(tmp_path):
+    """The first scan parses strictly four-line FASTQ with a pool (fastq_io.h: FastqChunkParser) and starts over with the
+    serial reader when the file turns out not to be of that shape: same bytes out either way, for a plain file, a
+    gzip-ed one, small batches, and a file whose LAST record is multi-line (the restart happens at the very end)."""
+    d, names, n_rg = named_dataset(seed=515, genome_len=20000, coverage=24, n_per_million=2000, ragged=True, mid_reads=60, extra_errors=80)
+    comments = ["c%d" % r if r % 4 == 0 else "" for r in range(len(names))]
+    fq, gz = tmp_path / "in.fq", tmp_path / "in.fq.gz"
+    write_fastq(fq, d, names, comments)
+    write_fastq(gz, d, names, comments)
+    rc, want, err = run_cli(["-g", d["genome_len"], fq], {"KBBQ_SEED": "12", "KBBQ_SERIAL_PARSE": "1"})
+    assert rc == 0, err
+    want = gzip.decompress(want)
+    for path, env in ((fq, {}), (gz, {}), (gz, {"KBBQ_BATCH_READS": "333"}), (fq, {"KBBQ_HOST_CACHE_MB": "0"})):
+        rc, out, err = run_cli(["-g", d["genome_len"], path], dict(env, KBBQ_SEED="12"))
+        assert rc == 0, err
+        assert gzip.decompress(out) == want, (path, env)
+    # the same records, the last one written over two sequence and two quality lines
+    text = fq.read_bytes().decode().split("\n")
+    assert text[-1] == "" and len(text[-4]) > 3
+    s, q = text[-4], text[-2]
+    multi = "\n".join(text[:-4] + [s[:2], s[2:], "+", q[:2], q[2:], ""])
+    ml = tmp_path / "multi.fq"
+    ml.write_text(multi)
+    rc, out, err = run_cli(["-g", d["genome_len"], ml], {"KBBQ_SEED": "12"})
+    assert rc == 0, err
+    assert gzip.decompress(out) == want

@@ -146,3 +146,82 @@ def test_bgzf_level_knob_changes_size_not_content(tmp_path):
         assert gzip.decompress(out) == payload
         sizes[level] = len(out)
     assert sizes["1"] > sizes[""] >= sizes["9"] and sizes["bogus"] == sizes[""]     # default = zlib's default level, like the reference
+
+
+# ---- the block-parallel FASTQ parser (FastqChunkParser): equal to the serial reader on strictly four-line input, "#complex" otherwise
+
+def parse_fast(path, threads=4, io_threads=3):
+    out = subprocess.run([CLI, "--io-test", "parse-fast", str(path), str(threads)], capture_output=True, text=True, check=True,
+                         env=dict(os.environ, KBBQ_IO_THREADS=str(io_threads))).stdout
+    return out
+
+
+def serial_text(path):
+    return subprocess.run([CLI, "--io-test", "parse", str(path)], capture_output=True, text=True, check=True).stdout
+
+
+def _strict_fastq(n, seed, read_len=151, ragged=False, tricky_quals=True):
+    rng = np.random.RandomState(seed)
+    recs = []
+    for i in range(n):
+        ln = int(rng.randint(1, 2 * read_len)) if ragged else read_len
+        seq = "".join(rng.choice(list("ACGTNacgtn"), ln))
+        q = [chr(c) for c in rng.randint(33, 75, ln)]
+        if tricky_quals and i % 7 == 0:
+            q[0] = "@"                      # a quality line that starts like a header
+        if tricky_quals and i % 11 == 0:
+            q[0] = "+"
+        name = "r%d/%d_RG:Z:g%d" % (i, 1 + i % 2, (i // 50) % 4) if i % 13 else "x%d" % i
+        comment = ("\tafter a tab" if i % 5 == 0 else " c%d with blanks" % i) if i % 3 else ""
+        plus = "+" + (name if i % 17 == 0 else "")
+        recs.append("@%s%s\n%s\n%s\n%s\n" % (name, comment, seq, plus, "".join(q)))
+    return "".join(recs)
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_fast_parser_equals_the_serial_reader(tmp_path, ragged):
+    import bamutil
+    text = _strict_fastq(60000, 21 + ragged, ragged=ragged)      # ~19 MB: several pieces; with the 32 MB chunks one chunk
+    plain, gz, bg = tmp_path / "a.fq", tmp_path / "a.fq.gz", tmp_path / "a.fq.bgz"
+    plain.write_text(text)
+    with gzip.open(gz, "wt", compresslevel=1) as fh:
+        fh.write(text)
+    bg.write_bytes(bamutil.bgzf_compress(text.encode(), ragged_seed=4))
+    want = serial_text(plain)
+    assert want.count("\n") == 60001
+    for path in (plain, gz, bg):
+        for threads in (1, 5):
+            assert parse_fast(path, threads) == want
+
+
+def test_fast_parser_across_chunks_and_without_final_newline(tmp_path):
+    text = _strict_fastq(240000, 5, read_len=100)[:-1]      # ~52 MB: two chunk boundaries; the last line has no newline
+    p = tmp_path / "b.fq"
+    p.write_text(text)
+    assert parse_fast(p, 6) == serial_text(p)
+
+
+@pytest.mark.parametrize("text", [
+    "@r1 c\nACGT\nNNAC\n+\nIIII\n!!#I\n@r2\nAC\n+\nII\n",          # multi-line record
+    "@r1\nACGT\n+\nIIII\n\n@r2\nAC\n+\nII\n",                      # blank line between records
+    "@r1\nACGT\r\n+\r\nIIII\r\n",                                  # carriage returns
+    "@r1\n\n+\n\n@r2\nAC\n+\nII\n",                                # empty read
+    ">fa1\nACGT\n@r2\nAC\n+\nII\n",                                # FASTA record first
+    "@r1\nACGT\n+\nIII\n",                                         # truncated quality
+    "junk\n@r1\nACGT\n+\nIIII\n",                                  # bytes before the first record
+    "@r1\nACGT\n+\nIIII\n@r2\nAC\n",                               # file ends inside a record
+])
+def test_fast_parser_declines_what_is_not_strict_four_line_fastq(tmp_path, text):
+    p = tmp_path / "c.fq"
+    p.write_text(text)
+    out = parse_fast(p, 2)
+    assert out.endswith("#complex\n"), out
+
+
+def test_fast_parser_empty_file_and_fatal_name(tmp_path):
+    p = tmp_path / "e.fq"
+    p.write_text("")
+    assert parse_fast(p) == "#end -1\n" == serial_text(p)
+    p.write_text("@ab_x\nAC\n+\nII\n@a_RG:Z:q\nAC\n+\nII\n@cd\nAC\n+\nII\n")     # second name is shorter than two characters
+    out = parse_fast(p).split("\n")
+    assert out[0].split("\t")[0] == "ab_x" and out[1].split("\t")[:3] == ["a_RG:Z:q", "?", "!"] and out[2] == "#end -1"
