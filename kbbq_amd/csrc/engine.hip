@@ -154,6 +154,7 @@ struct kbbq_engine {
         // whole insert side of the pass (emit, split, apply) runs beside the next batches' k_infer
         hipStream_t stream[2] = {nullptr, nullptr};
         hipEvent_t ev_flush = nullptr;       // a flush on the side stream has finished (pass boundaries wait for it)
+        bool flush_on_main = false;          // emits on the side stream, split + apply on the engine's (KBBQ_PASS2_SIDE=2)
         // the learnt estimate is read back without stopping either stream: copy into page-locked memory + event
         unsigned long long *h_inserted = nullptr;
         hipEvent_t ev_est = nullptr;
@@ -570,7 +571,15 @@ int bucket_flush(kbbq_engine *e, int w, bool barrier = true) {
     if (!b.pending[w]) return KBBQ_OK;
     const BucketDev B = bucket_dev(e, w);
     const FiltDev F = e->filt[w].dev();
-    hipStream_t st = bucket_stream(e, w);
+    const hipStream_t emit_st = bucket_stream(e, w);
+    // split + apply where the emits ran, or -- pass 2 with only the emits on the side stream -- on the engine's stream
+    // once the emits are through (and the side stream's later emits wait for the flush in turn)
+    const bool hop = w == 1 && b.flush_on_main && emit_st != e->stream;
+    hipStream_t st = hop ? e->stream : emit_st;
+    if (hop) {
+        HIP_TRY(hipEventRecord(b.ev_flush, emit_st));
+        HIP_TRY(hipStreamWaitEvent(st, b.ev_flush, 0));
+    }
     HIP_TRY(hipMemsetAsync(b.tickets, 0, kTicketBytes, st));
     {
         Timed t(e, w ? "k_split_trusted" : "k_split_sampled", st);
@@ -585,7 +594,10 @@ int bucket_flush(kbbq_engine *e, int w, bool barrier = true) {
     }
     HIP_TRY(hipMemsetAsync(b.l1_cnt, 0, kL1CntBytes, st));
     HIP_TRY(hipMemsetAsync(b.l2_cnt, 0, (size_t)B.nb1 * NB2 * 4, st));
-    if (st != e->stream && barrier) {
+    if (hop) {
+        HIP_TRY(hipEventRecord(b.ev_flush, st));
+        HIP_TRY(hipStreamWaitEvent(emit_st, b.ev_flush, 0));
+    } else if (st != e->stream && barrier) {
         HIP_TRY(hipEventRecord(b.ev_flush, st));
         HIP_TRY(hipStreamWaitEvent(e->stream, b.ev_flush, 0));
     }
@@ -1515,9 +1527,10 @@ template <int NW> struct LaunchTrusted {
             // Off by default: measured +2.4 % on the 30x workload (profiles/r02_bench_full_i_{side,noside}.json) -- the side
             // kernels mostly take turns with k_infer's waves rather than run beside them -- at the price of kernel durations
             // that are no longer exclusive in pass 2 (k_infer is the kernel the roofline is quoted for).  KBBQ_PASS2_SIDE=1.
-            static const bool want_side = getenv("KBBQ_PASS2_SIDE") && atoi(getenv("KBBQ_PASS2_SIDE")) != 0 && !getenv("KBBQ_NO_OVERLAP");
-            const bool side = want_side;
+            static const int side_mode = getenv("KBBQ_PASS2_SIDE") && !getenv("KBBQ_NO_OVERLAP") ? atoi(getenv("KBBQ_PASS2_SIDE")) : 0;
+            const bool side = side_mode != 0;      // 1: emit, split, apply on the side stream; 2: the emits only
             e->bk.stream[1] = side ? e->stream2 : e->stream;
+            e->bk.flush_on_main = side_mode == 2;
             if (side) {
                 HIP_TRY(hipEventRecord(e->ev_infer, e->stream));
                 HIP_TRY(hipStreamWaitEvent(e->stream2, e->ev_infer, 0));

@@ -1,9 +1,13 @@
 #!/bin/bash
+# randomised differential runs (tests/fuzz_parity.py) on the GPU; KBBQ_BUCKET=1 sends the small filters of these cases
+# through the slice-bucketed insert path (emit / split / apply) as well
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
-timeout -k 10 500 python -u -m pytest tests/test_bucket_gpu.py tests/test_fuzz_gpu.py -x -q 2>&1 | tail -5 || exit 1
 cd tests
-for seed in 11 12 13; do
-  timeout -k 10 700 python -u fuzz_parity.py 150 $seed > $R/gpurun_out/r02_fuzz_$seed.log 2>&1; echo "seed $seed rc $? $(tail -1 $R/gpurun_out/r02_fuzz_$seed.log)"
+for seed in ${SEEDS:-21 22}; do
+  KBBQ_BUCKET=1 timeout -k 10 700 python -u fuzz_parity.py 150 $seed > $R/gpurun_out/r02_fuzz_bucket_$seed.log 2>&1; echo "bucketed seed $seed rc $? $(tail -1 $R/gpurun_out/r02_fuzz_bucket_$seed.log)"
+done
+for seed in ${SEEDS2:-23}; do
+  timeout -k 10 700 python -u fuzz_parity.py 150 $seed > $R/gpurun_out/r02_fuzz_$seed.log 2>&1; echo "direct seed $seed rc $? $(tail -1 $R/gpurun_out/r02_fuzz_$seed.log)"
 done
