@@ -298,8 +298,12 @@ typedef struct kbbq_profile_entry {
 } kbbq_profile_entry;
 int kbbq_profile_get(kbbq_engine *e, kbbq_profile_entry *out, int32_t max_entries, int32_t *n_out);
 int kbbq_profile_reset(kbbq_engine *e);
-/* Counters of the last pass-3 work: reads sent to the correction kernel, Bloom
- * queries issued there. */
+/* Counters: [0] reads sent to the correction kernel and [1] Bloom queries issued there (pass 3), [2] reads of pass 3,
+ * [3] Bloom blocks fetched by pass 2, [4],[5] flushes of the slice-bucketed inserts per filter, [6] records inserted
+ * directly because a region was full, [7] records gathered per flush, [8] 1 when pass 2 or pass 4 met a quality above
+ * KBBQ_MAXQ = 93 (the reference indexes past its tables for such a base, covariateutils.hh:3, readutils.cc:578-580;
+ * the engine neither tallies nor recalibrates it and clamps it to 93 on output, as the final clamp of
+ * readutils.cc:592-594 would).  Writes min(n, 9) values. */
 int kbbq_stats_get(kbbq_engine *e, uint64_t *out, int32_t n);
 
 /* ---- host-only entry points (no GPU touched) --------------------------------

@@ -2049,7 +2049,7 @@ static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qu
         }
         const unsigned blocks = (unsigned)std::min<uint64_t>((lanes + 1023) / 1024, lds > 76 * 1024 ? 256 : 256 * 2);
         hipLaunchKernelGGL(k_recalibrate, dim3(blocks), dim3(1024), lds, e->stream,
-                           R, D, d_out, 6, vec_ok, lds_rgs, read_index);
+                           R, D, d_out, 6, vec_ok, lds_rgs, read_index, e->d_qpresent + 3);
         HIP_TRY(hipGetLastError());
     }
     if (out_on_host) {
@@ -2160,6 +2160,13 @@ int kbbq_stats_get(kbbq_engine *e, uint64_t *out, int32_t n) {
     if (e->bk.allocated && n > 6) HIP_TRY(hipMemcpy(&direct, e->bk.direct, 8, hipMemcpyDeviceToHost));
     const uint64_t extra[4] = {e->bk.flushes[0], e->bk.flushes[1], direct, e->bk.allocated ? e->bk.capacity : 0};
     for (int i = 4; i < n && i < 8; ++i) out[i] = extra[i - 4];
+    // [8] 1 when pass 2 or pass 4 met a quality above KBBQ_MAXQ (93): the reference indexes past its tables there;
+    // the engine neither tallies nor recalibrates such a base and clamps it to 93 on output
+    if (n > 8) {
+        uint32_t flag = 0;
+        HIP_TRY(hipMemcpy(&flag, e->d_qpresent + 3, 4, hipMemcpyDeviceToHost));
+        out[8] = flag & 1u;
+    }
     return KBBQ_OK;
 }
 

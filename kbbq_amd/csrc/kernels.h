@@ -309,6 +309,7 @@ __global__ void __launch_bounds__(256, MINW) k_infer(ReadsDev R, KParams K, Filt
                 // bits, looked at before the atomic
                 const uint32_t bit = 1u << (q[c] & 31);
                 if (q[c] < 96 && !(qpresent[q[c] >> 5] & bit)) atomicOr(&qpresent[q[c] >> 5], bit);
+                if (q[c] >= KBBQ_NQ && !(qpresent[3] & 1u)) atomicOr(&qpresent[3], 1u);      // outside the model's range (kbbq_stats_get [8])
             }
             if (c * 64 < nk && s < nk) {
                 valid[c] = (lds_window32(L32 + 2 * St::M, o63 + s) & K.nmask_bits) == 0;
@@ -1132,7 +1133,7 @@ struct DqDev {
 };
 
 __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8_t *out, int minqual, int vec_ok, int lds_rgs,
-                                                       const uint32_t *read_index) {
+                                                       const uint32_t *read_index, uint32_t *qflag) {
     // The delta-Q tables of the first `lds_rgs` read groups sit in LDS, compacted over the quality axis: only the
     // D.n_slots quality values that have a non-zero cycle or dinucleotide delta anywhere get a slot (D.qslot; a
     // handful for binned qualities, so a dozen read groups fit), holding per (slot, second, cycle) one int16 with
@@ -1203,6 +1204,7 @@ __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8
         end2 = R.offsets ? R.offsets[r + 2] : end + R.read_len;
     }
     const int c0 = (int)(g0 - start);
+    int beyond = 0;      // a quality above KBBQ_MAXQ: the reference indexes past its tables there; the engine clamps it and says so (qflag)
     const bool plain = n == 16 && rg < lds_rgs && rg2 < lds_rgs && (bpos == 16 || (r + 1 < R.n_reads && end2 >= g0 + 16)) &&
                        c0 + bpos <= D.n_cycle && 16 - bpos <= D.n_cycle;
     if (plain) {
@@ -1219,6 +1221,7 @@ __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8
             const int b = (int)((bw >> (2 * i)) & 3), nn = (int)((nw >> i) & 1);
             const int q = qv[i];
             int v = q;
+            beyond |= q >= KBBQ_NQ;
             if (q >= minqual && q < KBBQ_NQ) {
                 const int sl = l_qslot[q];
                 if (sl != 255) {
@@ -1249,6 +1252,7 @@ __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8
         const int b = (int)((bw >> (2 * i)) & 3), nn = (int)((nw >> i) & 1);
         const int q = qv[i];
         int v = q;
+        beyond |= i < n && q >= KBBQ_NQ;
         if (i < n && q >= minqual && q < KBBQ_NQ && rg < D.n_rg && cyc < D.n_cycle) {
             const int cell = rg * KBBQ_NQ + q;
             const bool use_di = cyc > 0 && !nn && !prev_n;
@@ -1278,6 +1282,7 @@ __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8
     } else {
         for (int i = 0; i < n; ++i) out[g0 + i] = res[i];
     }
+    if (beyond && !(*qflag & 1u)) atomicOr(qflag, 1u);
     }
 }
 

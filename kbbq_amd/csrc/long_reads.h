@@ -119,6 +119,7 @@ __global__ void __launch_bounds__(256) k_infer_long(ReadsDev R, KParams K, FiltD
                     q[c] = R.qual[woff + s];
                     const uint32_t bit = 1u << (q[c] & 31);
                     if (q[c] < 96 && !(qpresent[q[c] >> 5] & bit)) atomicOr(&qpresent[q[c] >> 5], bit);
+                    if (q[c] >= KBBQ_NQ && !(qpresent[3] & 1u)) atomicOr(&qpresent[3], 1u);
                 }
                 bool valid = false, present = false;
                 if (c * 64 < wnk && s < wnk) {

@@ -302,10 +302,11 @@ class Engine:
         _lib.check(self.L.kbbq_profile_reset(self.h))
 
     def stats(self):
-        out = (ctypes.c_uint64 * 8)()
-        _lib.check(self.L.kbbq_stats_get(self.h, out, 8))
+        out = (ctypes.c_uint64 * 9)()
+        _lib.check(self.L.kbbq_stats_get(self.h, out, 9))
         return dict(corrected_reads=out[0], correction_queries=out[1], reads=out[2], infer_lookups=out[3],
-                    bucket_flushes=(out[4], out[5]), bucket_direct=out[6], bucket_capacity=out[7])
+                    bucket_flushes=(out[4], out[5]), bucket_direct=out[6], bucket_capacity=out[7],
+                    quality_above_93=bool(out[8]))
 
     def stream_ptr(self):
         return self.L.kbbq_engine_stream(self.h)

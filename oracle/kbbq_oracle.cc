@@ -858,13 +858,15 @@ struct Cov {
     void consume(const Read &rd, int minscore) {
         ensure((size_t)rd.rg + 1, rd.seq.size());
         const size_t r = (size_t)rd.rg;
-        uint64_t nerr = 0;
-        for (size_t i = 0; i < rd.err.size(); ++i) nerr += rd.err[i];
-        rg[r * 2] += nerr;
-        rg[r * 2 + 1] += rd.seq.size();
+        // A quality above KBBQ_MAXQ = 93 (possible in a BAM, not in printable FASTQ): the reference's tables grow with
+        // the largest quality seen (covariateutils.cc:108-112) and would model it; this restatement and the engine keep
+        // 94 quality rows and leave such a base out of EVERY covariate, the read-group totals included (a departure,
+        // DESIGN.md section 7; the engine reports it, kbbq_stats_get [8]).
         for (size_t i = 0; i < rd.seq.size(); ++i) {
             const size_t qq = rd.qual[i];
-            if (qq >= (size_t)NQ) continue;   // reference would index past 93 freely; engine-defined: ignored
+            if (qq >= (size_t)NQ) continue;
+            rg[r * 2] += rd.err[i];
+            rg[r * 2 + 1] += 1;
             q[(r * NQ + qq) * 2] += rd.err[i];
             q[(r * NQ + qq) * 2 + 1] += 1;
             const size_t ci = (((r * NQ + qq) * 2 + (rd.second ? 1 : 0)) * C + i) * 2;

@@ -554,3 +554,22 @@ def test_overlapped_and_in_order_pass3_agree_on_device_batches():
         assert out.returncode == 0 and "pass3 ok" in out.stdout, out.stdout + out.stderr
         outs.append(out.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1]
+
+
+def test_qualities_above_93_are_reported_and_handled_like_the_oracle():
+    """The reference's covariate tables end at KBBQ_MAXQ = 93 and a larger quality (a BAM can hold 255) indexes past them;
+    oracle and engine leave such a base out of the model, write it as 93 (the clamp of readutils.cc:592-594) and the
+    engine says that it met one (kbbq_stats_get [8])."""
+    d = common.make_dataset(seed=919, genome_len=15000, coverage=24, extra_errors=40)
+    plain = common.run_engine(d, uniform=True, n_batches=2)
+    assert plain["stats"]["quality_above_93"] is False
+    rng = np.random.RandomState(3)
+    q = d["qual"].copy()
+    at = rng.choice(len(q), size=300, replace=False)
+    q[at] = rng.choice([94, 95, 96, 120, 200, 255], size=len(at)).astype(np.uint8)
+    d2 = dict(d, qual=np.ascontiguousarray(q))
+    eng = common.run_engine(d2, uniform=True, n_batches=2)
+    ora = common.run_oracle(d2)
+    common.assert_same_run(eng, ora)
+    assert eng["stats"]["quality_above_93"] is True
+    assert (np.asarray(eng["recal"])[at] == 93).all()
