@@ -1204,7 +1204,15 @@ __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8
         end2 = R.offsets ? R.offsets[r + 2] : end + R.read_len;
     }
     const int c0 = (int)(g0 - start);
-    int beyond = 0;      // a quality above KBBQ_MAXQ: the reference indexes past its tables there; the engine clamps it and says so (qflag)
+    // a quality above KBBQ_MAXQ = 93 among the 16 (bytes past the batch are 0): q + 34 >= 128, four bytes at a time.  The
+    // reference's tables would grow for it; the engine leaves the base out of the model, clamps it and says so (qflag).
+    uint32_t beyond = 0;
+    {
+        uint32_t w4[4];
+        memcpy(w4, qv, 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) beyond |= (((w4[j] & 0x7F7F7F7Fu) + 0x22222222u) | w4[j]) & 0x80808080u;
+    }
     const bool plain = n == 16 && rg < lds_rgs && rg2 < lds_rgs && (bpos == 16 || (r + 1 < R.n_reads && end2 >= g0 + 16)) &&
                        c0 + bpos <= D.n_cycle && 16 - bpos <= D.n_cycle;
     if (plain) {
@@ -1221,7 +1229,6 @@ __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8
             const int b = (int)((bw >> (2 * i)) & 3), nn = (int)((nw >> i) & 1);
             const int q = qv[i];
             int v = q;
-            beyond |= q >= KBBQ_NQ;
             if (q >= minqual && q < KBBQ_NQ) {
                 const int sl = l_qslot[q];
                 if (sl != 255) {
@@ -1252,7 +1259,6 @@ __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8
         const int b = (int)((bw >> (2 * i)) & 3), nn = (int)((nw >> i) & 1);
         const int q = qv[i];
         int v = q;
-        beyond |= i < n && q >= KBBQ_NQ;
         if (i < n && q >= minqual && q < KBBQ_NQ && rg < D.n_rg && cyc < D.n_cycle) {
             const int cell = rg * KBBQ_NQ + q;
             const bool use_di = cyc > 0 && !nn && !prev_n;
