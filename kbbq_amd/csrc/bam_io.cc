@@ -149,6 +149,151 @@ int BamReader::next(BamRecord &rec) {
     return (int)block;
 }
 
+// ------------------------------------------------------------ read of a record ----
+bool decode_bam_read(const BamRecord &b, bool use_oq, std::string &seq, std::vector<uint8_t> &qual, std::string &rg, bool &second,
+                     std::string &err) {
+    b.sequence(seq);
+    int status = 0;
+    if (use_oq) {
+        std::string oq;
+        if (!b.aux_string("OQ", oq, status)) {
+            err = "Error: --use-oq was specified but unable to read OQ tag on read " + b.name() + "\n";
+            err += status == BAM_AUX_MISSING ? "OQ not found. Try again without the --use-oq option.\n" : "Tag data is corrupt. Repair the tags and try again.\n";
+            return false;
+        }
+        if (oq.size() != b.l_seq()) {   // the reference indexes past the shorter of the two
+            err = "Error: OQ tag of read " + b.name() + " has " + std::to_string(oq.size()) + " values for " + std::to_string(b.l_seq()) + " bases.\n";
+            return false;
+        }
+        qual.resize(oq.size());
+        for (size_t i = 0; i < oq.size(); ++i) qual[i] = (uint8_t)(oq[i] - 33);
+    } else {
+        qual.assign(b.qual(), b.qual() + b.l_seq());
+    }
+    if (b.reverse()) std::reverse(qual.begin(), qual.end());   // readutils.cc:36-39
+    if (!b.aux_string("RG", rg, status)) {
+        err = "Error: Unable to read RG tag on read " + b.name() + "\n";
+        err += status == BAM_AUX_MISSING ? "RG not found. Every read in the BAM must have an RG tag; add tags with samtools addreplacerg and try again.\n"
+                                         : "Tag data is corrupt. Repair the tags and try again.\n";
+        return false;
+    }
+    second = b.second();
+    return true;
+}
+
+// ------------------------------------------------------------ chunk parser ----
+BamChunkParser::BamChunkParser(const std::string &path, bool use_oq, int io_threads, int parse_threads, bool keep_records)
+    : ChunkPipeline(parse_threads), use_oq_(use_oq), keep_records_(keep_records) {
+    BamReader head(path, io_threads);
+    if (!head.ok()) return;
+    header_ = head.header();
+    src_ = head.release();
+    if (src_) start();
+}
+
+void BamChunkParser::produce() {
+    constexpr size_t kChunk = 32u << 20, kPiece = 2u << 20;
+    std::vector<unsigned char> carry;
+    bool eof = false, bad = false, failed = false;
+    while (!eof && !bad && !stopping()) {
+        auto chunk = std::make_shared<std::vector<unsigned char>>();
+        chunk->resize(carry.size() + kChunk);
+        if (!carry.empty()) memcpy(chunk->data(), carry.data(), carry.size());
+        size_t have = carry.size();
+        carry.clear();
+        while (have < chunk->size()) {
+            const int got = src_->read(chunk->data() + have, (unsigned)std::min<size_t>(chunk->size() - have, 1u << 30));
+            if (got < 0) failed = true;      // (a read error -- bad checksum, file cut inside a block -- is never a clean end)
+            if (got <= 0) { eof = true; break; }
+            have += (size_t)got;
+        }
+        chunk->resize(have);
+        if (have == 0 && !failed) break;
+        const unsigned char *b = chunk->data();
+        // whole records: [block_size u32][block]; a partial one waits for the next chunk, a malformed size or -- at the
+        // end of the stream -- a partial record ends the stream after the piece before it
+        size_t begin = 0, p = 0;
+        auto flush = [&](size_t end, bool last) {
+            auto job = std::make_shared<Job>();
+            job->chunk = chunk;
+            job->begin = begin;
+            job->end = end;
+            job->last = last;      // here: a bad record follows
+            submit(job);
+            begin = end;
+        };
+        for (;;) {
+            if (have - p < 4) break;
+            const uint32_t block = (uint32_t)b[p] | (uint32_t)b[p + 1] << 8 | (uint32_t)b[p + 2] << 16 | (uint32_t)b[p + 3] << 24;
+            if (block < 32 || block > (1u << 29)) { bad = true; break; }
+            if (have - p - 4 < block) break;
+            p += 4 + (size_t)block;
+            if (p - begin >= kPiece) flush(p, false);
+        }
+        const bool truncated = eof && (p < have || failed);      // bytes that are no whole record at the end of the stream
+        if (bad || truncated) {
+            flush(p, true);      // (possibly an empty piece: it carries the end-of-stream mark)
+        } else {
+            if (p > begin) flush(p, false);
+            carry.assign(b + p, b + have);
+        }
+    }
+}
+
+void BamChunkParser::parse(Job &job) {
+    auto piece = std::make_shared<ReadPiece>();
+    job.piece = piece;
+    ReadPiece &P = *piece;
+    P.off.assign(1, 0);
+    P.blob_off.assign(1, 0);
+    P.end_of_stream = job.last;
+    const unsigned char *b = job.chunk->data();
+    const size_t bytes = job.end - job.begin;
+    P.seq.reserve(bytes / 2);
+    P.qual.reserve(bytes / 2);
+    if (keep_records_) P.blob.reserve(bytes);
+    BamRecord rec;
+    std::string seq, rg, last_rg, err;
+    std::vector<uint8_t> qual;
+    uint32_t last_rg_index = 0;
+    bool have_last = false;
+    for (size_t p = job.begin; p < job.end;) {
+        const uint32_t block = (uint32_t)b[p] | (uint32_t)b[p + 1] << 8 | (uint32_t)b[p + 2] << 16 | (uint32_t)b[p + 3] << 24;
+        rec.data.assign(b + p + 4, b + p + 4 + block);
+        p += 4 + (size_t)block;
+        if (!rec.well_formed()) {      // sam_read1 < -1: the passes' loops end here
+            P.end_of_stream = true;
+            return;
+        }
+        bool second = false;
+        if (!decode_bam_read(rec, use_oq_, seq, qual, rg, second, err)) {
+            P.fatal_at = (long)P.n();
+            P.fatal_msg = err;
+            return;
+        }
+        if (!have_last || rg != last_rg) {
+            size_t i = 0;
+            while (i < P.rg_names.size() && P.rg_names[i] != rg) ++i;
+            if (i == P.rg_names.size()) P.rg_names.push_back(rg);
+            last_rg = rg;
+            last_rg_index = (uint32_t)i;
+            have_last = true;
+        }
+        P.rg.push_back(last_rg_index);
+        P.second.push_back(second ? 1 : 0);
+        P.seq.insert(P.seq.end(), seq.begin(), seq.end());
+        P.qual.insert(P.qual.end(), qual.begin(), qual.end());
+        P.qual.resize(P.seq.size(), 0);
+        P.off.push_back(P.seq.size());
+        P.longest = std::max(P.longest, seq.size());
+        if (keep_records_) {
+            P.blob.append((const char *)rec.data.data(), rec.data.size());
+            P.lens.push_back((uint32_t)rec.data.size());
+            P.blob_off.push_back(P.blob.size());
+        }
+    }
+}
+
 // ------------------------------------------------------------------ writer ----
 static void put32(std::string &s, uint32_t v) {
     for (int i = 0; i < 4; ++i) s.push_back((char)(v >> (8 * i)));

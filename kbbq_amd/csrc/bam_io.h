@@ -66,6 +66,12 @@ struct BamRecord {
     bool aux_update_string(const char tag[2], const std::string &text, int &status);
 };
 
+// What CReadData's BAM constructor takes from one record (readutils.cc:13-61): bases in sequencing orientation, the
+// qualities (OQ:Z with use_oq) in the same orientation, the RG:Z tag, second-in-pair.  False with the text the command
+// line prints (the reference's messages) when --use-oq finds no usable OQ tag or the record has no RG tag.
+bool decode_bam_read(const BamRecord &b, bool use_oq, std::string &seq, std::vector<uint8_t> &qual, std::string &rg, bool &second,
+                     std::string &err);
+
 class BamReader {
 public:
     explicit BamReader(const std::string &path, int threads = 1);
@@ -73,12 +79,31 @@ public:
     bool ok() const { return ok_; }
     const BamHeader &header() const { return header_; }
     int next(BamRecord &rec);   // >= 0 ok, -1 end of file, -2 truncated or malformed (sam_read1's convention)
+    std::unique_ptr<ByteSource> release() { ok_ = false; return std::move(fh_); }   // the stream, positioned after the header
 
 private:
     bool read_exact(void *dst, size_t n);
     std::unique_ptr<ByteSource> fh_;
     BamHeader header_;
     bool ok_ = false;
+};
+
+// The records of a BAM stream through the pool of fastq_io.h (ChunkPipeline): alignment blocks carry their length, so
+// the reader thread cuts pieces exactly; the workers do decode_bam_read.  A truncated or malformed block ends the
+// stream after the records before it, as sam_read1 < -1 ends the reference's loops.
+class BamChunkParser : public ChunkPipeline {
+public:
+    BamChunkParser(const std::string &path, bool use_oq, int io_threads, int parse_threads, bool keep_records);
+    ~BamChunkParser() override { stop(); }
+    bool ok() const { return src_ != nullptr; }
+    const BamHeader &header() const { return header_; }
+
+private:
+    void produce() override;
+    void parse(Job &job) override;
+    std::unique_ptr<ByteSource> src_;
+    BamHeader header_;
+    bool use_oq_, keep_records_;
 };
 
 class BamWriter {

@@ -346,16 +346,19 @@ int looks_like_record_start(const unsigned char *b, size_t p, size_t end) {
 }
 }  // namespace
 
-FastqChunkParser::FastqChunkParser(const std::string &path, int io_threads, int parse_threads, bool keep_records)
-    : src_(open_bytes(path, io_threads)), keep_records_(keep_records) {
-    if (!src_) return;
-    parse_threads = std::max(1, parse_threads);
-    max_in_flight_ = (size_t)parse_threads * 6 + 16;
-    for (int i = 0; i < parse_threads; ++i) pool_.emplace_back(&FastqChunkParser::worker, this);
-    reader_ = std::thread(&FastqChunkParser::reader, this);
+// ---- the pipeline: reader thread -> pool -> consumer, in order ----
+ChunkPipeline::~ChunkPipeline() { stop(); }
+
+void ChunkPipeline::start() {
+    max_in_flight_ = (size_t)parse_threads_ * 6 + 16;
+    for (int i = 0; i < parse_threads_; ++i) pool_.emplace_back(&ChunkPipeline::worker, this);
+    reader_ = std::thread(&ChunkPipeline::run_reader, this);
+    started_ = true;
 }
 
-FastqChunkParser::~FastqChunkParser() {
+void ChunkPipeline::stop() {
+    if (!started_) return;
+    started_ = false;
     {
         std::lock_guard<std::mutex> lk(mu_);
         stop_ = true;
@@ -364,9 +367,15 @@ FastqChunkParser::~FastqChunkParser() {
     cv_room_.notify_all();
     if (reader_.joinable()) reader_.join();
     for (auto &t : pool_) t.join();
+    pool_.clear();
 }
 
-void FastqChunkParser::submit(std::shared_ptr<Job> job) {
+bool ChunkPipeline::stopping() {
+    std::lock_guard<std::mutex> lk(mu_);
+    return stop_;
+}
+
+void ChunkPipeline::submit(std::shared_ptr<Job> job) {
     std::unique_lock<std::mutex> lk(mu_);
     cv_room_.wait(lk, [&] { return stop_ || in_flight_ < max_in_flight_; });
     if (stop_) return;
@@ -378,14 +387,60 @@ void FastqChunkParser::submit(std::shared_ptr<Job> job) {
     cv_done_.notify_all();      // (the consumer may be waiting for a first piece)
 }
 
-void FastqChunkParser::reader() {
-    std::vector<unsigned char> carry;
-    bool eof = false;
-    while (!eof) {
+void ChunkPipeline::run_reader() {
+    produce();
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        finished_ = true;
+    }
+    cv_done_.notify_all();
+}
+
+void ChunkPipeline::worker() {
+    for (;;) {
+        std::shared_ptr<Job> job;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_todo_.wait(lk, [&] { return stop_ || !todo_.empty(); });
+            if (stop_) return;
+            job = todo_.front();
+            todo_.pop_front();
+        }
+        parse(*job);
         {
             std::lock_guard<std::mutex> lk(mu_);
-            if (stop_) break;
+            job->done = true;
         }
+        cv_done_.notify_all();
+    }
+}
+
+std::shared_ptr<ReadPiece> ChunkPipeline::next() {
+    if (!started_ || ended_) return nullptr;
+    std::shared_ptr<Job> job;
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] { return !order_.empty() || finished_; });
+        if (order_.empty()) { ended_ = true; return nullptr; }
+        job = order_.front();
+        cv_done_.wait(lk, [&] { return job->done; });
+        order_.pop_front();
+        --in_flight_;
+    }
+    cv_room_.notify_one();
+    if (job->piece->complex || job->piece->fatal_at >= 0 || job->piece->end_of_stream) ended_ = true;
+    return job->piece;
+}
+
+FastqChunkParser::FastqChunkParser(const std::string &path, int io_threads, int parse_threads, bool keep_records)
+    : ChunkPipeline(parse_threads), src_(open_bytes(path, io_threads)), keep_records_(keep_records) {
+    if (src_) start();
+}
+
+void FastqChunkParser::produce() {
+    std::vector<unsigned char> carry;
+    bool eof = false;
+    while (!eof && !stopping()) {
         auto chunk = std::make_shared<std::vector<unsigned char>>();
         chunk->resize(carry.size() + kChunkBytes);
         if (!carry.empty()) memcpy(chunk->data(), carry.data(), carry.size());
@@ -449,33 +504,10 @@ void FastqChunkParser::reader() {
             begin = end;
         }
     }
-    {
-        std::lock_guard<std::mutex> lk(mu_);
-        finished_ = true;
-    }
-    cv_done_.notify_all();
 }
 
-void FastqChunkParser::worker() {
-    for (;;) {
-        std::shared_ptr<Job> job;
-        {
-            std::unique_lock<std::mutex> lk(mu_);
-            cv_todo_.wait(lk, [&] { return stop_ || !todo_.empty(); });
-            if (stop_) return;
-            job = todo_.front();
-            todo_.pop_front();
-        }
-        parse(*job, keep_records_);
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            job->done = true;
-        }
-        cv_done_.notify_all();
-    }
-}
-
-void FastqChunkParser::parse(Job &job, bool keep_records) {
+void FastqChunkParser::parse(Job &job) {
+    const bool keep_records = keep_records_;
     auto piece = std::make_shared<FastqPiece>();
     job.piece = piece;
     FastqPiece &P = *piece;
@@ -554,23 +586,6 @@ void FastqChunkParser::parse(Job &job, bool keep_records) {
         p = n3 ? q1 + 1 : end;
     }
     // (p == end: the piece ended exactly where the next one starts, which proves that cut)
-}
-
-std::shared_ptr<FastqPiece> FastqChunkParser::next() {
-    if (!src_ || ended_) return nullptr;
-    std::shared_ptr<Job> job;
-    {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_done_.wait(lk, [&] { return !order_.empty() || finished_; });
-        if (order_.empty()) { ended_ = true; return nullptr; }
-        job = order_.front();
-        cv_done_.wait(lk, [&] { return job->done; });
-        order_.pop_front();
-        --in_flight_;
-    }
-    cv_room_.notify_one();
-    if (job->piece->complex || job->piece->fatal_at >= 0) ended_ = true;
-    return job->piece;
 }
 
 // -------------------------------------------------------------- read names ----

@@ -57,60 +57,81 @@ private:
     bool eof_ = false;
 };
 
-// ---- block-parallel FASTQ parse ---------------------------------------------------------------------------------
-// The usual FASTQ file is a run of strictly four-line records ("@header\nSEQ\n+...\nQUAL\n", |SEQ| = |QUAL| > 0,
-// no carriage returns, nothing between records).  For such a stream the work of FastqReader + parse_read_name can be
-// done by a pool: a reader thread cuts the decompressed bytes into pieces at record starts, workers parse the pieces,
-// the consumer gets them back in file order.  A cut is a GUESS ("\n@" whose line after next starts with '+'); it is
-// proved by the piece before it, whose strict parse -- started at a proven record start -- must end exactly there.
-// Anything that is not strictly of that shape (multi-line records, FASTA records, empty reads, '\r', blank lines, a
-// truncated tail) marks the piece `complex`: the caller then starts over with FastqReader, which is the definition.
-struct FastqPiece {
-    std::vector<uint8_t> seq, qual;        // bases as text, qualities minus 33 (readutils.cc:70-71), concatenated
+// ---- block-parallel parse of the input ---------------------------------------------------------------------------
+// A reader thread cuts the decompressed bytes of the input into pieces at record starts, a pool of workers parses
+// the pieces, the consumer gets them back in file order (ChunkPipeline).  A piece carries what a batch of the engine
+// and the output pass need of its records.
+struct ReadPiece {
+    std::vector<uint8_t> seq, qual;        // bases as text, qualities as numbers (readutils.cc:13-104), concatenated
     std::vector<uint64_t> off;             // n + 1 offsets into seq / qual
-    std::vector<uint8_t> second;           // per read: second in pair (parse_read_name)
+    std::vector<uint8_t> second;           // per read: second in pair
     std::vector<std::string> rg_names;     // read groups in order of first appearance in this piece
     std::vector<uint32_t> rg;              // per read: index into rg_names
-    std::string blob;                      // name, comment, sequence text of every record, back to back
-    std::vector<uint32_t> lens;            // three lengths per record
+    std::string blob;                      // FASTQ: name, comment, sequence text of every record; BAM: the alignment blocks
+    std::vector<uint32_t> lens;            // FASTQ: three lengths per record; BAM: one
     std::vector<uint64_t> blob_off;        // n + 1 offsets into blob
     size_t longest = 0;
-    bool complex = false;
-    long fatal_at = -1;                    // parse_read_name failed on this record (std::out_of_range in the reference)
-    std::string fatal_name;
+    bool complex = false;                  // FASTQ only: not strictly four-line records -- start over with FastqReader
+    bool end_of_stream = false;            // BAM: a truncated or malformed record follows the last one of this piece (sam_read1 < -1)
+    long fatal_at = -1;                    // the record after the last one of this piece is an error the command line reports
+    std::string fatal_name, fatal_msg;     // FASTQ: the read name (parse_read_name failed); BAM: the text for stderr
     size_t n() const { return off.empty() ? 0 : off.size() - 1; }
 };
+using FastqPiece = ReadPiece;
 
-class FastqChunkParser {
+class ChunkPipeline {
 public:
-    FastqChunkParser(const std::string &path, int io_threads, int parse_threads, bool keep_records);
-    ~FastqChunkParser();
-    bool ok() const { return src_ != nullptr; }
-    // the next piece in file order; null at the end of the stream (and after a complex piece has been handed out)
-    std::shared_ptr<FastqPiece> next();
+    virtual ~ChunkPipeline();              // (derived destructors call stop() first: the threads call their virtuals)
+    // the next piece in file order; null at the end of the stream and after a complex, fatal or end_of_stream piece
+    std::shared_ptr<ReadPiece> next();
 
-private:
+protected:
     struct Job {
         std::shared_ptr<std::vector<unsigned char>> chunk;
         size_t begin = 0, end = 0;
-        bool last = false;                 // the stream ends with this piece (its last line may lack the newline)
+        bool last = false;                 // the stream ends with this piece
         bool force_complex = false;
-        std::shared_ptr<FastqPiece> piece;
+        std::shared_ptr<ReadPiece> piece;
         bool done = false;
     };
-    void reader();
+    explicit ChunkPipeline(int parse_threads) : parse_threads_(parse_threads < 1 ? 1 : parse_threads) {}
+    void start();                          // at the end of the derived constructor
+    void stop();
+    bool stopping();
+    void submit(std::shared_ptr<Job> job); // blocks while too many pieces are in flight
+    virtual void produce() = 0;            // reader thread: cut the stream into jobs
+    virtual void parse(Job &job) = 0;      // worker thread
+
+private:
+    void run_reader();
     void worker();
-    void submit(std::shared_ptr<Job> job);
-    static void parse(Job &job, bool keep_records);
-    std::unique_ptr<ByteSource> src_;
-    bool keep_records_;
+    int parse_threads_;
     std::vector<std::thread> pool_;
     std::deque<std::shared_ptr<Job>> order_, todo_;      // guarded by mu_
     std::mutex mu_;
     std::condition_variable cv_todo_, cv_done_, cv_room_;
     size_t in_flight_ = 0, max_in_flight_ = 64;
-    bool stop_ = false, finished_ = false, ended_ = false;
-    std::thread reader_;                   // last member: starts when everything above exists
+    bool stop_ = false, finished_ = false, ended_ = false, started_ = false;
+    std::thread reader_;
+};
+
+// The usual FASTQ file is a run of strictly four-line records ("@header\nSEQ\n+...\nQUAL\n", |SEQ| = |QUAL| > 0,
+// no carriage returns, nothing between records).  For such a stream the work of FastqReader + parse_read_name is done
+// by the pool.  A cut is a GUESS ("\n@" whose line after next starts with '+'); it is proved by the piece before it,
+// whose strict parse -- started at a proven record start -- must end exactly there.  Anything that is not strictly of
+// that shape (multi-line records, FASTA records, empty reads, '\r', blank lines, a truncated tail) marks the piece
+// `complex`: the caller then starts over with FastqReader, which is the definition.
+class FastqChunkParser : public ChunkPipeline {
+public:
+    FastqChunkParser(const std::string &path, int io_threads, int parse_threads, bool keep_records);
+    ~FastqChunkParser() override { stop(); }
+    bool ok() const { return src_ != nullptr; }
+
+private:
+    void produce() override;
+    void parse(Job &job) override;
+    std::unique_ptr<ByteSource> src_;
+    bool keep_records_;
 };
 
 // The dense read-group index in order of first appearance (CReadData::rg_to_int, readutils.cc:10-11,100-103).

@@ -136,36 +136,11 @@ public:
     int next(Item &it) override {
         const int rc = in_.next(it.bam);
         if (rc < 0) return rc;
-        const BamRecord &b = it.bam;
-        b.sequence(it.seq);
-        int status = 0;
-        if (use_oq_) {
-            std::string oq;
-            if (!b.aux_string("OQ", oq, status)) {
-                std::cerr << "Error: --use-oq was specified but unable to read OQ tag on read " << b.name() << std::endl;
-                if (status == BAM_AUX_MISSING) std::cerr << "OQ not found. Try again without the --use-oq option." << std::endl;
-                else std::cerr << "Tag data is corrupt. Repair the tags and try again." << std::endl;
-                return SRC_FATAL;
-            }
-            if (oq.size() != b.l_seq()) {   // the reference indexes past the shorter of the two
-                std::cerr << "Error: OQ tag of read " << b.name() << " has " << oq.size() << " values for " << b.l_seq() << " bases." << std::endl;
-                return SRC_FATAL;
-            }
-            it.qual.resize(oq.size());
-            for (size_t i = 0; i < oq.size(); ++i) it.qual[i] = (uint8_t)(oq[i] - 33);
-        } else {
-            it.qual.assign(b.qual(), b.qual() + b.l_seq());
-        }
-        if (b.reverse()) std::reverse(it.qual.begin(), it.qual.end());   // readutils.cc:36-39
-        if (!b.aux_string("RG", it.rg, status)) {
-            std::cerr << "Error: Unable to read RG tag on read " << b.name() << std::endl;
-            if (status == BAM_AUX_MISSING)
-                std::cerr << "RG not found. Every read in the BAM must have an RG tag; add tags with "
-                          << "samtools addreplacerg and try again." << std::endl;
-            else std::cerr << "Tag data is corrupt. Repair the tags and try again." << std::endl;
+        std::string err;
+        if (!decode_bam_read(it.bam, use_oq_, it.seq, it.qual, it.rg, it.second, err)) {
+            std::cerr << err << std::flush;
             return SRC_FATAL;
         }
-        it.second = b.second();
         return rc;
     }
 
@@ -256,15 +231,17 @@ struct Batch {
         return finish();
     }
 
-    // The same batch from the block-parallel parser (fastq_io.h: FastqChunkParser), strictly four-line FASTQ only.
+    // The same batch from the block-parallel parsers (fastq_io.h: FastqChunkParser, strictly four-line FASTQ only; bam_io.h:
+    // BamChunkParser).
     // Returns false when no read was collected; `complex` says the stream is not of that shape and the scan has to
     // start over with the serial reader.  The records go straight into `store` (when given).
     struct Fast {
-        std::unique_ptr<FastqChunkParser> parser;
-        std::shared_ptr<FastqPiece> cur;
+        std::unique_ptr<ChunkPipeline> parser;      // FastqChunkParser or BamChunkParser
+        std::shared_ptr<ReadPiece> cur;
         size_t at = 0;
         std::vector<int> rg_map;
         bool complex = false;
+        int lens_per_record = 3;                    // RecordStore's layout: FASTQ 3 lengths per record, BAM 1
     };
     bool fill_fast(Fast &f, ReadGroups &groups, size_t max_reads, RecordStore *store) {
         fq_recs.clear(); bam_recs.clear(); seq.clear(); qual.clear(); flags.clear(); rg.clear();
@@ -273,7 +250,8 @@ struct Batch {
         longest = 0;
         while (rg.size() < max_reads) {
             if (f.cur && f.at == f.cur->n() && f.cur->fatal_at >= 0) {      // (the piece's parse stopped at that record)
-                std::cerr << put_now << " Error: read name '" << f.cur->fatal_name << "' is shorter than 2 characters before the first '_'." << std::endl;
+                if (!f.cur->fatal_msg.empty()) std::cerr << f.cur->fatal_msg << std::flush;
+                else std::cerr << put_now << " Error: read name '" << f.cur->fatal_name << "' is shorter than 2 characters before the first '_'." << std::endl;
                 fatal = true;
                 return false;
             }
@@ -295,12 +273,13 @@ struct Batch {
             for (size_t r = a; r < b; ++r) {
                 off.push_back(base + P.off[r + 1]);
                 longest = std::max<size_t>(longest, P.off[r + 1] - P.off[r]);
+                if (P.off[r + 1] == P.off[r]) saw_empty = true;
                 rg.push_back((uint16_t)f.rg_map[P.rg[r]]);
             }
             flags.insert(flags.end(), P.second.begin() + a, P.second.begin() + b);
             if (store) {
                 store->blob.append(P.blob, P.blob_off[a], P.blob_off[b] - P.blob_off[a]);
-                store->lens.insert(store->lens.end(), P.lens.begin() + 3 * a, P.lens.begin() + 3 * b);
+                store->lens.insert(store->lens.end(), P.lens.begin() + f.lens_per_record * a, P.lens.begin() + f.lens_per_record * b);
             }
             f.at = b;
         }
@@ -414,6 +393,32 @@ static int io_test(int argc, char *argv[]) {
             for (size_t i = 0; i < q.size(); ++i) q[i] = (char)(it.qual[i] + 33);
             printf("%s\t%d\t%s\t%d\t%d\t%s\t%s\n", it.bam.name().c_str(), (int)it.bam.flag(), it.rg.c_str(), groups.index_of(it.rg), (int)it.second,
                    it.seq.c_str(), q.c_str());
+        }
+        printf("#end %d\n", rc);
+        return 0;
+    }
+    if (what == "bam-fast" && argc > 3) {     // the same lines from the block-parallel BAM parser: --io-test bam-fast FILE [use-oq] [threads]
+        BamChunkParser in(argv[3], argc > 4 && std::string(argv[4]) == "use-oq", std::max(2, io_threads), argc > 5 ? atoi(argv[5]) : 4, true);
+        if (!in.ok()) return 2;
+        printf("#text %zu genome %llu refs %zu\n", in.header().text.size(), (unsigned long long)in.header().genome_length(), in.header().refs.size());
+        ReadGroups groups;
+        int rc = -1;
+        while (auto piece = in.next()) {
+            const ReadPiece &P = *piece;
+            std::vector<int> map;
+            for (auto &n : P.rg_names) map.push_back(groups.index_of(n));
+            BamRecord b;
+            for (size_t r = 0; r < P.n(); ++r) {
+                b.data.assign((const uint8_t *)P.blob.data() + P.blob_off[r], (const uint8_t *)P.blob.data() + P.blob_off[r + 1]);
+                if (P.lens[r] != b.data.size()) return 3;
+                const size_t len = P.off[r + 1] - P.off[r];
+                std::string q(len, ' ');
+                for (size_t i = 0; i < len; ++i) q[i] = (char)(P.qual[P.off[r] + i] + 33);
+                printf("%s\t%d\t%s\t%d\t%d\t%s\t%s\n", b.name().c_str(), (int)b.flag(), P.rg_names[P.rg[r]].c_str(), map[P.rg[r]], (int)P.second[r],
+                       std::string((const char *)P.seq.data() + P.off[r], len).c_str(), q.c_str());
+            }
+            if (P.fatal_at >= 0) { fflush(stdout); std::cerr << P.fatal_msg << std::flush; rc = SRC_FATAL; }
+            else if (P.end_of_stream) rc = -2;
         }
         printf("#end %d\n", rc);
         return 0;
@@ -551,10 +556,11 @@ int main(int argc, char *argv[]) {
         if (!resident.on || !resident.rec_budget) resident.keep_recs = false;
     };
     init_resident();
-    // FASTQ input is parsed by a pool when it is strictly four-line (fastq_io.h: FastqChunkParser); anything else -- found
-    // out while parsing -- starts the scan over with the serial reader.  KBBQ_SERIAL_PARSE=1: the serial reader at once.
+    // The first scan parses its input with a pool: BAM always (bam_io.h: BamChunkParser), FASTQ when it is strictly
+    // four-line (fastq_io.h: FastqChunkParser) -- anything else, found out while parsing, starts the scan over with the
+    // serial reader.  KBBQ_SERIAL_PARSE=1: the serial readers at once.
     for (int attempt = 0; attempt < 2; ++attempt) {
-        const bool fast = attempt == 0 && !is_bam && g_io_threads > 1 && !(getenv("KBBQ_SERIAL_PARSE") && atoi(getenv("KBBQ_SERIAL_PARSE")));
+        const bool fast = attempt == 0 && g_io_threads > 1 && !(getenv("KBBQ_SERIAL_PARSE") && atoi(getenv("KBBQ_SERIAL_PARSE")));
         if (attempt == 1) {
             groups = ReadGroups();
             seqlen = n_reads = 0;
@@ -564,9 +570,19 @@ int main(int argc, char *argv[]) {
         }
         std::unique_ptr<Source> in;
         Batch::Fast ff;
-        if (fast) {
-            ff.parser.reset(new FastqChunkParser(filename, g_io_threads, out_threads, resident.on && resident.keep_recs));
-            if (!ff.parser->ok()) {
+        if (fast && is_bam) {
+            auto *bp = new BamChunkParser(filename, use_oq, g_io_threads, out_threads, resident.on && resident.keep_recs);
+            ff.parser.reset(bp);
+            ff.lens_per_record = 1;
+            if (!bp->ok()) {
+                std::cerr << put_now << " Error opening file " << filename << std::endl;
+                return 1;
+            }
+            bam_header = bp->header();
+        } else if (fast) {
+            auto *fp = new FastqChunkParser(filename, g_io_threads, out_threads, resident.on && resident.keep_recs);
+            ff.parser.reset(fp);
+            if (!fp->ok()) {
                 std::cerr << put_now << " Error opening file " << filename << std::endl;
                 return 1;
             }

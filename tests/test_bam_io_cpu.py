@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import bamutil
+import common
 from test_cli_io_cpu import CLI
 
 
@@ -39,19 +40,22 @@ def write_bam(path, recs, refs=(("chr1", 1000), ("chrUn_x", 234567)), text="@HD\
 
 
 THREADS = {"KBBQ_IO_THREADS": "1"}      # set per test: 1 = zlib's gzread on the caller, > 1 = pool of inflaters over the BGZF blocks
+MODE = {"what": "bam"}                  # set per test: "bam" = the serial reader, "bam-fast" = the block-parallel parser (BamChunkParser)
 
 
 def io_bam(path, *more):
-    p = subprocess.run([CLI, "--io-test", "bam", str(path)] + list(more), capture_output=True, text=True, env=dict(os.environ, **THREADS))
+    p = subprocess.run([CLI, "--io-test", MODE["what"], str(path)] + list(more), capture_output=True, text=True, env=dict(os.environ, **THREADS))
     lines = p.stdout.rstrip("\n").split("\n")
     return lines[0], [ln.split("\t") for ln in lines[1:-1]], int(lines[-1].split()[1]), p.stderr
 
 
-@pytest.fixture(params=[1, 4], autouse=True)
+@pytest.fixture(params=[(1, "bam"), (4, "bam"), (4, "bam-fast")], autouse=True, ids=["serial-1", "serial-4", "pool-4"])
 def io_threads(request):
-    THREADS["KBBQ_IO_THREADS"] = str(request.param)
-    yield request.param
+    THREADS["KBBQ_IO_THREADS"] = str(request.param[0])
+    MODE["what"] = request.param[1]
+    yield request.param[0]
     THREADS["KBBQ_IO_THREADS"] = "1"
+    MODE["what"] = "bam"
 
 
 @pytest.mark.parametrize("ragged", [None, 7])
@@ -119,14 +123,14 @@ def test_truncated_and_foreign_files(tmp_path):
     _, rows, rc, _ = io_bam(p)
     assert rc == -2 and len(rows) == 9                 # sam_read1 reports a truncated record as an error
     p.write_bytes(bamutil.bgzf_compress(b"BAM\2" + stream[4:]))
-    assert subprocess.run([CLI, "--io-test", "bam", str(p)], capture_output=True, env=dict(os.environ, **THREADS)).returncode == 2
+    assert subprocess.run([CLI, "--io-test", MODE["what"], str(p)], capture_output=True, env=dict(os.environ, **THREADS)).returncode == 2
     # a block whose checksum does not match its data, and a file cut in the middle of a block
     good = bamutil.bgzf_compress(stream, block=4000)
     bad = bytearray(good)
     bad[len(good) // 2] ^= 0x55
     for blob in (bytes(bad), good[:len(good) // 2]):
         p.write_bytes(blob)
-        run = subprocess.run([CLI, "--io-test", "bam", str(p)], capture_output=True, text=True, env=dict(os.environ, **THREADS))
+        run = subprocess.run([CLI, "--io-test", MODE["what"], str(p)], capture_output=True, text=True, env=dict(os.environ, **THREADS))
         lines = run.stdout.rstrip("\n").split("\n")
         # never a clean end of file: either the header already fails (zlib reads ahead) or the records stop with an error
         assert run.returncode == 2 or (lines[-1].startswith("#end") and int(lines[-1].split()[1]) < -1 and len(lines) - 2 < 10)
@@ -155,3 +159,19 @@ def test_writer_round_trip_and_set_oq(tmp_path):
     recs[0]["tags"] = [("RG", "Z", "g"), ("OQ", "i", 1)]
     write_bam(p, recs)
     assert subprocess.run([CLI, "--io-test", "bamcopy", str(p), "set-oq"], capture_output=True).returncode == 3
+
+
+def test_pool_parser_equals_the_serial_reader_across_chunks(tmp_path):
+    """200 000 records (57 MB of alignment blocks: two 32 MB chunks, ~30 pieces): the block-parallel parser prints what
+    the serial reader prints, record by record, with plain and with reversed records."""
+    if MODE["what"] != "bam-fast":
+        pytest.skip("compares the two modes itself")
+    import sys
+    p = tmp_path / "big.bam"
+    subprocess.run([sys.executable, os.path.join(common.ROOT, "tools", "make_bam.py"), str(p), "1000000", "30"], check=True, capture_output=True)
+    env = dict(os.environ, KBBQ_IO_THREADS="4")
+    serial = subprocess.run([CLI, "--io-test", "bam", str(p)], capture_output=True, check=True, env=env).stdout
+    for threads in ("1", "7"):
+        pool = subprocess.run([CLI, "--io-test", "bam-fast", str(p), "", threads], capture_output=True, check=True, env=env).stdout
+        assert pool == serial
+    assert serial.count(b"\n") == 200002

@@ -14,4 +14,4 @@ for mode in address,undefined thread; do
 done
 cd $R
 KBBQ_CLI=$O/kbbq_address ASAN_OPTIONS=detect_leaks=0 python -m pytest tests/test_cli_io_cpu.py tests/test_bam_io_cpu.py -x -q
-KBBQ_CLI=$O/kbbq_thread TSAN_OPTIONS=halt_on_error=1 python -m pytest tests/test_cli_io_cpu.py -x -q
+KBBQ_CLI=$O/kbbq_thread TSAN_OPTIONS=halt_on_error=1 python -m pytest tests/test_cli_io_cpu.py tests/test_bam_io_cpu.py -x -q
