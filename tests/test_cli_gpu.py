@@ -412,3 +412,18 @@ def test_cli_block_parallel_and_serial_fastq_parse_agree(tmp_path):
     rc, out, err = run_cli(["-g", d["genome_len"], ml], {"KBBQ_SEED": "12"})
     assert rc == 0, err
     assert gzip.decompress(out) == want
+
+
+@pytest.mark.parametrize("use_oq", [False, True])
+def test_cli_block_parallel_and_serial_bam_parse_agree(tmp_path, use_oq):
+    """BAM records go through the same pool (bam_io.h: BamChunkParser) in the first scan; the bytes written must be those
+    of the serial reader (KBBQ_SERIAL_PARSE=1), with small batches and without the record cache as well."""
+    db, recs, path, n_rg = bam_dataset(tmp_path, use_oq=use_oq, seed=616, genome_len=20000, coverage=24, n_per_million=2000, ragged=True, extra_errors=60)
+    args = (["--use-oq"] if use_oq else []) + ["--set-oq", path]
+    rc, want, err = run_cli(args, {"KBBQ_SEED": "21", "KBBQ_SERIAL_PARSE": "1"})
+    assert rc == 0, err
+    want = bamutil.bgzf_decompress(want)
+    for env in ({}, {"KBBQ_BATCH_READS": "211"}, {"KBBQ_HOST_CACHE_MB": "0"}):
+        rc, out, err = run_cli(args, dict(env, KBBQ_SEED="21"))
+        assert rc == 0, err
+        assert bamutil.bgzf_decompress(out) == want, env
