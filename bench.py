@@ -287,18 +287,22 @@ def pcie_inclusive(genome_len, coverage, local_rank):
     sub_bytes = [(0.375, 0.0), (1.375, 0.0), (1.375, 0.0), (1.375, 1.0)]
     once_bytes = [(1.375, 0.0), (0.0, 0.0), (0.0, 0.0), (0.0, 1.0)]
 
-    def bound(bytes_per_pass):
-        return sum(max(nb * u / h2d + nb * dwn / d2h, c) for (u, dwn), c in zip(bytes_per_pass, t_res))
+    def bound(bytes_per_pass, duplex=False):
+        # a pass cannot be faster than its transfers or than its resident time; `duplex`: the two directions of pass 4 fully
+        # overlapped (the link carries both at once; the engine pipelines a host batch's pass 4 in pieces), otherwise summed
+        return sum(max(max(nb * u / h2d, nb * dwn / d2h) if duplex else nb * u / h2d + nb * dwn / d2h, c)
+                   for (u, dwn), c in zip(bytes_per_pass, t_res))
 
     def mode(t, bytes_per_pass, text):
-        b = bound(bytes_per_pass)
+        b, bd = bound(bytes_per_pass), bound(bytes_per_pass, True)
         return dict(value=round(nb / sum(t) / 1e9, 4), unit="Gbases/s", seconds=round(sum(t), 3), pass_seconds=[round(x, 3) for x in t],
-                    bound_Gbases_per_s=round(nb / b / 1e9, 4), fraction_of_bound=round(b / sum(t), 3), traffic=text)
+                    bound_Gbases_per_s=round(nb / b / 1e9, 4), fraction_of_bound=round(b / sum(t), 3),
+                    duplex_bound_Gbases_per_s=round(nb / bd / 1e9, 4), fraction_of_duplex_bound=round(bd / sum(t), 3), traffic=text)
 
     return dict(host_link=dict(h2d_GBps=round(up.value, 2), d2h_GBps=round(dn.value, 2), how="one 1 GiB copy each way, page-locked host memory"),
                 sample="%d reads x %d bp = %.3g bases as page-locked host batches of %d reads (the command line's batch size)" % (n_reads, READ_LEN, nb, PB),
                 resident_pass_seconds=[round(x, 3) for x in t_res],
-                bound="per mode: sum over the four passes of max(bytes / measured link rate, the pass's resident time)",
+                bound="per mode: sum over the four passes of max(bytes up / measured H2D rate + bytes down / measured D2H rate, the pass's resident time); duplex bound: the two directions of a pass overlapped",
                 resubmit=mode(t_sub, sub_bytes, "4.5 B/base H2D (pass 1 sends no qualities), 1 B/base D2H"),
                 upload_once=mode(t_once, once_bytes, "1.4 B/base H2D, 1 B/base D2H"))
 

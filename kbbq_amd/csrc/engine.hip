@@ -320,9 +320,16 @@ int acquire_slot(kbbq_engine *e, size_t need, kbbq_engine::StageSlot **out) {
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// (pass 4 on a host batch: the caller copies bases, N mask and qualities itself, piece by piece -- recalibrate_impl)
+struct DeferredCopy {
+    char *d_bases = nullptr, *d_nmask = nullptr, *d_qual = nullptr;
+    kbbq_engine::StageSlot *slot = nullptr;
+};
+
 // device view of a batch; host batches are copied (freed at the next sync)
 // need_qual = false (pass 1: k-mers only): a host batch's qualities are not copied
-int device_view(kbbq_engine *e, const kbbq_reads *in, ReadsDev *out, int *max_len, bool need_qual = true) {
+// defer (host batches): the three big arrays are NOT copied and the engine's stream does not wait: the caller does both
+int device_view(kbbq_engine *e, const kbbq_reads *in, ReadsDev *out, int *max_len, bool need_qual = true, DeferredCopy *defer = nullptr) {
     if (!in) return fail(KBBQ_EINVAL, "null batch");
     if (in->n_reads == 0) return fail(KBBQ_EINVAL, "empty batch");
     if (!in->offsets && in->read_len == 0) return fail(KBBQ_EINVAL, "batch has neither offsets nor read_len");
@@ -370,9 +377,13 @@ int device_view(kbbq_engine *e, const kbbq_reads *in, ReadsDev *out, int *max_le
         HIP_TRY(hipMemsetAsync(d + o_b + nb_b, 0, 8, e->copy));
         HIP_TRY(hipMemsetAsync(d + o_m + nb_m, 0, 8, e->copy));
         HIP_TRY(hipMemsetAsync(d + o_q + nb_q, 0, 16, e->copy));
-        HIP_TRY(hipMemcpyAsync(d + o_b, in->bases, nb_b, hipMemcpyHostToDevice, e->copy));
-        HIP_TRY(hipMemcpyAsync(d + o_m, in->nmask, nb_m, hipMemcpyHostToDevice, e->copy));
-        if (need_qual) HIP_TRY(hipMemcpyAsync(d + o_q, in->qual, nb_q, hipMemcpyHostToDevice, e->copy));
+        if (defer) {
+            defer->d_bases = d + o_b; defer->d_nmask = d + o_m; defer->d_qual = d + o_q; defer->slot = sl;
+        } else {
+            HIP_TRY(hipMemcpyAsync(d + o_b, in->bases, nb_b, hipMemcpyHostToDevice, e->copy));
+            HIP_TRY(hipMemcpyAsync(d + o_m, in->nmask, nb_m, hipMemcpyHostToDevice, e->copy));
+            if (need_qual) HIP_TRY(hipMemcpyAsync(d + o_q, in->qual, nb_q, hipMemcpyHostToDevice, e->copy));
+        }
         if (nb_o) HIP_TRY(hipMemcpyAsync(d + o_o, in->offsets, nb_o, hipMemcpyHostToDevice, e->copy));
         if (nb_f) HIP_TRY(hipMemcpyAsync(d + o_f, in->flags, nb_f, hipMemcpyHostToDevice, e->copy));
         if (nb_g) HIP_TRY(hipMemcpyAsync(d + o_g, in->rg, nb_g, hipMemcpyHostToDevice, e->copy));
@@ -381,7 +392,7 @@ int device_view(kbbq_engine *e, const kbbq_reads *in, ReadsDev *out, int *max_le
             HIP_TRY(hipMemcpyAsync(d + o_c, in->offcase, nb_c, hipMemcpyHostToDevice, e->copy));
         }
         HIP_TRY(hipEventRecord(sl->h2d, e->copy));
-        HIP_TRY(hipStreamWaitEvent(e->stream, sl->h2d, 0));      // (the side stream only ever follows the main one)
+        HIP_TRY(hipStreamWaitEvent(e->stream, sl->h2d, 0));      // (the side stream only ever follows the main one; with `defer`: the small arrays)
         R.bases = (const uint64_t *)(d + o_b); R.nmask = (const uint64_t *)(d + o_m); R.qual = (const uint8_t *)(d + o_q);
         R.offsets = nb_o ? (const uint64_t *)(d + o_o) : nullptr;
         R.flags = nb_f ? (const uint8_t *)(d + o_f) : nullptr;
@@ -2020,7 +2031,14 @@ static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qu
     if (!e->dq_set) return fail(KBBQ_ESTATE, "no delta-Q tables yet");
     HostBatchDone host_done(e, reads);
     ReadsDev R; int max_len;
-    int rc = device_view(e, reads, &R, &max_len);
+    // a large host batch with its result in host memory goes through in pieces (below): 64 Ki-base multiples, at least 2^23
+    // bases each, about four per batch
+    static const bool no_pipe = getenv("KBBQ_NO_PASS4_PIPELINE") != nullptr || getenv("KBBQ_NO_OVERLAP") != nullptr;
+    static const uint64_t piece_env = env_u64("KBBQ_PASS4_PIECE", 0);      // tests: pieces of that many bases (rounded up to 64)
+    const uint64_t piece = piece_env ? ((piece_env + 63) >> 6) << 6 : std::max<uint64_t>(1ull << 23, ((reads->n_bases / 4 + 65535) >> 16) << 16);
+    const bool pipelined = !reads->on_device && out_on_host && !no_pipe && reads->n_bases >= 2 * piece;
+    DeferredCopy dc;
+    int rc = device_view(e, reads, &R, &max_len, true, pipelined ? &dc : nullptr);
     if (rc) return rc;
     uint8_t *d_out = qual_out;
     if (out_on_host) {
@@ -2033,25 +2051,48 @@ static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qu
     D.n_rg = e->p.n_rg; D.n_cycle = e->p.max_read_len; D.n_slots = e->dq_slots;
     const uint32_t *read_index;
     if ((rc = build_read_index(e, R, 14, e->stream, &read_index))) return rc;
-    {
+    const int per_rg = (D.n_slots * (4 * D.n_cycle + 16) + KBBQ_NQ * 2 + 3) & ~3;
+    // tables of as many read groups as fit (kernels.h: compacted over the quality axis): two 1024-lane blocks
+    // per CU share the 160 KB of LDS when one group takes at most 64 KB; otherwise one block per CU and up to 152 KB
+    const int budget = per_rg + 96 <= 64 * 1024 ? 64 * 1024 - 96 : 152 * 1024 - 96;
+    const int lds_rgs = std::max(0, std::min(D.n_rg, budget / per_rg));
+    const size_t lds = 96 + (size_t)lds_rgs * per_rg;
+    if (lds > e->attr_lds_recal) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_recalibrate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        e->attr_lds_recal = lds;
+    }
+    const int vec_ok = (((uintptr_t)R.qual | (uintptr_t)d_out) & 15) == 0;
+    auto launch = [&](uint64_t base0, uint64_t base1) -> int {      // the bases [base0, base1), base0 a multiple of 16
         Timed t(e, "k_recalibrate");
-        const uint64_t lanes = (R.n_bases + 15) / 16;
-        const int vec_ok = (((uintptr_t)R.qual | (uintptr_t)d_out) & 15) == 0;
-        const int per_rg = (D.n_slots * (4 * D.n_cycle + 16) + KBBQ_NQ * 2 + 3) & ~3;
-        // tables of as many read groups as fit (kernels.h: compacted over the quality axis): two 1024-lane blocks
-        // per CU share the 160 KB of LDS when one group takes at most 64 KB; otherwise one block per CU and up to 152 KB
-        const int budget = per_rg + 96 <= 64 * 1024 ? 64 * 1024 - 96 : 152 * 1024 - 96;
-        const int lds_rgs = std::max(0, std::min(D.n_rg, budget / per_rg));
-        const size_t lds = 96 + (size_t)lds_rgs * per_rg;
-        if (lds > e->attr_lds_recal) {
-            HIP_TRY(hipFuncSetAttribute((const void *)k_recalibrate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            e->attr_lds_recal = lds;
-        }
+        const uint64_t lanes = (base1 - base0 + 15) / 16;
         const unsigned blocks = (unsigned)std::min<uint64_t>((lanes + 1023) / 1024, lds > 76 * 1024 ? 256 : 256 * 2);
         hipLaunchKernelGGL(k_recalibrate, dim3(blocks), dim3(1024), lds, e->stream,
-                           R, D, d_out, 6, vec_ok, lds_rgs, read_index, e->d_qpresent + 3);
+                           R, D, d_out, 6, vec_ok, lds_rgs, read_index, e->d_qpresent + 3, base0, base1);
         HIP_TRY(hipGetLastError());
+        return KBBQ_OK;
+    };
+    if (pipelined) {
+        // piece i's copy in, piece i-1's kernel and piece i-2's copy out at the same time: host -> device on the copy
+        // stream, the kernel on the engine's, device -> host on the side stream (the link carries both directions at
+        // once); the kernel reads the base before its first one, which an earlier piece brought
+        const uint64_t nb = R.n_bases;
+        for (uint64_t b0 = 0; b0 < nb; b0 += piece) {
+            const uint64_t b1 = std::min(nb, b0 + piece);
+            const uint64_t w0 = b0 / 32, w1 = b1 == nb ? nb / 32 + 1 : b1 / 32, m0 = b0 / 64, m1 = b1 == nb ? nb / 64 + 1 : b1 / 64;
+            HIP_TRY(hipMemcpyAsync(dc.d_bases + w0 * 8, reads->bases + w0, (w1 - w0) * 8, hipMemcpyHostToDevice, e->copy));
+            HIP_TRY(hipMemcpyAsync(dc.d_nmask + m0 * 8, reads->nmask + m0, (m1 - m0) * 8, hipMemcpyHostToDevice, e->copy));
+            HIP_TRY(hipMemcpyAsync(dc.d_qual + b0, reads->qual + b0, b1 - b0, hipMemcpyHostToDevice, e->copy));
+            HIP_TRY(hipEventRecord(dc.slot->h2d, e->copy));      // (the guard waits for the last of them: the whole batch has left the caller's memory)
+            HIP_TRY(hipStreamWaitEvent(e->stream, dc.slot->h2d, 0));
+            if ((rc = launch(b0, b1))) return rc;
+            HIP_TRY(hipEventRecord(e->ev_main, e->stream));
+            HIP_TRY(hipStreamWaitEvent(e->stream2, e->ev_main, 0));
+            HIP_TRY(hipMemcpyAsync(qual_out + b0, d_out + b0, b1 - b0, hipMemcpyDeviceToHost, e->stream2));
+        }
+        HIP_TRY(hipStreamSynchronize(e->stream2));
+        return KBBQ_OK;
     }
+    if ((rc = launch(0, R.n_bases))) return rc;
     if (out_on_host) {
         HIP_TRY(hipMemcpyAsync(qual_out, d_out, R.n_bases, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));

@@ -1133,7 +1133,7 @@ struct DqDev {
 };
 
 __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8_t *out, int minqual, int vec_ok, int lds_rgs,
-                                                       const uint32_t *read_index, uint32_t *qflag) {
+                                                       const uint32_t *read_index, uint32_t *qflag, uint64_t base0, uint64_t base1) {
     // The delta-Q tables of the first `lds_rgs` read groups sit in LDS, compacted over the quality axis: only the
     // D.n_slots quality values that have a non-zero cycle or dinucleotide delta anywhere get a slot (D.qslot; a
     // handful for binned qualities, so a dozen read groups fit), holding per (slot, second, cycle) one int16 with
@@ -1161,7 +1161,8 @@ __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8
     }
     __syncthreads();
     // persistent blocks: the table load above is paid once per block, not once per 4 KB of qualities
-    for (uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; g0 < R.n_bases;
+    // (the launch covers the bases [base0, base1) of the batch: a host batch may arrive in pieces)
+    for (uint64_t g0 = base0 + ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; g0 < base1;
          g0 += (uint64_t)gridDim.x * blockDim.x * 16) {
     // read containing g0
     uint64_t r, start, end;

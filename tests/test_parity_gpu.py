@@ -573,3 +573,26 @@ def test_qualities_above_93_are_reported_and_handled_like_the_oracle():
     common.assert_same_run(eng, ora)
     assert eng["stats"]["quality_above_93"] is True
     assert (np.asarray(eng["recal"])[at] == 93).all()
+
+
+@pytest.mark.parametrize("piece", ["64", "4160", "70000"])
+def test_pass4_of_a_host_batch_in_pieces(piece):
+    """A large host batch with its result in host memory goes through pass 4 in pieces -- copy in, kernel and copy out of
+    successive pieces overlap on three streams (engine.hip: recalibrate_impl).  KBBQ_PASS4_PIECE shrinks the pieces so
+    that small batches cross many piece boundaries (inside reads, between reads, at 64-base word boundaries): same
+    qualities as the oracle's for uniform, ragged and many-read-group batches.  (The switch is read once per process.)"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r); import common\n"
+        "for name in ('uniform_150', 'ragged_2rg_paired', 'wide_qualities_6rg_250', 'reads_400'):\n"
+        "    maker, dkw, rkw, ekw = common.PARITY_CASES[name]\n"
+        "    d = maker(**dkw)\n"
+        "    eng = common.run_engine(d, **rkw, **dict(ekw, n_batches=2))\n"
+        "    ora = common.run_oracle(d, **rkw)\n"
+        "    common.assert_same_run(eng, ora)\n"
+        "print('ok')\n" % os.path.dirname(os.path.abspath(__file__))
+    )
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KBBQ_PASS4_PIECE=piece), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-3000:]
