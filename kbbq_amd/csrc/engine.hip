@@ -2076,6 +2076,10 @@ static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qu
         // stream, the kernel on the engine's, device -> host on the side stream (the link carries both directions at
         // once); the kernel reads the base before its first one, which an earlier piece brought
         const uint64_t nb = R.n_bases;
+        struct SideDone {      // the caller's output buffer is its own again on every return path
+            hipStream_t st;
+            ~SideDone() { (void)hipStreamSynchronize(st); }
+        } side_done{e->stream2};
         for (uint64_t b0 = 0; b0 < nb; b0 += piece) {
             const uint64_t b1 = std::min(nb, b0 + piece);
             const uint64_t w0 = b0 / 32, w1 = b1 == nb ? nb / 32 + 1 : b1 / 32, m0 = b0 / 64, m1 = b1 == nb ? nb / 64 + 1 : b1 / 64;
@@ -2089,7 +2093,7 @@ static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qu
             HIP_TRY(hipStreamWaitEvent(e->stream2, e->ev_main, 0));
             HIP_TRY(hipMemcpyAsync(qual_out + b0, d_out + b0, b1 - b0, hipMemcpyDeviceToHost, e->stream2));
         }
-        HIP_TRY(hipStreamSynchronize(e->stream2));
+        HIP_TRY(hipStreamSynchronize(e->stream2));      // (reports a failed copy; the guard's wait is then a no-op)
         return KBBQ_OK;
     }
     if ((rc = launch(0, R.n_bases))) return rc;
