@@ -78,7 +78,9 @@ def or_allreduce_(t, or_into, slab_words=1 << 26, group=None, or_pieces=None, fo
         for s in range(n_slabs):
             w_next = start_a2a(s + 1) if s + 1 < n_slabs else None
             w.wait()
-            r, m = recv[s & 1], mine[s & 1]
+            while len(gathers) >= 2:       # mine[s & 1] was the source of slab s-2's all_gather: that one first
+                gathers.pop(0).wait()      # (RCCL: a stream dependency, no host wait -- and already implied by the
+            r, m = recv[s & 1], mine[s & 1]    #  communicator's issue order; gloo runs its collectives on several threads)
             m.copy_(r[rank * piece:(rank + 1) * piece])
             if or_pieces is not None:
                 or_pieces(m, r, piece, n, rank)
@@ -87,8 +89,6 @@ def or_allreduce_(t, or_into, slab_words=1 << 26, group=None, or_pieces=None, fo
                     if j != rank:
                         or_into(m, r[j * piece:(j + 1) * piece])
             gathers.append(dist.all_gather_into_tensor(view_of(s), m, group=group, async_op=True))
-            if len(gathers) > 2:           # keeps the handle list short; its buffers were reused safely anyway
-                gathers.pop(0).wait()
             w = w_next
         for g in gathers:
             g.wait()
