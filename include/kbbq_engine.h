@@ -10,7 +10,9 @@
  *
  * Threading: one host thread per engine (the reference's passes are
  * single-threaded and non-reentrant).  All device work of
- * an engine runs on its own HIP stream (kbbq_engine_stream()).
+ * an engine runs on its own HIP streams (kbbq_engine_stream()).  Every entry point
+ * works on the engine's device and leaves the calling thread's current HIP device
+ * as it found it.
  *
  * Results are independent of batch size, batch order inside a pass (given each
  * batch's first_kmer_ordinal) and GPU count: Bloom inserts are bitwise ORs and
@@ -35,8 +37,9 @@ extern "C" {
 #define KBBQ_ESTATE (-1)    /* call out of order (e.g. trusted pass before thresholds are set) */
 
 #define KBBQ_MAX_KMER 32        /* bloom.hh:15 */
-#define KBBQ_MAXQ 93            /* covariateutils.hh:3 */
-#define KBBQ_NQ 94
+#define KBBQ_MAXQ 93            /* covariateutils.hh:3: the largest quality the MODEL proposes and the output clamp (readutils.cc:592-594) */
+#define KBBQ_NQ 256             /* quality rows of every table: an input quality is any uint8_t (a BAM can hold up to 255) and the
+                                 * reference's tables grow with the largest one seen (covariateutils.cc:65-76,102-116,147-164) */
 #define KBBQ_MAX_READ_LEN 65535 /* a read's positions travel in 16 bits (the reference has no limit: covariateutils.cc:102-116);
                                  * reads of up to 512 bases take the staged fast kernels, longer ones the windowed forms */
 #define KBBQ_DEFAULT_BLOOM_SEED 0xA5A5A5A55A5A5A5AULL   /* bloom.hh:389 */
@@ -62,6 +65,15 @@ typedef struct kbbq_params {
 } kbbq_params;
 
 #define KBBQ_F_PROFILE 1    /* time every kernel with HIP events (kbbq_profile_get) */
+/* Behavioural switches (none changes a result), fixed when the engine is created.  Each also has an environment
+ * variable, read at kbbq_engine_create when the flag is not given (README.md). */
+#define KBBQ_F_NO_OVERLAP 2          /* every kernel in order on one stream: exclusive kernel durations for profiles (KBBQ_NO_OVERLAP=1) */
+#define KBBQ_F_BUCKET_OFF 4          /* direct Bloom inserts whatever the filter size (KBBQ_BUCKET=0) */
+#define KBBQ_F_BUCKET_ON 8           /* slice-bucketed inserts whatever the filter size (KBBQ_BUCKET=1; default: filters of 256 MB and more) */
+#define KBBQ_F_LANE_WALK 16          /* the one-read-per-lane form of the correction walk for every read (KBBQ_CORRECT=lane) */
+#define KBBQ_F_NO_FASTPATH 32        /* no in-scan fast path: every read with untrusted k-mers takes the walk (KBBQ_NO_FASTPATH=1) */
+#define KBBQ_F_PASS2_INORDER 64      /* the insert side of pass 2 behind k_infer instead of beside it (KBBQ_PASS2_SIDE=0) */
+#define KBBQ_F_NO_PASS4_PIPELINE 128 /* pass 4 of a host batch in one piece (KBBQ_NO_PASS4_PIPELINE=1) */
 
 /* One batch of reads, structure of arrays.  All pointers are device pointers if
  * on_device != 0, host pointers otherwise.  A host batch is copied into one of the
@@ -136,6 +148,10 @@ void kbbq_engine_destroy(kbbq_engine *e);
 int kbbq_engine_reset(kbbq_engine *e);
 /* Block until everything submitted so far has finished. */
 int kbbq_engine_sync(kbbq_engine *e);
+/* Numeric knobs of an engine (tests and measurements; none changes a result): "bucket_records" = records gathered per
+ * flush of the slice-bucketed inserts (before the first batch; KBBQ_BUCKET_RECORDS), "pass4_piece" = bases per piece of
+ * the pass-4 pipeline of a host batch (KBBQ_PASS4_PIECE).  KBBQ_EINVAL for an unknown name. */
+int kbbq_engine_tune(kbbq_engine *e, const char *name, uint64_t value);
 /* hipStream_t of the engine, as void*. */
 void *kbbq_engine_stream(kbbq_engine *e);
 const char *kbbq_last_error(void);
@@ -234,10 +250,10 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
 /* --fixed mode (kbbq.cc:367-378): tally with caller-supplied error bits. */
 int kbbq_tally_batch(kbbq_engine *e, const kbbq_reads *reads, const uint64_t *errors);
 
-/* Dense covariate histograms, {errors,total} pairs of u64:
- *   rg    [n_rg][2]                 q     [n_rg][94][2]
- *   cycle [n_rg][94][2][max_read_len][2]   (third index: 0 first-in-pair, 1 second)
- *   dinuc [n_rg][94][16][2]         (dinuc = 4*prev + cur, covariateutils.hh:92-96) */
+/* Dense covariate histograms, {errors,total} pairs of u64 (KBBQ_NQ = 256 quality rows):
+ *   rg    [n_rg][2]                 q     [n_rg][256][2]
+ *   cycle [n_rg][256][2][max_read_len][2]   (third index: 0 first-in-pair, 1 second)
+ *   dinuc [n_rg][256][16][2]         (dinuc = 4*prev + cur, covariateutils.hh:92-96) */
 typedef struct kbbq_covariates {
     uint64_t n_rg, n_cycle;
     uint64_t *rg, *q, *cycle, *dinuc;   /* caller-allocated host arrays */
@@ -254,9 +270,9 @@ typedef struct kbbq_dq {
     uint64_t n_rg, n_cycle;
     int32_t *meanq;   /* [n_rg] */
     int32_t *rgdq;    /* [n_rg] */
-    int32_t *qdq;     /* [n_rg][94] */
-    int32_t *cycledq; /* [n_rg][94][2][n_cycle] */
-    int32_t *dinucdq; /* [n_rg][94][16] */
+    int32_t *qdq;     /* [n_rg][256] */
+    int32_t *cycledq; /* [n_rg][256][2][n_cycle] */
+    int32_t *dinucdq; /* [n_rg][256][16] */
 } kbbq_dq;
 /* Host-side model on the engine's histograms; installs the tables on the device. */
 int kbbq_train(kbbq_engine *e);
@@ -300,10 +316,9 @@ int kbbq_profile_get(kbbq_engine *e, kbbq_profile_entry *out, int32_t max_entrie
 int kbbq_profile_reset(kbbq_engine *e);
 /* Counters: [0] reads sent to the correction kernel and [1] Bloom queries issued there (pass 3), [2] reads of pass 3,
  * [3] Bloom blocks fetched by pass 2, [4],[5] flushes of the slice-bucketed inserts per filter, [6] records inserted
- * directly because a region was full, [7] records gathered per flush, [8] 1 when pass 2 or pass 4 met a quality above
- * KBBQ_MAXQ = 93 (the reference indexes past its tables for such a base, covariateutils.hh:3, readutils.cc:578-580;
- * the engine neither tallies nor recalibrates it and clamps it to 93 on output, as the final clamp of
- * readutils.cc:592-594 would).  Writes min(n, 9) values. */
+ * directly because a region was full, [7] records gathered per flush, [8] always 0 (rounds 1-2: a quality above 93 was
+ * met and left out of the model; every uint8_t quality is modelled now, as the reference's growing tables do).
+ * Writes min(n, 9) values. */
 int kbbq_stats_get(kbbq_engine *e, uint64_t *out, int32_t n);
 
 /* ---- host-only entry points (no GPU touched) --------------------------------

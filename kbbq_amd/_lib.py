@@ -21,8 +21,16 @@ c_vp = ctypes.c_void_p
 
 KBBQ_OK = 0
 KBBQ_F_PROFILE = 1
+# behavioural switches of an engine (include/kbbq_engine.h); none changes a result
+KBBQ_F_NO_OVERLAP = 2
+KBBQ_F_BUCKET_OFF = 4
+KBBQ_F_BUCKET_ON = 8
+KBBQ_F_LANE_WALK = 16
+KBBQ_F_NO_FASTPATH = 32
+KBBQ_F_PASS2_INORDER = 64
+KBBQ_F_NO_PASS4_PIPELINE = 128
 DEFAULT_BLOOM_SEED = 0xA5A5A5A55A5A5A5A
-NQ = 94
+NQ = 256
 MAX_READ_LEN = 512
 
 
@@ -70,6 +78,7 @@ SYMBOLS = {
     "kbbq_engine_reset": (ctypes.c_int, [c_vp]),
     "kbbq_engine_sync": (ctypes.c_int, [c_vp]),
     "kbbq_engine_stream": (c_vp, [c_vp]),
+    "kbbq_engine_tune": (ctypes.c_int, [c_vp, ctypes.c_char_p, c_u64]),
     "kbbq_last_error": (ctypes.c_char_p, []),
     "kbbq_filter_info_get": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.POINTER(FilterInfo)]),
     "kbbq_filter_device_table": (c_vp, [c_vp, ctypes.c_int]),

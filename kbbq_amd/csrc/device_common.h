@@ -200,6 +200,14 @@ __device__ __forceinline__ void or_bits64(uint32_t *bits, uint64_t first, uint64
     }
 }
 
+// Which quality values a kernel has met: a 256-bit set per workgroup in LDS (the reference's covariate tables grow
+// with the largest quality seen, covariateutils.cc:65-76,102-116; a quality is a uint8_t), OR-ed into the engine's
+// 8-word array when the block ends.  A look first, an LDS atomic only the first time a value shows up.
+__device__ __forceinline__ void qseen_note(uint32_t *lds_mask, uint32_t q) {
+    const uint32_t bit = 1u << (q & 31);
+    if (!(lds_mask[q >> 5] & bit)) atomicOr(&lds_mask[q >> 5], bit);
+}
+
 // select W[idx] from a small wave-uniform array without dynamic indexing
 template <int NW>
 __device__ __forceinline__ uint64_t sel_word(const uint64_t (&W)[NW], int idx) {

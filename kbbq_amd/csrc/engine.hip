@@ -40,7 +40,6 @@ static int fail(int code, const char *fmt, ...) {
 
 #include "kernels.h"
 #include "bucket.h"
-#include "lookup.h"
 #include "long_reads.h"
 
 // ============================================================ engine object
@@ -75,8 +74,25 @@ struct PendingEvent {
     hipEvent_t a, b;
 };
 
+// Behavioural switches, fixed when the engine is created: a KBBQ_F_* flag of kbbq_params.flags, or -- where no flag
+// says otherwise -- the environment variable of the same meaning (README.md) as it stands at kbbq_engine_create.
+// None changes a result.
+struct Options {
+    bool no_overlap = false;          // KBBQ_F_NO_OVERLAP / KBBQ_NO_OVERLAP: every kernel in order on one stream
+    bool no_fastpath = false;         // KBBQ_F_NO_FASTPATH / KBBQ_NO_FASTPATH: every read with untrusted k-mers takes the walk
+    bool lane_walk = false;           // KBBQ_F_LANE_WALK / KBBQ_CORRECT=lane: the one-read-per-lane form of the walk
+    bool no_pass4_pipeline = false;   // KBBQ_F_NO_PASS4_PIPELINE / KBBQ_NO_PASS4_PIPELINE: pass 4 of a host batch in one piece
+    bool pass2_side = true;           // KBBQ_F_PASS2_INORDER / KBBQ_PASS2_SIDE=0 clear it: the insert side of pass 2 beside k_infer
+    bool tally_general = false;       // KBBQ_TALLY_GENERAL: the general tally kernel for every batch shape (A/B)
+    bool debug_bucket = false;        // KBBQ_DEBUG_BUCKET: one stderr line per flush of the bucketed inserts
+    int bucket = -1;                  // KBBQ_F_BUCKET_ON / _OFF, KBBQ_BUCKET=1/0: bucketed / direct inserts; -1: by filter size
+    uint64_t bucket_records = 0;      // KBBQ_BUCKET_RECORDS: records gathered per flush (0: a share of the free HBM)
+    uint64_t pass4_piece = 0;         // KBBQ_PASS4_PIECE: piece size of pass 4's pipeline in bases (0: about a quarter of a batch)
+};
+
 struct kbbq_engine {
     kbbq_params p;
+    Options opt;
     KParams K;
     hipStream_t stream = nullptr;
     // Pass 3 alternates device-resident batches between two streams: the latency-bound correction walk and the
@@ -91,8 +107,9 @@ struct kbbq_engine {
     bool side_busy[2] = {false, false};     // counters of that side not yet added to stats
     uint64_t side_reads[2] = {0, 0};
     int side_turn = 0;
-    uint32_t *d_qpresent = nullptr;     // quality values seen by pass 2 (3 words of bits), read at kbbq_trusted_finish
-    TallyPlan tally_plan;               // quality -> LDS table slot of the tally (identity until pass 2 has spoken)
+    uint32_t *d_qpresent = nullptr;     // quality values seen by pass 2 (256 bits), read at kbbq_trusted_finish
+    uint32_t qpresent[8] = {};          // ... as read then; pass 3 on its own (--fixed mode) adds each batch's values (k_qpresence)
+    bool qpresent_known = false;        // pass 2 has finished since the last reset: its set covers every batch of pass 3
     uint8_t *d_dq_qslot = nullptr;      // apply kernel: quality -> LDS table slot (upload_dq)
     int dq_slots = 0;
     uint32_t *d_rg_present[2] = {nullptr, nullptr};     // which read groups a batch contains (run_tally), per stream
@@ -129,6 +146,7 @@ struct kbbq_engine {
     } slot[3];
     int slot_turn = 0, cur_slot = -1;
     bool cur_slot_side = false;      // the batch in cur_slot is also read on the side stream (pass 3)
+    bool cur_h2d_recorded = false;   // the slot's h2d event stands for THIS batch's copies (HostBatchDone)
     hipStream_t copy = nullptr;
     uint64_t stats[4] = {0, 0, 0, 0};
     // profiling
@@ -154,7 +172,6 @@ struct kbbq_engine {
         // whole insert side of the pass (emit, split, apply) runs beside the next batches' k_infer
         hipStream_t stream[2] = {nullptr, nullptr};
         hipEvent_t ev_flush = nullptr;       // a flush on the side stream has finished (pass boundaries wait for it)
-        bool flush_on_main = false;          // emits on the side stream, split + apply on the engine's (KBBQ_PASS2_SIDE=2)
         // the learnt estimate is read back without stopping either stream: copy into page-locked memory + event
         unsigned long long *h_inserted = nullptr;
         hipEvent_t ev_est = nullptr;
@@ -188,14 +205,28 @@ int ensure_scratch(kbbq_engine *e, int idx, size_t bytes) {
     return KBBQ_OK;
 }
 
-// quality -> slot map of the tally from the presence bits of pass 2; no bits (pass 3 used on its own) = every quality its own slot
-static void plan_tally_slots(TallyPlan &P, const uint32_t mask[3]) {
+// quality -> slot map of the tally from the presence bits (256: a quality is any uint8_t).  At most `max_slots`
+// values get a slot (what the LDS tables hold, and never more than 255: 255 means "none"); the rest -- more distinct
+// qualities than any real instrument writes -- are counted through global atomics by the kernels.
+static void plan_tally_slots(TallyPlan &P, const uint32_t mask[8], int max_slots) {
     memset(P.qslot, 255, sizeof P.qslot);
     memset(P.qof, 0, sizeof P.qof);
     P.n_slots = 0;
-    const bool none = !(mask[0] | mask[1] | mask[2]);
+    max_slots = std::max(1, std::min(max_slots, 255));
+    int top = -1;
     for (int q = 0; q < KBBQ_NQ; ++q)
-        if (none || ((mask[q >> 5] >> (q & 31)) & 1)) { P.qof[P.n_slots] = (uint8_t)q; P.qslot[q] = (uint8_t)P.n_slots++; }
+        if ((mask[q >> 5] >> (q & 31)) & 1) top = q;
+    if (top >= 0 && top + 1 <= max_slots) {
+        // few, small values (the usual FASTQ range): slot = quality, no lookup in the kernels
+        for (int q = 0; q <= top; ++q) { P.qof[q] = (uint8_t)q; P.qslot[q] = (uint8_t)q; }
+        P.n_slots = top + 1;
+        P.identity = 1;
+    } else {
+        for (int q = 0; q < KBBQ_NQ && P.n_slots < max_slots; ++q)
+            if ((mask[q >> 5] >> (q & 31)) & 1) { P.qof[P.n_slots] = (uint8_t)q; P.qslot[q] = (uint8_t)P.n_slots++; }
+        P.identity = 0;
+    }
+    if (P.n_slots == 0) { P.n_slots = 1; P.qof[0] = 0; P.qslot[0] = 0; P.identity = 1; }      // (an empty set: one unused slot)
     P.rg_base = 0; P.n_rgs = 1; P.cbase = 0;
 }
 
@@ -269,23 +300,39 @@ int sync_engine(kbbq_engine *e) {
 // guard waits for the batch's copy into its staging slot -- not for the kernels -- and notes when the slot is free.
 struct HostBatchDone {
     kbbq_engine *e;
-    HostBatchDone(kbbq_engine *e_, const kbbq_reads *) : e(e_) { e->cur_slot = -1; e->cur_slot_side = false; }
+    HostBatchDone(kbbq_engine *e_, const kbbq_reads *) : e(e_) { e->cur_slot = -1; e->cur_slot_side = false; e->cur_h2d_recorded = false; }
     ~HostBatchDone() {
         if (e->cur_slot < 0) return;
         kbbq_engine::StageSlot &s = e->slot[e->cur_slot];
         if (hipEventRecord(s.done[0], e->stream) == hipSuccess) s.busy[0] = true;
         if (e->cur_slot_side && hipEventRecord(s.done[1], e->stream2) == hipSuccess) s.busy[1] = true;
-        hipEventSynchronize(s.h2d);
+        // the event of THIS batch's copies -- or, when an error came before it could be recorded (the event then still
+        // carries the batch before), everything queued on the copy stream
+        if (e->cur_h2d_recorded) hipEventSynchronize(s.h2d);
+        else hipStreamSynchronize(e->copy);
         e->cur_slot = -1;
     }
 };
 
-// every ABI entry that takes an engine works on the engine's device, whatever the caller's current device is
+// Every ABI entry that takes an engine works on the engine's device and leaves the calling thread's current device
+// as it found it (a process that drives several GPUs, or torch with another current device, is not disturbed).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) err = hipSetDevice(device);
+        else if (err == hipSuccess) prev = -1;      // nothing to restore
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
 #define ENGINE_DEVICE(e)                                                                              \
-    do {                                                                                              \
-        if (!(e)) return fail(KBBQ_EINVAL, "null engine");                                            \
-        HIP_TRY(hipSetDevice((e)->p.device));                                                         \
-    } while (0)
+    if (!(e)) return fail(KBBQ_EINVAL, "null engine");                                                \
+    DeviceGuard engine_device_guard((e)->p.device);                                                   \
+    if (engine_device_guard.err != hipSuccess)                                                        \
+        return fail(KBBQ_EIO, "hipSetDevice(%d): %s", (e)->p.device, hipGetErrorString(engine_device_guard.err))
 
 // one non-blocking copy stream per device for uploads made before any engine exists (kept for the life of the process)
 hipStream_t shared_copy_stream(int device) {
@@ -392,6 +439,7 @@ int device_view(kbbq_engine *e, const kbbq_reads *in, ReadsDev *out, int *max_le
             HIP_TRY(hipMemcpyAsync(d + o_c, in->offcase, nb_c, hipMemcpyHostToDevice, e->copy));
         }
         HIP_TRY(hipEventRecord(sl->h2d, e->copy));
+        e->cur_h2d_recorded = true;
         HIP_TRY(hipStreamWaitEvent(e->stream, sl->h2d, 0));      // (the side stream only ever follows the main one; with `defer`: the small arrays)
         R.bases = (const uint64_t *)(d + o_b); R.nmask = (const uint64_t *)(d + o_m); R.qual = (const uint8_t *)(d + o_q);
         R.offsets = nb_o ? (const uint64_t *)(d + o_o) : nullptr;
@@ -450,7 +498,7 @@ int upload_dq(kbbq_engine *e) {
     HIP_TRY(hipMemcpyAsync(e->d_dq_dinuc, di.data(), nd, hipMemcpyHostToDevice, e->stream));
     // quality values that carry a cycle or dinucleotide delta in some read group get a slot in the apply
     // kernel's LDS tables; the others only need their base value
-    uint8_t slot[96];
+    uint8_t slot[KBBQ_NQ];
     memset(slot, 255, sizeof slot);
     int n_slots = 0;
     for (int q = 0; q < kNQ; ++q) {
@@ -460,10 +508,11 @@ int upload_dq(kbbq_engine *e) {
             for (size_t i = 0; i < 2 * d.n_cycle && !any; ++i) any = cyc[c0 + i] != 0;
             for (size_t i = 0; i < 16 && !any; ++i) any = di[d0 + i] != 0;
         }
-        if (any) slot[q] = (uint8_t)n_slots++;
+        if (any && n_slots < 255) slot[q] = (uint8_t)n_slots;      // (255 means "none"; dq_slots > 255 sends the apply kernel to its global tables)
+        if (any) ++n_slots;
     }
     e->dq_slots = n_slots;
-    HIP_TRY(hipMemcpyAsync(e->d_dq_qslot, slot, 96, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_dq_qslot, slot, KBBQ_NQ, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->dq_set = true;
     return KBBQ_OK;
@@ -475,10 +524,8 @@ uint64_t env_u64(const char *name, uint64_t dflt) {
     return v && *v ? strtoull(v, nullptr, 10) : dflt;
 }
 
-bool bucket_private() {      // level-1 regions per emitting workgroup (default) or per XCD (KBBQ_BUCKET_SHARED=1), bucket.h
-    static const bool shared = getenv("KBBQ_BUCKET_SHARED") && atoi(getenv("KBBQ_BUCKET_SHARED")) != 0;
-    return !shared;
-}
+// level-1 regions belong to the emitting workgroup (bucket.h; per-XCD shared regions were measured in round 2 and lost)
+constexpr bool bucket_private() { return true; }
 
 void bucket_shape(uint64_t n_blocks, uint64_t capacity, uint32_t *n_sub, int *nb1, uint32_t *cap1, uint32_t *cap2) {
     *n_sub = (uint32_t)((n_blocks + SUB_BLOCKS - 1) >> SUB_BITS);
@@ -513,9 +560,8 @@ const size_t kL1CntBytes = (size_t)EMIT_GRID * MAX_NB1 * 4, kL2CntBytes = (size_
 bool bucket_on(kbbq_engine *e, int w) {
     kbbq_engine::Buckets &b = e->bk;
     if (b.mode[w] >= 0) return b.mode[w] == 1;
-    const char *env = getenv("KBBQ_BUCKET");      // 0: always direct, 1: always bucketed; default: by filter size
     const uint64_t n_blocks = e->filt[w].spec.n_blocks;
-    bool want = env && *env ? atoi(env) != 0 : e->filt[w].table_bytes() >= (256u << 20);
+    bool want = e->opt.bucket >= 0 ? e->opt.bucket != 0 : e->filt[w].table_bytes() >= (256u << 20);
     if (n_blocks > ((uint64_t)MAX_NB1 << L1_SHIFT)) want = false;
     if (want && !b.allocated) {
         size_t free_b = 0, total_b = 0;
@@ -524,7 +570,7 @@ bool bucket_on(kbbq_engine *e, int w) {
         uint64_t cap = (uint64_t)((double)free_b * 0.45 / 14.5);
         cap = std::min<uint64_t>(cap, 4000000000ULL);
         cap = std::min<uint64_t>(cap, std::max<uint64_t>(1u << 20, 32 * big));
-        cap = env_u64("KBBQ_BUCKET_RECORDS", cap);
+        if (e->opt.bucket_records) cap = e->opt.bucket_records;
         cap = std::max<uint64_t>(cap, 4096);
         size_t l1_bytes = 0, l2_bytes = 0;
         for (int f = 0; f < 2; ++f) {
@@ -569,8 +615,7 @@ void bucket_poll_estimate(kbbq_engine *e) {
         b.frac_trusted = std::min(1.0, 1.03 * (double)(now - b.est_prev) / (double)b.est_bases + 0.005);
     b.inserted_at_flush[1] = now;
     b.est_pending = false;
-    static const bool debug = getenv("KBBQ_DEBUG_BUCKET") != nullptr;
-    if (debug) fprintf(stderr, "[bucket] inserted %llu (before %llu) over %llu bases -> %.4f trusted inserts per base\n", now,
+    if (e->opt.debug_bucket) fprintf(stderr, "[bucket] inserted %llu (before %llu) over %llu bases -> %.4f trusted inserts per base\n", now,
                        (unsigned long long)b.est_prev, (unsigned long long)b.est_bases, b.frac_trusted);
 }
 
@@ -583,14 +628,7 @@ int bucket_flush(kbbq_engine *e, int w, bool barrier = true) {
     const BucketDev B = bucket_dev(e, w);
     const FiltDev F = e->filt[w].dev();
     const hipStream_t emit_st = bucket_stream(e, w);
-    // split + apply where the emits ran, or -- pass 2 with only the emits on the side stream -- on the engine's stream
-    // once the emits are through (and the side stream's later emits wait for the flush in turn)
-    const bool hop = w == 1 && b.flush_on_main && emit_st != e->stream;
-    hipStream_t st = hop ? e->stream : emit_st;
-    if (hop) {
-        HIP_TRY(hipEventRecord(b.ev_flush, emit_st));
-        HIP_TRY(hipStreamWaitEvent(st, b.ev_flush, 0));
-    }
+    hipStream_t st = emit_st;
     HIP_TRY(hipMemsetAsync(b.tickets, 0, kTicketBytes, st));
     {
         Timed t(e, w ? "k_split_trusted" : "k_split_sampled", st);
@@ -605,10 +643,7 @@ int bucket_flush(kbbq_engine *e, int w, bool barrier = true) {
     }
     HIP_TRY(hipMemsetAsync(b.l1_cnt, 0, kL1CntBytes, st));
     HIP_TRY(hipMemsetAsync(b.l2_cnt, 0, (size_t)B.nb1 * NB2 * 4, st));
-    if (hop) {
-        HIP_TRY(hipEventRecord(b.ev_flush, st));
-        HIP_TRY(hipStreamWaitEvent(emit_st, b.ev_flush, 0));
-    } else if (st != e->stream && barrier) {
+    if (st != e->stream && barrier) {
         HIP_TRY(hipEventRecord(b.ev_flush, st));
         HIP_TRY(hipStreamWaitEvent(e->stream, b.ev_flush, 0));
     }
@@ -634,8 +669,7 @@ int bucket_flush(kbbq_engine *e, int w, bool barrier = true) {
         }
     }
     {
-        static const bool debug = getenv("KBBQ_DEBUG_BUCKET") != nullptr;
-        if (debug) fprintf(stderr, "[bucket] flush %d of filter %d: estimate %.3g records over %llu bases (%.4f per base), barrier %d\n",
+        if (e->opt.debug_bucket) fprintf(stderr, "[bucket] flush %d of filter %d: estimate %.3g records over %llu bases (%.4f per base), barrier %d\n",
                            (int)b.flushes[w], w, b.pending_est[w], (unsigned long long)b.bases_since[w], w ? b.frac_trusted : 0.0, (int)barrier);
     }
     b.bases_since[w] = 0;
@@ -688,9 +722,26 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(KBBQ_ENODEV, "no HIP device visible");
     if (params->device < 0 || params->device >= ndev) return fail(KBBQ_ENODEV, "device %d of %d", params->device, ndev);
-    HIP_TRY(hipSetDevice(params->device));
+    DeviceGuard create_guard(params->device);      // (the caller's current device is restored on return)
+    HIP_TRY(create_guard.err);
     kbbq_engine *e = new kbbq_engine;
     e->p = *params;
+    {
+        Options &o = e->opt;
+        auto env_set = [](const char *name) { const char *v = getenv(name); return v && *v; };
+        auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; };
+        const int fl = params->flags;
+        o.no_overlap = (fl & KBBQ_F_NO_OVERLAP) || env_set("KBBQ_NO_OVERLAP");
+        o.no_fastpath = (fl & KBBQ_F_NO_FASTPATH) || env_set("KBBQ_NO_FASTPATH");
+        o.lane_walk = (fl & KBBQ_F_LANE_WALK) || (getenv("KBBQ_CORRECT") && !strcmp(getenv("KBBQ_CORRECT"), "lane"));
+        o.no_pass4_pipeline = (fl & KBBQ_F_NO_PASS4_PIPELINE) || env_set("KBBQ_NO_PASS4_PIPELINE") || o.no_overlap;
+        o.pass2_side = !(fl & KBBQ_F_PASS2_INORDER) && env_int("KBBQ_PASS2_SIDE", 1) != 0 && !o.no_overlap;
+        o.tally_general = env_set("KBBQ_TALLY_GENERAL");
+        o.debug_bucket = env_set("KBBQ_DEBUG_BUCKET");
+        o.bucket = (fl & KBBQ_F_BUCKET_ON) ? 1 : (fl & KBBQ_F_BUCKET_OFF) ? 0 : env_set("KBBQ_BUCKET") ? (env_int("KBBQ_BUCKET", 0) != 0 ? 1 : 0) : -1;
+        o.bucket_records = env_u64("KBBQ_BUCKET_RECORDS", 0);
+        o.pass4_piece = env_u64("KBBQ_PASS4_PIECE", 0);
+    }
     e->K.k = params->k;
     e->K.shift = 2u * (unsigned)(params->k - 1);
     e->K.mask = params->k < 32 ? ((1ULL << (2 * params->k)) - 1) : ~0ULL;
@@ -735,8 +786,8 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
     CREATE_TRY(hipMalloc(&e->d_counters, 64));
     CREATE_TRY(hipMemset(e->d_counters, 0, 64));
     e->cur_cnt = e->d_counters;
-    CREATE_TRY(hipMalloc(&e->d_dq_qslot, 96));
-    CREATE_TRY(hipMalloc(&e->d_qpresent, 16));
+    CREATE_TRY(hipMalloc(&e->d_dq_qslot, KBBQ_NQ));
+    CREATE_TRY(hipMalloc(&e->d_qpresent, 32));
     for (int i = 0; i < 2; ++i) CREATE_TRY(hipMalloc(&e->d_rg_present[i], (((size_t)params->n_rg + 31) / 32) * 4 + 4));
     for (int w = 0; w < 2; ++w) {
         FilterHost &f = e->filt[w];
@@ -770,7 +821,7 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
 
 void kbbq_engine_destroy(kbbq_engine *e) {
     if (!e) return;
-    hipSetDevice(e->p.device);
+    DeviceGuard destroy_guard(e->p.device);
     if (e->stream) { hipStreamSynchronize(e->stream); }
     if (e->stream2) hipStreamSynchronize(e->stream2);
     if (e->copy) hipStreamSynchronize(e->copy);
@@ -824,7 +875,9 @@ int kbbq_engine_reset(kbbq_engine *e) {
     }
     HIP_TRY(hipMemsetAsync(e->d_hist, 0, (e->hist_cycle_words + e->hist_dinuc_words) * 8, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_counters, 0, 64, e->stream));
-    HIP_TRY(hipMemsetAsync(e->d_qpresent, 0, 16, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_qpresent, 0, 32, e->stream));
+    memset(e->qpresent, 0, sizeof e->qpresent);
+    e->qpresent_known = false;
     if (e->bk.allocated) {      // records gathered for the old filters are dropped
         HIP_TRY(hipMemsetAsync(e->bk.l1_cnt, 0, kL1CntBytes, e->stream));
         HIP_TRY(hipMemsetAsync(e->bk.l2_cnt, 0, kL2CntBytes, e->stream));
@@ -835,10 +888,6 @@ int kbbq_engine_reset(kbbq_engine *e) {
     e->bk.frac_trusted = 0.75;
     e->bk.stream[0] = e->bk.stream[1] = nullptr;
     for (int w = 0; w < 2; ++w) { e->bk.pending[w] = false; e->bk.pending_est[w] = 0; e->bk.bases_since[w] = 0; e->bk.inserted_at_flush[w] = 0; e->bk.flushes[w] = 0; }
-    {
-        const uint32_t none[3] = {0, 0, 0};
-        plan_tally_slots(e->tally_plan, none);
-    }
     e->thresholds_set = false;
     e->dq_set = false;
     memset(e->stats, 0, sizeof e->stats);
@@ -853,6 +902,19 @@ int kbbq_engine_sync(kbbq_engine *e) {
 }
 
 void *kbbq_engine_stream(kbbq_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+int kbbq_engine_tune(kbbq_engine *e, const char *name, uint64_t value) {
+    if (!e || !name) return fail(KBBQ_EINVAL, "null argument");
+    if (!strcmp(name, "bucket_records")) {
+        if (e->bk.allocated) return fail(KBBQ_ESTATE, "the record buffers are allocated already");
+        e->opt.bucket_records = value;
+    } else if (!strcmp(name, "pass4_piece")) {
+        e->opt.pass4_piece = value;
+    } else {
+        return fail(KBBQ_EINVAL, "unknown knob '%s'", name);
+    }
+    return KBBQ_OK;
+}
 
 int kbbq_filter_info_get(kbbq_engine *e, int which, kbbq_filter_info *out) {
     ENGINE_DEVICE(e);
@@ -876,7 +938,8 @@ int kbbq_filter_info_get(kbbq_engine *e, int which, kbbq_filter_info *out) {
 
 void *kbbq_filter_device_table(kbbq_engine *e, int which) {
     if (!e || which < 0 || which > 1) return nullptr;
-    if (hipSetDevice(e->p.device) != hipSuccess || bucket_flush_all(e) != KBBQ_OK) return nullptr;      // the array is about to be read
+    DeviceGuard guard(e->p.device);
+    if (guard.err != hipSuccess || bucket_flush_all(e) != KBBQ_OK) return nullptr;      // the array is about to be read
     return e->filt[which].d_table;
 }
 void *kbbq_filter_device_counter(kbbq_engine *e, int which) { return e && which >= 0 && which < 2 ? e->filt[which].d_inserted : nullptr; }
@@ -1031,7 +1094,10 @@ int kbbq_pack_bases_case(const uint8_t *seq, uint64_t n_bases, uint64_t *bases_o
 int kbbq_reads_upload(kbbq_engine *e, const kbbq_reads *host, kbbq_reads *dev) {
     // e may be NULL: batches can be made resident before the engine (whose size depends on them) exists
     if (!host || !dev) return fail(KBBQ_EINVAL, "null argument");
-    if (e) HIP_TRY(hipSetDevice(e->p.device));
+    int cur_dev = 0;
+    HIP_TRY(hipGetDevice(&cur_dev));
+    DeviceGuard guard(e ? e->p.device : cur_dev);
+    HIP_TRY(guard.err);
     if (host->on_device) return fail(KBBQ_EINVAL, "batch is already on the device");
     *dev = *host;
     dev->on_device = 1;
@@ -1090,7 +1156,10 @@ int kbbq_host_free(void *p) {
 
 int kbbq_measure_host_link(int32_t device, uint64_t bytes, double *h2d_gbps, double *d2h_gbps) {
     if (!bytes) return fail(KBBQ_EINVAL, "bad argument");
-    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    int cur_dev = 0;
+    HIP_TRY(hipGetDevice(&cur_dev));
+    DeviceGuard guard(device >= 0 ? device : cur_dev);
+    HIP_TRY(guard.err);
     void *h = nullptr, *d = nullptr;
     hipEvent_t a = nullptr, b = nullptr;
     hipStream_t st = nullptr;
@@ -1131,8 +1200,11 @@ int kbbq_measure_host_link(int32_t device, uint64_t bytes, double *h2d_gbps, dou
 int kbbq_reads_free(kbbq_engine *e, kbbq_reads *dev) {
     if (!dev) return fail(KBBQ_EINVAL, "null argument");
     if (!dev->on_device) return fail(KBBQ_EINVAL, "not a device batch");
+    int cur_dev = 0;
+    HIP_TRY(hipGetDevice(&cur_dev));
+    DeviceGuard guard(e ? e->p.device : cur_dev);
+    HIP_TRY(guard.err);
     if (e) {
-        HIP_TRY(hipSetDevice(e->p.device));
         int rc = sync_engine(e);
         if (rc) return rc;
     } else {
@@ -1225,26 +1297,20 @@ static int launch_emit(kbbq_engine *e, int w, ReadsDev R, const uint64_t *mask, 
     const size_t lds = (size_t)8 * RPW * CH * 64 * 8;
     hipStream_t st = bucket_stream(e, w);
     Timed t(e, w ? "k_emit_trusted" : "k_emit_sampled", st);
-    static const bool dense = !(getenv("KBBQ_EMIT_DENSE") && atoi(getenv("KBBQ_EMIT_DENSE")) == 0);      // A/B: hash every lane of every chunk
-#define KBBQ_EMIT(BYB, PRIV)                                                                                                  \
+    // (level-1 regions per emitting workgroup, only the marked k-mers hashed: the round-2 winners of bucket.h's variants)
+#define KBBQ_EMIT(BYB)                                                                                                        \
     do {                                                                                                                      \
-        if (dense) KBBQ_EMIT2(BYB, PRIV, true); else KBBQ_EMIT2(BYB, PRIV, false);                                            \
-    } while (0)
-#define KBBQ_EMIT2(BYB, PRIV, DENSE)                                                                                          \
-    do {                                                                                                                      \
-        const void *fn = (const void *)k_emit_marked<NW, CH, BYB, RPW, PRIV, DENSE>;                                           \
+        const void *fn = (const void *)k_emit_marked<NW, CH, BYB, RPW, true, true>;                                            \
         size_t &raised = e->attr_lds_correct[fn];                                                                             \
         if (lds > 48 * 1024 && lds > raised) {                                                                                \
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
             raised = lds;                                                                                                     \
         }                                                                                                                     \
-        hipLaunchKernelGGL((k_emit_marked<NW, CH, BYB, RPW, PRIV, DENSE>), dim3(grid), dim3(BK_THREADS), lds, st, R, e->K,     \
+        hipLaunchKernelGGL((k_emit_marked<NW, CH, BYB, RPW, true, true>), dim3(grid), dim3(BK_THREADS), lds, st, R, e->K,      \
                            e->filt[w].dev(), B, mask, mask_words, kofs, inserted);                                            \
     } while (0)
-    if (bucket_private()) { if (w == 0) KBBQ_EMIT(false, true); else KBBQ_EMIT(true, true); }
-    else                  { if (w == 0) KBBQ_EMIT(false, false); else KBBQ_EMIT(true, false); }
+    if (w == 0) KBBQ_EMIT(false); else KBBQ_EMIT(true);
 #undef KBBQ_EMIT
-#undef KBBQ_EMIT2
     HIP_TRY(hipGetLastError());
     return KBBQ_OK;
 }
@@ -1253,11 +1319,8 @@ static int launch_emit(kbbq_engine *e, int w, ReadsDev R, const uint64_t *mask, 
 static int dispatch_emit(kbbq_engine *e, int w, int max_len, ReadsDev R, const uint64_t *mask, uint64_t mask_words, const uint64_t *kofs,
                          unsigned long long *inserted) {
     const int max_nk = std::max(1, max_len - e->p.k + 1);
-    static const int rpw8 = getenv("KBBQ_EMIT_RPW") ? atoi(getenv("KBBQ_EMIT_RPW")) : 0;
-    if (max_len <= 192) {
-        if (max_nk <= 128) return rpw8 == 8 ? launch_emit<3, 2, 8>(e, w, R, mask, mask_words, kofs, inserted)
-                                 : rpw8 == 2 ? launch_emit<3, 2, 2>(e, w, R, mask, mask_words, kofs, inserted)
-                                            : launch_emit<3, 2, 4>(e, w, R, mask, mask_words, kofs, inserted);
+    if (max_len <= 192) {      // four reads per emitting wave (two and eight were measured in round 2: no better)
+        if (max_nk <= 128) return launch_emit<3, 2, 4>(e, w, R, mask, mask_words, kofs, inserted);
         return launch_emit<3, 3, 4>(e, w, R, mask, mask_words, kofs, inserted);
     }
     if (max_len <= 320) return launch_emit<5, 5, 2>(e, w, R, mask, mask_words, kofs, inserted);
@@ -1276,8 +1339,7 @@ int kbbq_sample_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t first_km
     const uint64_t *kofs; uint64_t n_draws;
     if ((rc = kmer_prefix(e, R, &kofs, &n_draws))) return rc;
     if (n_draws == 0) return KBBQ_OK;
-    static const bool no_overlap = getenv("KBBQ_NO_OVERLAP") != nullptr;
-    const bool overlap = reads->on_device && !no_overlap;
+    const bool overlap = reads->on_device && !e->opt.no_overlap;
     const int turn = overlap ? e->draw_turn : 0;
     const int slot = turn ? 13 : 0;
     if ((rc = ensure_scratch(e, slot, (n_draws / 64 + 2) * 8))) return rc;
@@ -1369,137 +1431,6 @@ int kbbq_set_thresholds(kbbq_engine *e, const int32_t *thresholds, int32_t n) {
 }  // extern "C"
 
 
-// ---- measurement harness for slice-bucketed LOOKUPS (lookup.h): KBBQ_LOOKUP_PROBE=1 runs the whole chain for every
-// uniform short-read batch of pass 2, after the product's k_infer, into buffers of its own; nothing it computes is used
-// except -- KBBQ_LOOKUP_PROBE=2 -- to compare its insert decisions with k_infer's (a mismatch count on stderr).
-struct LookupProbe {
-    bool ready = false;
-    uint64_t for_bases = 0;
-    LookupDev B;
-    IdsDev D;
-    uint32_t *take = nullptr, *mismatch = nullptr;
-    unsigned long long *dummy = nullptr;
-    size_t l1cnt_bytes = 0, l2cnt_bytes = 0, dcnt_bytes = 0, bits_bytes = 0;
-};
-static LookupProbe g_probe;
-
-__global__ void k_count_diff(const uint32_t *a, const uint32_t *b, uint64_t n, uint32_t *out) {
-    uint32_t d = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) d += __popc(a[i] ^ b[i]);
-    if (d) atomicAdd(out, d);
-}
-
-static int lookup_probe(kbbq_engine *e, const ReadsDev &R, const Thresholds &thr, const uint32_t *take_ref, int level) {
-    LookupProbe &P = g_probe;
-    const FiltDev F = e->filt[0].dev();
-    if (!P.ready || P.for_bases < R.n_bases) {
-        if (P.ready) return KBBQ_OK;      // (sized by the first batch; a larger one later is skipped)
-        const uint64_t room_bases = R.n_bases + R.n_bases / 4;      // (later batches may be a little larger)
-        const double records = 0.8 * (double)room_bases + 65536.0;
-        const double emitters = (double)std::min<uint64_t>((R.n_reads + 31) / 32, EMIT_GRID);
-        const uint64_t n_blocks = F.n_blocks;
-        LookupDev &B = P.B;
-        B.n_sub = (uint32_t)((n_blocks + SUB_BLOCKS - 1) >> SUB_BITS);
-        B.nb1 = (int)((B.n_sub + NB2 - 1) >> NB2_BITS);
-        const double f1 = std::min(1.0, (double)(1ULL << L1_SHIFT) / (double)n_blocks), f2 = std::min(1.0, (double)SUB_BLOCKS / (double)n_blocks);
-        B.cap1 = (uint32_t)(records * 1.15 * f1 / emitters) + 64;
-        B.cap2 = (uint32_t)(records * 1.25 * f2) + 32;
-        B.cap_abs = (uint32_t)(records * 0.4 / N_XCD * 1.3) + 1024;
-        P.l1cnt_bytes = (size_t)EMIT_GRID * B.nb1 * 4;
-        P.l2cnt_bytes = (size_t)B.nb1 * NB2 * 4;
-        P.bits_bytes = (room_bases / 64 + 2) * 8;
-        IdsDev &D = P.D;
-        D.n_bins = (int)((room_bases >> IDS_BIN_BITS) + 1);
-        if (D.n_bins > 512) return KBBQ_OK;
-        D.cap = (uint32_t)(records * 0.4 / IDS_GRID / D.n_bins * 1.5) + 256;
-        P.dcnt_bytes = (size_t)IDS_GRID * D.n_bins * 4;
-        HIP_TRY(hipMalloc(&B.l1, (size_t)EMIT_GRID * B.nb1 * B.cap1 * 8));
-        HIP_TRY(hipMalloc(&B.l1id, (size_t)EMIT_GRID * B.nb1 * B.cap1 * 4));
-        HIP_TRY(hipMalloc(&B.l2, (size_t)B.nb1 * NB2 * B.cap2 * 8));
-        HIP_TRY(hipMalloc(&B.l1_cnt, P.l1cnt_bytes));
-        HIP_TRY(hipMalloc(&B.l2_cnt, P.l2cnt_bytes));
-        HIP_TRY(hipMalloc(&B.tickets, kTicketBytes));
-        HIP_TRY(hipMalloc(&B.abs_cnt, kTicketBytes));
-        HIP_TRY(hipMalloc(&B.abs_list, (size_t)N_XCD * B.cap_abs * 4));
-        HIP_TRY(hipMalloc(&B.absent_bits, P.bits_bytes));
-        HIP_TRY(hipMalloc(&B.direct, 8));
-        HIP_TRY(hipMalloc(&D.regions, (size_t)IDS_GRID * D.n_bins * D.cap * 4));
-        HIP_TRY(hipMalloc(&D.cnt, P.dcnt_bytes));
-        HIP_TRY(hipMalloc(&P.take, P.bits_bytes));
-        HIP_TRY(hipMalloc(&P.dummy, 64));
-        HIP_TRY(hipMalloc(&P.mismatch, 64));
-        HIP_TRY(hipMemsetAsync(B.direct, 0, 8, e->stream));
-        HIP_TRY(hipMemsetAsync(P.dummy, 0, 64, e->stream));
-        P.ready = true;
-        P.for_bases = room_bases;
-        fprintf(stderr, "[lookup probe] nb1 %d n_sub %u cap1 %u cap2 %u cap_abs %u bins %d cap %u\n", B.nb1, B.n_sub, B.cap1, B.cap2, B.cap_abs,
-                D.n_bins, D.cap);
-    }
-    const LookupDev &B = P.B;
-    const IdsDev &D = P.D;
-    hipStream_t st = e->stream;
-    HIP_TRY(hipMemsetAsync(B.l1_cnt, 0, P.l1cnt_bytes, st));
-    HIP_TRY(hipMemsetAsync(B.l2_cnt, 0, P.l2cnt_bytes, st));
-    HIP_TRY(hipMemsetAsync(B.tickets, 0, kTicketBytes, st));
-    HIP_TRY(hipMemsetAsync(B.abs_cnt, 0, kTicketBytes, st));
-    HIP_TRY(hipMemsetAsync(B.absent_bits, 0, P.bits_bytes, st));
-    HIP_TRY(hipMemsetAsync(D.cnt, 0, P.dcnt_bytes, st));
-    HIP_TRY(hipMemsetAsync(P.take, 0, P.bits_bytes, st));
-    {
-        Timed t(e, "probe_emit_lookup");
-        const void *fn = (const void *)k_emit_lookup<3, 2, 4>;
-        const size_t lds = (size_t)8 * 4 * 2 * 64 * 12;
-        size_t &raised = e->attr_lds_correct[fn];
-        if (lds > raised) { HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); raised = lds; }
-        const uint64_t n_tiles = (R.n_reads + 31) / 32;
-        hipLaunchKernelGGL((k_emit_lookup<3, 2, 4>), dim3((unsigned)std::min<uint64_t>(n_tiles, EMIT_GRID)), dim3(BK_THREADS), lds, st, R, e->K, F, B,
-                           0u, P.dummy);
-        HIP_TRY(hipGetLastError());
-    }
-    {
-        Timed t(e, "probe_split_lookup");
-        hipLaunchKernelGGL(k_split_lookup, dim3(256 * 2), dim3(BK_THREADS), 0, st, F, B, (B.cap1 + LSPLIT_TILE - 1) / LSPLIT_TILE);
-        HIP_TRY(hipGetLastError());
-    }
-    {
-        Timed t(e, "probe_apply_lookup");
-        hipLaunchKernelGGL(k_apply_lookup, dim3(B.n_sub), dim3(APPLY_THREADS), 0, st, F, B);
-        HIP_TRY(hipGetLastError());
-    }
-    {
-        Timed t(e, "probe_scatter_ids");
-        hipLaunchKernelGGL(k_scatter_ids, dim3(IDS_GRID), dim3(BK_THREADS), 0, st, B, D);
-        HIP_TRY(hipGetLastError());
-    }
-    {
-        Timed t(e, "probe_ids_to_bits");
-        const void *fn = (const void *)k_ids_to_bits;
-        const size_t lds = 128 * 1024;
-        size_t &raised = e->attr_lds_correct[fn];
-        if (lds > raised) { HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); raised = lds; }
-        hipLaunchKernelGGL(k_ids_to_bits, dim3(D.n_bins * 4), dim3(1024), lds, st, B, D, (uint32_t)R.n_bases);
-        HIP_TRY(hipGetLastError());
-    }
-    {
-        Timed t(e, "probe_infer_deferred");
-        hipLaunchKernelGGL((k_infer<3, 1, true>), dim3(wave_grid(R.n_reads)), dim3(256), 0, st, R, e->K, F, thr, P.take, P.dummy, (uint32_t *)nullptr,
-                           (uint32_t *)(P.dummy + 2), P.dummy + 1, (const uint64_t *)B.absent_bits);
-        HIP_TRY(hipGetLastError());
-    }
-    if (level >= 2) {
-        uint32_t h[2] = {0, 0};
-        unsigned long long direct = 0;
-        HIP_TRY(hipMemsetAsync(P.mismatch, 0, 8, st));
-        hipLaunchKernelGGL(k_count_diff, dim3(1024), dim3(256), 0, st, (const uint32_t *)P.take, take_ref, (R.n_bases / 64 + 1) * 2, P.mismatch);
-        HIP_TRY(hipMemcpyAsync(h, P.mismatch, 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(&direct, B.direct, 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        fprintf(stderr, "[lookup probe] %llu reads: insert decisions differing from k_infer's: %u; overflow records so far %llu\n",
-                (unsigned long long)R.n_reads, h[0], direct);
-    }
-    return KBBQ_OK;
-}
-
 template <int NW> struct LaunchTrusted {
     static int go(kbbq_engine *e, ReadsDev R, uint32_t *take_bits, uint32_t *err_out, int max_len) {
         Thresholds thr;
@@ -1507,41 +1438,25 @@ template <int NW> struct LaunchTrusted {
         for (size_t i = 0; i < e->thresholds.size() && i <= KBBQ_MAX_KMER; ++i) thr.v[i] = e->thresholds[i];
         {
             Timed t(e, "k_infer");
-            static const int occ = getenv("KBBQ_INFER_OCC") ? atoi(getenv("KBBQ_INFER_OCC")) : 0;
-            static const int per_cu = getenv("KBBQ_INFER_BLOCKS") ? atoi(getenv("KBBQ_INFER_BLOCKS")) : 0;
-            if (per_cu > 0)
-                hipLaunchKernelGGL(k_infer<NW>, dim3(std::min(wave_grid(R.n_reads), 256 * per_cu)), dim3(256), 0, e->stream, R, e->K,
-                                   e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3, (const uint64_t *)nullptr);
-            else if (occ == 8)
-                hipLaunchKernelGGL((k_infer<NW, 8>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
-                                   e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3, (const uint64_t *)nullptr);
-            else if (occ == 7)
-                hipLaunchKernelGGL((k_infer<NW, 7>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
-                                   e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3, (const uint64_t *)nullptr);
+            // NK: chunks of 64 lanes that can hold a k-mer start (150-base reads, k = 32: 119 starts, two of the three chunks)
+            if (std::max(1, max_len - e->p.k + 1) <= (NW - 1) * 64)
+                hipLaunchKernelGGL((k_infer<NW, NW - 1>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
+                                   e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3);
             else
-            hipLaunchKernelGGL(k_infer<NW>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
-                               e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3, (const uint64_t *)nullptr);
+                hipLaunchKernelGGL((k_infer<NW, NW>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
+                                   e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3);
             HIP_TRY(hipGetLastError());
-        }
-        {
-            static const int probe = getenv("KBBQ_LOOKUP_PROBE") ? atoi(getenv("KBBQ_LOOKUP_PROBE")) : 0;
-            if (probe && NW == 3 && !R.offsets && max_len - e->p.k + 1 <= 128 && R.n_bases < (1ull << 31)) {
-                int prc = lookup_probe(e, R, thr, take_bits, probe);
-                if (prc) return prc;
-            }
         }
         if (bucket_on(e, 1)) {
             // The insert side of pass 2 -- emit, and split + apply whenever the record buffers fill -- runs on the
             // side stream: it is ALU-, streaming- and L2-bound, k_infer is bound by random HBM lines, so batch i's
             // inserts run beside batch i+1's k_infer.  (Overflow records are inserted directly by the emit kernel:
-            // on the same stream as k_apply, so the two never touch the trusted filter at the same time.)
-            // Off by default: measured +2.4 % on the 30x workload (profiles/r02_bench_full_i_{side,noside}.json) -- the side
-            // kernels mostly take turns with k_infer's waves rather than run beside them -- at the price of kernel durations
-            // that are no longer exclusive in pass 2 (k_infer is the kernel the roofline is quoted for).  KBBQ_PASS2_SIDE=1.
-            static const int side_mode = getenv("KBBQ_PASS2_SIDE") && !getenv("KBBQ_NO_OVERLAP") ? atoi(getenv("KBBQ_PASS2_SIDE")) : 0;
-            const bool side = side_mode != 0;      // 1: emit, split, apply on the side stream; 2: the emits only
+            // on the same stream as k_apply, so the two never touch the trusted filter at the same time; the direct
+            // inserts of long reads are ordered against that stream by events, kbbq_trusted_batch.)
+            // Measured +2.4 % on the 30x workload (profiles/r02_bench_full_i_{side,noside}.json); the exclusive duration
+            // of k_infer -- the kernel the roofline is quoted for -- comes from the in-order run (KBBQ_F_NO_OVERLAP).
+            const bool side = e->opt.pass2_side;
             e->bk.stream[1] = side ? e->stream2 : e->stream;
-            e->bk.flush_on_main = side_mode == 2;
             if (side) {
                 HIP_TRY(hipEventRecord(e->ev_infer, e->stream));
                 HIP_TRY(hipStreamWaitEvent(e->stream2, e->ev_infer, 0));
@@ -1625,10 +1540,24 @@ int kbbq_trusted_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *infer_
                                e->filt[1].d_inserted, d_err, e->d_qpresent, e->d_counters + 3);
             HIP_TRY(hipGetLastError());
         }
-        Timed t(e, "k_insert_trusted_long");
-        hipLaunchKernelGGL(k_insert_marked_long<true>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K, e->filt[1].dev(),
-                           (const uint64_t *)take_bits, R.n_bases / 64 + 2, (const uint64_t *)nullptr, (unsigned long long *)nullptr);
-        HIP_TRY(hipGetLastError());
+        // These inserts are atomic ORs straight into the trusted filter.  Batches of short reads of the same pass may have
+        // records pending, or a flush (k_apply: load a slice, OR, store it back -- no atomics) running, on the side
+        // stream: the direct inserts wait for what is queued there, and what is queued there later waits for them.
+        const bool side_busy = e->bk.stream[1] && e->bk.stream[1] != e->stream;
+        if (side_busy) {
+            HIP_TRY(hipEventRecord(e->bk.ev_flush, e->bk.stream[1]));
+            HIP_TRY(hipStreamWaitEvent(e->stream, e->bk.ev_flush, 0));
+        }
+        {
+            Timed t(e, "k_insert_trusted_long");
+            hipLaunchKernelGGL(k_insert_marked_long<true>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K, e->filt[1].dev(),
+                               (const uint64_t *)take_bits, R.n_bases / 64 + 2, (const uint64_t *)nullptr, (unsigned long long *)nullptr);
+            HIP_TRY(hipGetLastError());
+        }
+        if (side_busy) {
+            HIP_TRY(hipEventRecord(e->ev_infer, e->stream));
+            HIP_TRY(hipStreamWaitEvent(e->bk.stream[1], e->ev_infer, 0));
+        }
     } else if ((rc = dispatch_nw<LaunchTrusted>(max_len, e, R, take_bits, d_err, max_len))) return rc;
     if (take_slot >= 0 && bucket_stream(e, 1) != e->stream && e->bk.mode[1] == 1 && max_len <= kStagedMax) {
         HIP_TRY(hipEventRecord(e->ev_take[take_slot], bucket_stream(e, 1)));      // the emit has read this scratch array
@@ -1644,11 +1573,8 @@ int kbbq_trusted_finish(kbbq_engine *e, uint64_t *inserted) {
     if (!e) return fail(KBBQ_EINVAL, "null engine");
     int rc = sync_engine(e);
     if (rc) return rc;
-    {
-        uint32_t mask[4] = {0, 0, 0, 0};
-        HIP_TRY(hipMemcpy(mask, e->d_qpresent, 16, hipMemcpyDeviceToHost));
-        plan_tally_slots(e->tally_plan, mask);
-    }
+    HIP_TRY(hipMemcpy(e->qpresent, e->d_qpresent, 32, hipMemcpyDeviceToHost));      // the tally sizes its LDS tables by these (run_tally)
+    e->qpresent_known = true;
     if (inserted) HIP_TRY(hipMemcpy(inserted, e->filt[1].d_inserted, 8, hipMemcpyDeviceToHost));
     return KBBQ_OK;
 }
@@ -1657,19 +1583,14 @@ int kbbq_trusted_finish(kbbq_engine *e, uint64_t *inserted) {
 }  // extern "C"
 
 template <int NW> struct LaunchScan {
-    static int go(kbbq_engine *e, ReadsDev R, uint64_t *tmask, uint8_t *dirty, uint32_t *err_bits, int fast) {
+    static int go(kbbq_engine *e, ReadsDev R, uint64_t *tmask, uint8_t *dirty, uint32_t *err_bits, int fast, int max_len) {
         Timed t(e, "k_scan_trusted", e->cur);
-        static const int occ = getenv("KBBQ_SCAN_OCC") ? atoi(getenv("KBBQ_SCAN_OCC")) : 0;
-        static const int per_cu = getenv("KBBQ_SCAN_BLOCKS") ? atoi(getenv("KBBQ_SCAN_BLOCKS")) : 0;
-        if (per_cu > 0)
-            hipLaunchKernelGGL(k_scan_trusted<NW>, dim3(std::min(wave_grid(R.n_reads), 256 * per_cu)), dim3(256), 0, e->cur, R, e->K,
-                               e->filt[1].dev(), tmask, dirty, err_bits, e->cur_cnt, fast);
-        else if (occ == 8)
-            hipLaunchKernelGGL((k_scan_trusted<NW, 8>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->cur, R, e->K,
+        if (std::max(1, max_len - e->p.k + 1) <= (NW - 1) * 64)      // (NK: see k_infer)
+            hipLaunchKernelGGL((k_scan_trusted<NW, NW - 1>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->cur, R, e->K,
                                e->filt[1].dev(), tmask, dirty, err_bits, e->cur_cnt, fast);
         else
-        hipLaunchKernelGGL(k_scan_trusted<NW>, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->cur, R, e->K,
-                           e->filt[1].dev(), tmask, dirty, err_bits, e->cur_cnt, fast);
+            hipLaunchKernelGGL((k_scan_trusted<NW, NW>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->cur, R, e->K,
+                               e->filt[1].dev(), tmask, dirty, err_bits, e->cur_cnt, fast);
         HIP_TRY(hipGetLastError());
         return KBBQ_OK;
     }
@@ -1743,26 +1664,31 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
     H.dinuc = e->d_hist + e->hist_cycle_words;
     H.n_rg = e->p.n_rg;
     H.n_cycle = e->p.max_read_len;
-    // LDS tables: ccap cycles x the quality values pass 2 saw x as many read groups as fit (one launch per set of
+    // LDS tables: ccap cycles x the quality values the batches hold x as many read groups as fit (one launch per set of
     // read groups and per window of ccap cycles; a launch whose read groups do not occur in the batch returns at once)
-    TallyPlan P = e->tally_plan;
     const int n_rg = R.rg ? e->p.n_rg : 1;
-    const bool compact = n_rg > 1;      // one read group: full-width tables fit and save the slot lookup
-    if (!compact) {
-        const uint32_t none[3] = {0, 0, 0};
-        plan_tally_slots(P, none);
-    }
     const int ccap = std::min(((max_len + 31) / 32) * 32, 192);
-    const size_t cyc_words = ((size_t)2 * ccap * P.n_slots + 1) / 2;
-    const size_t per_rg = (2 * cyc_words + 2 * (size_t)P.n_slots * 16) * 4;
+    if (!e->qpresent_known) {
+        // pass 3 on its own (--fixed mode, tests): no pass 2 has said which quality values occur -- this batch's are
+        // added to the set of the batches before it (a wait per batch; not the path of a normal run)
+        hipLaunchKernelGGL(k_qpresence, dim3(1024), dim3(256), 0, stream, R.qual, R.n_bases, e->d_qpresent);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(e->qpresent, e->d_qpresent, 32, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    // per quality slot: totals and errors of 2 x ccap cycles as 16-bit counters + 2 x 16 dinucleotide words
+    const size_t per_slot = (size_t)8 * ccap + 128;
+    TallyPlan P;
+    plan_tally_slots(P, e->qpresent, (int)((152 * 1024 - 512) / per_slot));
+    const size_t per_rg = (size_t)P.n_slots * per_slot;
     // (half of the LDS if everything fits in it: two blocks per CU)
     const size_t budget = (size_t)n_rg * per_rg <= 70 * 1024 ? 70 * 1024 : 140 * 1024;
-    const int per_launch = compact ? (int)std::max<size_t>(1, std::min<size_t>((size_t)n_rg, budget / per_rg)) : 1;
-    const size_t lds = (size_t)per_launch * per_rg + 4 + 96 + 4;
+    const int per_launch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_rg, budget / per_rg));
+    const size_t lds = (size_t)per_launch * per_rg + 4 + 256 + 4;
     if (lds > e->attr_lds_tally) {
-        HIP_TRY(hipFuncSetAttribute((const void *)k_tally<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_tally<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void *)k_tally_uniform, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_tally, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_tally_uniform<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_tally_uniform<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         e->attr_lds_tally = lds;
     }
     // 16 wavefronts share one set of LDS tables: one 1024-lane block per CU, two when the tables leave room
@@ -1781,12 +1707,12 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
     }
     const int n_windows = (max_len + ccap - 1) / ccap;
     // the common shape -- equally long reads, one read group, every cycle in one table -- has a kernel of its own
-    static const bool general_only = getenv("KBBQ_TALLY_GENERAL") != nullptr;
-    if (!general_only && !R.offsets && !compact && n_windows == 1 && R.read_len >= 16 && (int)R.read_len <= ccap && R.n_bases < (1ULL << 32) && vec_ok &&
+    if (!e->opt.tally_general && !R.offsets && n_rg == 1 && n_windows == 1 && R.read_len >= 16 && (int)R.read_len <= ccap && R.n_bases < (1ULL << 32) && vec_ok &&
         e->p.n_rg == 1) {
         const unsigned long long inv_len = ~0ULL / R.read_len + 1;      // ceil(2^64 / read_len): read_len is no power of two times... exact below
         Timed t(e, "k_tally", stream);
-        hipLaunchKernelGGL(k_tally_uniform, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, inv_len);
+        if (P.identity) hipLaunchKernelGGL(k_tally_uniform<false>, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, inv_len, P);
+        else hipLaunchKernelGGL(k_tally_uniform<true>, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, inv_len, P);
         HIP_TRY(hipGetLastError());
         return KBBQ_OK;
     }
@@ -1796,8 +1722,7 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
             P.rg_base = g;
             P.n_rgs = std::min(per_launch, n_rg - g);
             P.cbase = w * ccap;
-            if (compact) hipLaunchKernelGGL(k_tally<true>, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, vec_ok, P, present, read_index);
-            else hipLaunchKernelGGL(k_tally<false>, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, vec_ok, P, present, read_index);
+            hipLaunchKernelGGL(k_tally, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, vec_ok, P, present, read_index);
         }
     HIP_TRY(hipGetLastError());
     return KBBQ_OK;
@@ -1812,8 +1737,7 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
     // batches alternate between the two sides (a device-resident batch stays put by contract, a host batch sits in
     // a staging slot that is not reused before its kernels have finished).  A call that returns the flags runs
     // alone, in order: the caller's array is the caller's again on return.
-    static const bool no_overlap = getenv("KBBQ_NO_OVERLAP") != nullptr;
-    const bool overlap = own_err && !(errors_out && !reads->on_device) && !no_overlap;
+    const bool overlap = own_err && !(errors_out && !reads->on_device) && !e->opt.no_overlap;
     int side = 0, rc;
     if (overlap) {
         side = e->side_turn;
@@ -1852,12 +1776,12 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
     uint32_t *list = (uint32_t *)e->scratch[s_list];
     uint32_t *patch = (uint32_t *)e->scratch[s_patch];
     // isolated single errors are settled inside the scan (fast_path); the walk gets what is left (dirty == 1)
-    static const bool no_fast = getenv("KBBQ_NO_FASTPATH") != nullptr;
+    const bool no_fast = e->opt.no_fastpath;
     if (long_reads) {
         Timed t(e, "k_scan_trusted_long", e->cur);
         hipLaunchKernelGGL(k_scan_trusted_long, dim3(wave_grid(R.n_reads)), dim3(256), 0, e->cur, R, e->K, e->filt[1].dev(), tmask, NW, dirty);
         HIP_TRY(hipGetLastError());
-    } else if ((rc = dispatch_nw<LaunchScan>(max_len, e, R, tmask, dirty, d_err, (!no_fast && e->p.k >= 3) ? 1 : 0))) return rc;
+    } else if ((rc = dispatch_nw<LaunchScan>(max_len, e, R, tmask, dirty, d_err, (!no_fast && e->p.k >= 3) ? 1 : 0, max_len))) return rc;
     {
         Timed t(e, "k_compact", e->cur);
         // (long reads: every read that is not clean takes the run-time-sized lane-form walk, off-case or not)
@@ -1875,7 +1799,7 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
     }
     // one read per wavefront (correct_wave.h); the one-read-per-lane form (correct.h) serves k < 3
     // and KBBQ_CORRECT=lane (A/B checks)
-    static const bool lane_form = getenv("KBBQ_CORRECT") && !strcmp(getenv("KBBQ_CORRECT"), "lane");
+    const bool lane_form = e->opt.lane_walk;
     if (long_reads) {
         rc = launch_correct<0, 64>(e, R, list, e->cur_cnt, tmask, NW, d_err, patch, max_len, side);
     } else if (lane_form || e->p.k < 3) {
@@ -2033,8 +1957,8 @@ static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qu
     ReadsDev R; int max_len;
     // a large host batch with its result in host memory goes through in pieces (below): 64 Ki-base multiples, at least 2^23
     // bases each, about four per batch
-    static const bool no_pipe = getenv("KBBQ_NO_PASS4_PIPELINE") != nullptr || getenv("KBBQ_NO_OVERLAP") != nullptr;
-    static const uint64_t piece_env = env_u64("KBBQ_PASS4_PIECE", 0);      // tests: pieces of that many bases (rounded up to 64)
+    const bool no_pipe = e->opt.no_pass4_pipeline;
+    const uint64_t piece_env = e->opt.pass4_piece;      // tests: pieces of that many bases (rounded up to 64)
     const uint64_t piece = piece_env ? ((piece_env + 63) >> 6) << 6 : std::max<uint64_t>(1ull << 23, ((reads->n_bases / 4 + 65535) >> 16) << 16);
     const bool pipelined = !reads->on_device && out_on_host && !no_pipe && reads->n_bases >= 2 * piece;
     DeferredCopy dc;
@@ -2053,10 +1977,11 @@ static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qu
     if ((rc = build_read_index(e, R, 14, e->stream, &read_index))) return rc;
     const int per_rg = (D.n_slots * (4 * D.n_cycle + 16) + KBBQ_NQ * 2 + 3) & ~3;
     // tables of as many read groups as fit (kernels.h: compacted over the quality axis): two 1024-lane blocks
-    // per CU share the 160 KB of LDS when one group takes at most 64 KB; otherwise one block per CU and up to 152 KB
-    const int budget = per_rg + 96 <= 64 * 1024 ? 64 * 1024 - 96 : 152 * 1024 - 96;
-    const int lds_rgs = std::max(0, std::min(D.n_rg, budget / per_rg));
-    const size_t lds = 96 + (size_t)lds_rgs * per_rg;
+    // per CU share the 160 KB of LDS when one group takes at most 64 KB; otherwise one block per CU and up to 152 KB.
+    // (More than 255 quality values with a delta of their own -- no real data -- leave the slot map: global tables.)
+    const int budget = per_rg + 256 <= 64 * 1024 ? 64 * 1024 - 256 : 152 * 1024 - 256;
+    const int lds_rgs = D.n_slots > 255 ? 0 : std::max(0, std::min(D.n_rg, budget / per_rg));
+    const size_t lds = 256 + (size_t)lds_rgs * per_rg;
     if (lds > e->attr_lds_recal) {
         HIP_TRY(hipFuncSetAttribute((const void *)k_recalibrate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         e->attr_lds_recal = lds;
@@ -2067,7 +1992,7 @@ static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qu
         const uint64_t lanes = (base1 - base0 + 15) / 16;
         const unsigned blocks = (unsigned)std::min<uint64_t>((lanes + 1023) / 1024, lds > 76 * 1024 ? 256 : 256 * 2);
         hipLaunchKernelGGL(k_recalibrate, dim3(blocks), dim3(1024), lds, e->stream,
-                           R, D, d_out, 6, vec_ok, lds_rgs, read_index, e->d_qpresent + 3, base0, base1);
+                           R, D, d_out, 6, vec_ok, lds_rgs, read_index, base0, base1);
         HIP_TRY(hipGetLastError());
         return KBBQ_OK;
     };
@@ -2205,13 +2130,7 @@ int kbbq_stats_get(kbbq_engine *e, uint64_t *out, int32_t n) {
     if (e->bk.allocated && n > 6) HIP_TRY(hipMemcpy(&direct, e->bk.direct, 8, hipMemcpyDeviceToHost));
     const uint64_t extra[4] = {e->bk.flushes[0], e->bk.flushes[1], direct, e->bk.allocated ? e->bk.capacity : 0};
     for (int i = 4; i < n && i < 8; ++i) out[i] = extra[i - 4];
-    // [8] 1 when pass 2 or pass 4 met a quality above KBBQ_MAXQ (93): the reference indexes past its tables there;
-    // the engine neither tallies nor recalibrates such a base and clamps it to 93 on output
-    if (n > 8) {
-        uint32_t flag = 0;
-        HIP_TRY(hipMemcpy(&flag, e->d_qpresent + 3, 4, hipMemcpyDeviceToHost));
-        out[8] = flag & 1u;
-    }
+    if (n > 8) out[8] = 0;      // (rounds 1-2: "a quality above 93 was left out of the model"; every quality is modelled now)
     return KBBQ_OK;
 }
 

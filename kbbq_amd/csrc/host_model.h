@@ -16,7 +16,7 @@
 
 namespace kbbq {
 
-constexpr int kNQ = 94;
+constexpr int kNQ = 256;     // quality rows of every table: a quality is a uint8_t and the reference's tables grow with the largest seen (covariateutils.cc:65-76,102-116)
 constexpr uint64_t kBlockBits = 512;
 constexpr uint64_t kNumPatterns = 65536;
 
@@ -90,7 +90,7 @@ struct DqTables {
     uint64_t n_rg = 0, n_cycle = 0;
     std::vector<int32_t> meanq, rgdq, qdq, cycledq, dinucdq;
 };
-// cycle: [n_rg][94][2][n_cycle][2], dinuc: [n_rg][94][16][2]; q and rg totals are
+// cycle: [n_rg][256][2][n_cycle][2], dinuc: [n_rg][256][16][2]; q and rg totals are
 // the sums the reference accumulates separately (covariateutils.cc:30-76).
 void derive_q_rg(uint64_t n_rg, uint64_t n_cycle, const uint64_t *cycle, std::vector<uint64_t> &q,
                  std::vector<uint64_t> &rg);

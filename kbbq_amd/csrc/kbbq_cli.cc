@@ -908,11 +908,6 @@ int main(int argc, char *argv[]) {
         }
         if (!out.close()) return 1;
     }
-    {
-        uint64_t st[9] = {};
-        if (kbbq_stats_get(e, st, 9) == 0 && st[8])
-            std::cerr << put_now << " Warning: quality scores above " << 93 << " in the input: those bases were left out of the model and written as 93." << std::endl;
-    }
     clock.mark("pass4+format+deflate+write");
     resident.drop();
     kbbq_engine_destroy(e);

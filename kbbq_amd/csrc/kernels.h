@@ -251,17 +251,19 @@ struct Thresholds { int v[KBBQ_MAX_KMER + 1]; };
 
 // MINW: waves per SIMD the register allocation must leave room for (the kernel waits on random HBM lines three
 // quarters of the time: more resident waves keep more lookups in flight)
-// DEFER (lookup.h): the membership tests were made beforehand, slice by slice; `absent` holds one bit per k-mer start of
-// the batch (set = looked up and not in the filter) and the kernel touches the filter no more.
-template <int NW, int MINW = 1, bool DEFER = false>
+// NK: 64-lane chunks that can hold k-mer starts (the batch's longest read has at most NK * 64 of them; NK <= NW): their
+// loads are unconditional, so that they sit in one basic block and all go out together.
+template <int NW, int NK, int MINW = 1>
 __global__ void __launch_bounds__(256, MINW) k_infer(ReadsDev R, KParams K, FiltDev S, Thresholds thr, uint32_t *take_bits,
                                                 unsigned long long *inserted, uint32_t *err_out, uint32_t *qpresent,
-                                                unsigned long long *lookups, const uint64_t *absent = nullptr) {
+                                                unsigned long long *lookups) {
     using St = Stage<NW>;
     __shared__ uint32_t lds[4][St::LDS_U32];
     __shared__ int thr_lds[KBBQ_MAX_KMER + 1];
+    __shared__ uint32_t qseen[8];                  // quality values this block has met (256 bits), flushed once at the end
     const int lane = threadIdx.x & 63;
     if (threadIdx.x <= KBBQ_MAX_KMER) thr_lds[threadIdx.x] = thr.v[threadIdx.x];
+    if (threadIdx.x < 8) qseen[threadIdx.x] = 0;
     __syncthreads();
     uint32_t *L32 = lds[threadIdx.x >> 6];
     uint32_t *PW = L32 + 2 * St::WORDS;            // present bits: dword 0 = 0, dwords 1..2NW, then zeros
@@ -274,10 +276,9 @@ __global__ void __launch_bounds__(256, MINW) k_infer(ReadsDev R, KParams K, Filt
     if (lane < St::RES) { PW[lane] = 0; EW[lane] = 0; }
     uint64_t off = 0, word = 0;
     uint32_t len = 0;
-    const uint64_t abs_max = R.n_bases / 64 + 1;
     if (wave < R.n_reads) {
         read_span(R, wave, off, len);
-        word = stage_fetch<NW>(R, hint, DEFER ? absent : nullptr, off, abs_max, off, lane);
+        word = stage_fetch<NW>(R, hint, nullptr, 0, 0, off, lane);
     }
     for (uint64_t r = wave; r < R.n_reads; r += n_waves) {
         __builtin_amdgcn_wave_barrier();
@@ -288,55 +289,62 @@ __global__ void __launch_bounds__(256, MINW) k_infer(ReadsDev R, KParams K, Filt
         const int Lr = (int)len, nk = Lr - k + 1;
         if (r + n_waves < R.n_reads) {   // the next read's words travel while this one is processed
             read_span(R, r + n_waves, off, len);
-            word = stage_fetch<NW>(R, hint, DEFER ? absent : nullptr, off, abs_max, off, lane);
+            word = stage_fetch<NW>(R, hint, nullptr, 0, 0, off, lane);
         }
         if (nk <= 0) continue;           // engine-defined: the reference underflows size_t here
-        // every lane's block and pattern loads (and its quality byte) go out before the first result is needed
-        bool valid[NW], known[NW];
-        ulonglong2 t[NW], p[NW];
-        uint8_t q[NW];
+        // Step A (ALU and LDS only): which block and pattern every lane wants.  A lane with nothing to look up -- past the
+        // last k-mer, a k-mer with a non-ACGT base, one this read put into the sampled filter itself in pass 1 (hint
+        // bit) -- points at block 0 / pattern 0: one shared, cache-resident line per instruction, no branch around the load.
+        bool valid[NK], known[NK];
+        uint32_t blk[NK], pat[NK];
 #pragma unroll
-        for (int c = 0; c < NW; ++c) {
+        for (int c = 0; c < NK; ++c) {
             valid[c] = false;
-            known[c] = false;   // this read put the k-mer into the sampled filter itself (pass 1)
-            t[c] = make_ulonglong2(0, 0);
-            p[c] = make_ulonglong2(0, 0);
-            q[c] = 0;
+            known[c] = false;
+            blk[c] = 0;
+            pat[c] = 0;
             const int s = c * 64 + lane;
-            if (c * 64 < Lr && s < Lr) {
-                q[c] = R.qual[cur + s];
-                // which quality values occur at all (the tally of pass 3 sizes its LDS tables by them): a handful of
-                // bits, looked at before the atomic
-                const uint32_t bit = 1u << (q[c] & 31);
-                if (q[c] < 96 && !(qpresent[q[c] >> 5] & bit)) atomicOr(&qpresent[q[c] >> 5], bit);
-                if (q[c] >= KBBQ_NQ && !(qpresent[3] & 1u)) atomicOr(&qpresent[3], 1u);      // outside the model's range (kbbq_stats_get [8])
-            }
-            if (c * 64 < nk && s < nk) {
+            if (s < nk) {
                 valid[c] = (lds_window32(L32 + 2 * St::M, o63 + s) & K.nmask_bits) == 0;
                 known[c] = hint && lds_bit(L32 + 2 * St::H, o63 + s);
-                if (DEFER) {
-                    p[c].x = lds_bit(L32 + 2 * St::X, o63 + s);      // pattern bit the (empty) block lacks = absent
-                } else if (valid[c] && !known[c]) {
-                    const uint64_t key = canon_key(lds_window64(L32 + 2 * St::B, 2 * (o31 + s)), K);
-                    t[c] = S.table[block_of(S, key)];
-                    p[c] = S.patterns[pattern_of(S, key)];
-                }
+                const uint64_t key = canon_key(lds_window64(L32 + 2 * St::B, 2 * (o31 + s)), K);
+                if (valid[c] && !known[c]) { blk[c] = block_of(S, key); pat[c] = pattern_of(S, key); }
             }
         }
-        uint64_t V[NW];
+        // Step B: every load of the read goes out back to back -- quality bytes (streamed), blocks (one random HBM line
+        // each), patterns (1 MiB table, L2) -- before the first result is looked at: NK independent line fetches in
+        // flight per lane instead of one.  (Until round 3 the compiler sank the first use of a block right behind its
+        // load, and the quality byte fed a dependent global load + atomic in front of it: one fetch in flight per wave.)
+        uint8_t q[NW];
+        ulonglong2 t[NK], p[NK];
 #pragma unroll
         for (int c = 0; c < NW; ++c) {
-            V[c] = 0;
-            if (c * 64 < nk) {
-                const bool present = known[c] || (valid[c] && ((p[c].x & ~t[c].x) | (p[c].y & ~t[c].y)) == 0);
-                const uint64_t P = __ballot(present);
-                V[c] = __ballot(valid[c]);
-                looked += __popcll(__ballot(valid[c] && !known[c]));      // blocks actually fetched (reported, not used)
-                if (lane < 2) PW[1 + 2 * c + lane] = (uint32_t)(P >> (32 * lane));
-            } else if (lane < 2) {
-                PW[1 + 2 * c + lane] = 0;
-            }
+            const int s = c * 64 + lane;
+            q[c] = (c * 64 < Lr && s < Lr) ? R.qual[cur + s] : (uint8_t)0;
         }
+#pragma unroll
+        for (int c = 0; c < NK; ++c) t[c] = S.table[blk[c]];
+#pragma unroll
+        for (int c = 0; c < NK; ++c) p[c] = S.patterns[pat[c]];
+        __builtin_amdgcn_sched_barrier(0);
+        uint64_t V[NK];
+#pragma unroll
+        for (int c = 0; c < NK; ++c) {
+            const bool need = valid[c] && !known[c];
+            const bool present = known[c] || (need && ((p[c].x & ~t[c].x) | (p[c].y & ~t[c].y)) == 0);
+            const uint64_t P = __ballot(present);
+            V[c] = __ballot(valid[c]);
+            looked += __popcll(__ballot(need));      // blocks actually wanted (reported, not used)
+            if (lane < 2) PW[1 + 2 * c + lane] = (uint32_t)(P >> (32 * lane));
+        }
+#pragma unroll
+        for (int c = NK; c < NW; ++c)
+            if (lane < 2) PW[1 + 2 * c + lane] = 0;
+        // which quality values occur at all (the tally of pass 3 sizes its LDS tables by them): a look at the block's
+        // 256-bit set in LDS, an LDS atomic the first time
+#pragma unroll
+        for (int c = 0; c < NW; ++c)
+            if (c * 64 < Lr && c * 64 + lane < Lr) qseen_note(qseen, q[c]);
         __builtin_amdgcn_wave_barrier();
         // in[i] = present k-mers among the starts max(0,i-k+1)..min(i,nk-1): the k bits of the present
         // stream that end at bit i (bits before 0 and from nk on are zero)
@@ -361,7 +369,7 @@ __global__ void __launch_bounds__(256, MINW) k_infer(ReadsDev R, KParams K, Filt
         // the k-mer ending at i goes into the trusted filter iff it is valid and its k bases are all
         // unflagged (recalibrateutils.cc:26-38); the inserts themselves are k_insert_marked's
 #pragma unroll
-        for (int c = 0; c < NW; ++c) {
+        for (int c = 0; c < NK; ++c) {
             if (c * 64 < nk) {
                 const int s = c * 64 + lane;
                 const bool take = s < nk && ((V[c] >> lane) & 1) && (lds_window32(EW, s + 32) & K.nmask_bits) == 0;
@@ -373,6 +381,8 @@ __global__ void __launch_bounds__(256, MINW) k_infer(ReadsDev R, KParams K, Filt
     }
     if (lane == 0 && mine) atomicAdd(inserted, mine);
     if (lane == 0 && looked) atomicAdd(lookups, looked);
+    __syncthreads();
+    if (threadIdx.x < 8 && qseen[threadIdx.x]) atomicOr(&qpresent[threadIdx.x], qseen[threadIdx.x]);
 }
 
 // ---- pass 3a': the isolated-error fast path (inside k_scan_trusted) -------------------
@@ -495,7 +505,7 @@ __device__ __forceinline__ bool fast_path(const uint32_t *L32, const KParams &K,
 // Wave per read.  A read whose k-mers are all trusted has no errors
 // (readutils.cc:263-265) and needs nothing more than the tally; the others get
 // their mask stored and a flag for the correction kernel.
-template <int NW, int MINW = 1>
+template <int NW, int NK, int MINW = 1>
 __global__ void __launch_bounds__(256, MINW) k_scan_trusted(ReadsDev R, KParams K, FiltDev T, uint64_t *tmask,
                                                        uint8_t *dirty, uint32_t *err_bits, unsigned long long *stats,
                                                        int fast) {
@@ -537,33 +547,38 @@ __global__ void __launch_bounds__(256, MINW) k_scan_trusted(ReadsDev R, KParams 
         }
         uint64_t M[NW];
         int trusted = 0;
-        bool valid[NW], known[NW];
-        ulonglong2 t[NW], p[NW];
+        // addresses first, then every block (one random HBM line each) and pattern (L2) load of the read back to back,
+        // then the tests: NW line fetches in flight per lane (k_infer, steps A and B); a lane with nothing to look up
+        // reads block 0 / pattern 0
+        bool valid[NK], known[NK];
+        uint32_t blk[NK], pat[NK];
+        ulonglong2 t[NK], p[NK];
 #pragma unroll
-        for (int c = 0; c < NW; ++c) {
-            M[c] = 0;
+        for (int c = 0; c < NW; ++c) M[c] = 0;
+#pragma unroll
+        for (int c = 0; c < NK; ++c) {
             valid[c] = false;
             known[c] = false;   // this read put the k-mer into the trusted filter itself (pass 2)
-            t[c] = make_ulonglong2(0, 0);
-            p[c] = make_ulonglong2(0, 0);
+            blk[c] = 0;
+            pat[c] = 0;
             const int s = c * 64 + lane;
-            if (c * 64 < nk && s < nk) {
+            if (s < nk) {
                 const uint64_t key = canon_key(lds_window64(L32 + 2 * S::B, 2 * (o31 + s)), K);
                 valid[c] = (lds_window32(L32 + 2 * S::M, o63 + s) & K.nmask_bits) == 0;
                 known[c] = hint && lds_bit(L32 + 2 * S::H, o63 + s);
-                if (valid[c] && !known[c]) {
-                    t[c] = T.table[block_of(T, key)];
-                    p[c] = T.patterns[pattern_of(T, key)];
-                }
+                if (valid[c] && !known[c]) { blk[c] = block_of(T, key); pat[c] = pattern_of(T, key); }
             }
         }
 #pragma unroll
-        for (int c = 0; c < NW; ++c) {
-            if (c * 64 < nk) {
-                const bool ok = known[c] || (valid[c] && ((p[c].x & ~t[c].x) | (p[c].y & ~t[c].y)) == 0);
-                M[c] = __ballot(ok);
-                trusted += __popcll(M[c]);
-            }
+        for (int c = 0; c < NK; ++c) t[c] = T.table[blk[c]];
+#pragma unroll
+        for (int c = 0; c < NK; ++c) p[c] = T.patterns[pat[c]];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < NK; ++c) {
+            const bool ok = known[c] || (valid[c] && ((p[c].x & ~t[c].x) | (p[c].y & ~t[c].y)) == 0);
+            M[c] = __ballot(ok);
+            trusted += __popcll(M[c]);
         }
         // 0 = every k-mer trusted, nothing to do; 2 = settled by the fast path right here (the read is still staged:
         // waves in their lookup rounds and waves streaming through clean reads share the CU); 1 = needs the walk
@@ -759,8 +774,8 @@ __global__ void __launch_bounds__(256, 5) k_correct_wave(ReadsDev R, KParams K, 
 // read group of the block's first read; error counts and anything outside the
 // LDS table go straight to 64-bit global atomics (rare).
 struct HistDev {
-    unsigned long long *cycle;   // [n_rg][94][2][n_cycle][2]
-    unsigned long long *dinuc;   // [n_rg][94][16][2]
+    unsigned long long *cycle;   // [n_rg][256][2][n_cycle][2]
+    unsigned long long *dinuc;   // [n_rg][256][16][2]
     int n_rg, n_cycle;
 };
 
@@ -789,20 +804,21 @@ __global__ void k_rg_presence(const uint16_t *rg, uint64_t n_reads, uint32_t n_r
 }
 
 struct TallyPlan {
-    uint8_t qslot[96];     // slot of a quality value in the LDS tables, 255 = none (counted through global atomics)
-    uint8_t qof[96];       // quality value of a slot
-    int n_slots;           // slots in use
+    uint8_t qslot[256];    // slot of a quality value in the LDS tables, 255 = none (counted through global atomics)
+    uint8_t qof[256];      // quality value of a slot
+    int n_slots;           // slots in use (at most 255)
+    int identity;          // slot == quality for every quality below n_slots (few, small values: no lookup needed)
     int rg_base, n_rgs;    // this launch tallies the read groups [rg_base, rg_base + n_rgs)
     int cbase;             // ... and the cycles [cbase, cbase + ccap)
 };
 
-// COMPACT = false: every quality value is its own slot (one read group per launch fits then): no slot lookup.
-template <bool COMPACT>
+// The quality axis of the LDS tables is compacted to the values the batches hold (TallyPlan; a quality is any uint8_t,
+// as in the reference, whose tables grow with the largest one seen).
 __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uint32_t *err_bits, const uint32_t *patch,
                                                  int ccap, int minscore, int vec_ok, TallyPlan P, const uint32_t *present,
                                                  const uint32_t *read_index) {
     extern __shared__ uint32_t lds[];
-    const int ns = COMPACT ? P.n_slots : KBBQ_NQ, cbase = P.cbase;     // not COMPACT: the identity layout, a compile-time 94
+    const int ns = P.n_slots, cbase = P.cbase;
     if (present) {      // none of this launch's read groups occurs in the batch
         bool any = false;
         for (int g = P.rg_base; g < P.rg_base + P.n_rgs; ++g) any = any || ((present[g >> 5] >> (g & 31)) & 1);
@@ -817,14 +833,14 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
     uint8_t *l_qslot = reinterpret_cast<uint8_t *>(l_reads + 1);
     const int lds_words = P.n_rgs * per_rg + 1;
     for (int i = threadIdx.x; i < lds_words; i += blockDim.x) lds[i] = 0;
-    if (threadIdx.x < 96) l_qslot[threadIdx.x] = P.qslot[threadIdx.x];
+    if (threadIdx.x < 256) l_qslot[threadIdx.x] = P.qslot[threadIdx.x];
     __syncthreads();
     // one base: cycle and dinucleotide counters of (read group slot lr, quality q, second, cycle cyc)
     auto count = [&](int lr, int rg, int q, int second, int cyc, int er, bool dinuc_ok, int d) {
         const int cr = cyc - cbase;      // inside this launch's cycle window?
         if ((unsigned)cr >= (unsigned)ccap) return;
-        const int sl = COMPACT ? (int)l_qslot[q] : q;
-        if (!COMPACT || sl != 255) {
+        const int sl = (int)l_qslot[q];
+        if (sl != 255) {
             uint32_t *t = lds + lr * per_rg;
             // lanes of one instruction are 16 cycles apart: store cycle c at slot (c%16)*(ccap/16) + c/16 so that
             // they land in neighbouring words, not in two banks
@@ -836,7 +852,7 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
                 atomicAdd(&t[2 * cyc_words + sl * 16 + d], 1u);
                 if (er) atomicAdd(&t[2 * cyc_words + ns * 16 + sl * 16 + d], 1u);
             }
-        } else {      // a quality value pass 2 did not announce: straight to the histograms
+        } else {      // a quality value without a slot (not announced, or more distinct values than fit): straight to the histograms
             atomicAdd(&H.cycle[cyc_index(H, rg, q, second, cyc) + 1], 1ULL);
             if (er) atomicAdd(&H.cycle[cyc_index(H, rg, q, second, cyc)], 1ULL);
             if (dinuc_ok) {
@@ -897,10 +913,9 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
             }
             const int c0 = (int)(g0 - start);
             // read groups of this launch are [rg_base, rg_base + n_rgs); everything else belongs to another launch
-            // (not COMPACT: exactly one read group per launch, at offset 0 of the LDS)
-            const int lr1 = COMPACT ? rg - P.rg_base : 0, lr2 = COMPACT ? rg2 - P.rg_base : 0;
-            const bool mine1 = (COMPACT ? (unsigned)lr1 < (unsigned)P.n_rgs : rg == P.rg_base) && rg < H.n_rg;
-            const bool mine2 = (COMPACT ? (unsigned)lr2 < (unsigned)P.n_rgs : rg2 == P.rg_base) && rg2 < H.n_rg;
+            const int lr1 = rg - P.rg_base, lr2 = rg2 - P.rg_base;
+            const bool mine1 = (unsigned)lr1 < (unsigned)P.n_rgs && rg < H.n_rg;
+            const bool mine2 = (unsigned)lr2 < (unsigned)P.n_rgs && rg2 < H.n_rg;
             const bool one_boundary = bpos == 16 || (r + 1 < R.n_reads && end2 >= g0 + 16);
             if (n == 16 && one_boundary && !mine1 && (bpos == 16 || !mine2)) {
                 starts += bpos < 16 ? 1 : 0;       // a group of other launches' read groups
@@ -915,7 +930,7 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
                     int b = (int)((bw >> (2 * i)) & 3), nn = (int)((nw >> i) & 1);
                     if (cyc == (in2 ? pp2 : pp1)) { b = (int)((in2 ? pt2 : pt) & 3); nn = 0; }
                     const int q = qv[i];
-                    if (q < KBBQ_NQ && (in2 ? mine2 : mine1))
+                    if (in2 ? mine2 : mine1)
                         count(in2 ? lr2 : lr1, in2 ? rg2 : rg, q, in2 ? second2 : second, cyc, (int)((ew >> i) & 1u),
                               cyc >= 1 && q >= minscore && !(nn | prev_n), (prev_b << 2) | b);
                     prev_b = b;
@@ -940,8 +955,8 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
                     int b = (int)((bw >> (2 * i)) & 3), nn = (int)((nw >> i) & 1);
                     if ((pt >> 31) && (int)((pt >> 8) & 0xFFFF) == cyc) { b = (int)(pt & 3); nn = 0; }
                     const int q = qv[i];
-                    const int lr = COMPACT ? rg - P.rg_base : 0;
-                    if ((COMPACT ? (unsigned)lr < (unsigned)P.n_rgs : rg == P.rg_base) && rg < H.n_rg && cyc < H.n_cycle && q < KBBQ_NQ)
+                    const int lr = rg - P.rg_base;
+                    if ((unsigned)lr < (unsigned)P.n_rgs && rg < H.n_rg && cyc < H.n_cycle)
                         count(lr, rg, q, second, cyc, (int)((ew >> i) & 1), cyc >= 1 && q >= minscore && !nn && !prev_n, (prev_b << 2) | b);
                     prev_b = b;
                     prev_n = nn;
@@ -1001,28 +1016,43 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
 // ---- pass 3c, the common shape: uniform read length, one read group, one cycle window ------------------------
 // k_tally's general loop spends 1 700 VALU + 1 700 SALU instructions per 16 bases on bookkeeping that a batch of
 // equally long reads of one read group does not need (read boundaries from an offsets array, read-group slots,
-// quality slots, cycle windows).  Here: the read of a 16-base group is one 64-bit multiply-high (inv_len =
-// ceil(2^64 / read_len), exact for the 32-bit base offsets of a batch), a group lies in one read or straddles one
-// boundary (read_len >= 16), every quality value is its own slot and every cycle is in the table.  Same LDS
-// tables (packed 16-bit counters, cycle slots permuted against bank conflicts) and same result as k_tally<false>.
+// cycle windows).  Here: the read of a 16-base group is one 64-bit multiply-high (inv_len = ceil(2^64 / read_len),
+// exact for the 32-bit base offsets of a batch), a group lies in one read or straddles one boundary (read_len >= 16)
+// and every cycle is in the table.  Same LDS tables (packed 16-bit counters, cycle slots permuted against bank
+// conflicts) and same result as k_tally.  MAP = false: the plan is the identity (slot = quality for the values below
+// n_slots: the usual FASTQ range), no slot lookup; MAP = true: slot from the plan's table in LDS.  A quality without a
+// slot goes to the histograms directly.
+template <bool MAP>
 __global__ void __launch_bounds__(1024) k_tally_uniform(ReadsDev R, HistDev H, const uint32_t *err_bits, const uint32_t *patch,
-                                                         int ccap, int minscore, unsigned long long inv_len) {
+                                                         int ccap, int minscore, unsigned long long inv_len, TallyPlan P) {
     extern __shared__ uint32_t lds[];
-    constexpr int ns = KBBQ_NQ;
+    const int ns = P.n_slots;
     const int L = (int)R.read_len;
     const int cyc_words = (2 * ccap * ns + 1) / 2, cstep = ccap >> 4;
     uint32_t *t_err = lds + cyc_words, *t_di = lds + 2 * cyc_words, *t_die = t_di + ns * 16;
     const int lds_words = 2 * cyc_words + 2 * ns * 16;
+    uint8_t *l_qslot = reinterpret_cast<uint8_t *>(lds + lds_words);
     for (int i = threadIdx.x; i < lds_words; i += blockDim.x) lds[i] = 0;
+    if (MAP && threadIdx.x < 256) l_qslot[threadIdx.x] = P.qslot[threadIdx.x];
     __syncthreads();
-    auto count = [&](int tb, int q, int cyc, int er, bool dinuc_ok, int d) {
-        const int idx = tb + q * ccap + (cyc & 15) * cstep + (cyc >> 4);
-        const uint32_t one = 1u << (16 * (idx & 1));
-        atomicAdd(&lds[idx >> 1], one);
-        if (er) atomicAdd(&t_err[idx >> 1], one);
-        if (dinuc_ok) {
-            atomicAdd(&t_di[q * 16 + d], 1u);
-            if (er) atomicAdd(&t_die[q * 16 + d], 1u);
+    auto count = [&](int second, int q, int cyc, int er, bool dinuc_ok, int d) {
+        const int sl = MAP ? (int)l_qslot[q] : q;
+        if (MAP ? sl != 255 : sl < ns) {
+            const int idx = (second * ns + sl) * ccap + (cyc & 15) * cstep + (cyc >> 4);
+            const uint32_t one = 1u << (16 * (idx & 1));
+            atomicAdd(&lds[idx >> 1], one);
+            if (er) atomicAdd(&t_err[idx >> 1], one);
+            if (dinuc_ok) {
+                atomicAdd(&t_di[sl * 16 + d], 1u);
+                if (er) atomicAdd(&t_die[sl * 16 + d], 1u);
+            }
+        } else {
+            atomicAdd(&H.cycle[cyc_index(H, 0, q, second, cyc) + 1], 1ULL);
+            if (er) atomicAdd(&H.cycle[cyc_index(H, 0, q, second, cyc)], 1ULL);
+            if (dinuc_ok) {
+                atomicAdd(&H.dinuc[((uint64_t)q * 16 + d) * 2 + 1], 1ULL);
+                if (er) atomicAdd(&H.dinuc[((uint64_t)q * 16 + d) * 2], 1ULL);
+            }
         }
     };
     auto flush = [&]() {
@@ -1036,7 +1066,7 @@ __global__ void __launch_bounds__(1024) k_tally_uniform(ReadsDev R, HistDev H, c
                 if (!cnt) continue;
                 const int idx = 2 * w + h;
                 const int slot = idx % ccap, rest = idx / ccap;
-                const int q = rest % ns, sec = rest / ns;
+                const int q = MAP ? (int)P.qof[rest % ns] : rest % ns, sec = rest / ns;
                 const int c = (slot % cstep) * 16 + slot / cstep;
                 if (c < H.n_cycle) {
                     atomicAdd(&H.cycle[cyc_index(H, 0, q, sec, c) + 1], (unsigned long long)cnt);
@@ -1046,8 +1076,9 @@ __global__ void __launch_bounds__(1024) k_tally_uniform(ReadsDev R, HistDev H, c
         }
         for (int w = threadIdx.x; w < ns * 16; w += blockDim.x) {
             const uint32_t v = t_di[w], ve = t_die[w];
-            if (v) { t_di[w] = 0; atomicAdd(&H.dinuc[(uint64_t)w * 2 + 1], (unsigned long long)v); }
-            if (ve) { t_die[w] = 0; atomicAdd(&H.dinuc[(uint64_t)w * 2], (unsigned long long)ve); }
+            const uint64_t cell = (uint64_t)(MAP ? (int)P.qof[w >> 4] : (w >> 4)) * 16 + (w & 15);
+            if (v) { t_di[w] = 0; atomicAdd(&H.dinuc[cell * 2 + 1], (unsigned long long)v); }
+            if (ve) { t_die[w] = 0; atomicAdd(&H.dinuc[cell * 2], (unsigned long long)ve); }
         }
     };
     const uint64_t n_groups = (R.n_bases + 15) / 16;
@@ -1075,8 +1106,8 @@ __global__ void __launch_bounds__(1024) k_tally_uniform(ReadsDev R, HistDev H, c
             }
             const bool two = bpos < 16;
             const bool mine1 = !R.rg || R.rg[r] == 0, mine2 = !two || !R.rg || R.rg[r + 1] == 0;
-            const int tb1 = (R.flags ? (R.flags[r] & 1) : 0) * ns * ccap;
-            const int tb2 = (two && R.flags ? (R.flags[r + 1] & 1) : 0) * ns * ccap;
+            const int sec1 = R.flags ? (R.flags[r] & 1) : 0;
+            const int sec2 = two && R.flags ? (R.flags[r + 1] & 1) : 0;
             const uint32_t pt1 = patch ? patch[r] : 0u, pt2 = two && patch ? patch[r + 1] : 0u;
             const int pp1 = (pt1 >> 31) ? (int)((pt1 >> 8) & 0xFFFF) : -2, pp2 = (pt2 >> 31) ? (int)((pt2 >> 8) & 0xFFFF) : -2;
             if (pp1 >= 0 && pp1 == c0 - 1) { prev_b = (int)(pt1 & 3); prev_n = 0; }
@@ -1087,8 +1118,8 @@ __global__ void __launch_bounds__(1024) k_tally_uniform(ReadsDev R, HistDev H, c
                 int b = (int)((bw >> (2 * i)) & 3), nn = (int)((nw >> i) & 1);
                 if (cyc == (in2 ? pp2 : pp1)) { b = (int)((in2 ? pt2 : pt1) & 3); nn = 0; }
                 const int q = qv[i];
-                if (q < KBBQ_NQ && (in2 ? mine2 : mine1))
-                    count(in2 ? tb2 : tb1, q, cyc, (int)((ew >> i) & 1u), cyc >= 1 && q >= minscore && !(nn | prev_n), (prev_b << 2) | b);
+                if (in2 ? mine2 : mine1)
+                    count(in2 ? sec2 : sec1, q, cyc, (int)((ew >> i) & 1u), cyc >= 1 && q >= minscore && !(nn | prev_n), (prev_b << 2) | b);
                 prev_b = b;
                 prev_n = nn;
             }
@@ -1109,8 +1140,8 @@ __global__ void __launch_bounds__(1024) k_tally_uniform(ReadsDev R, HistDev H, c
                 if (cyc >= 1) base_at(g - 1, cyc - 1, pb, pn);
                 const int q = R.qual[g];
                 const int er = (int)((err_bits[g >> 5] >> (g & 31)) & 1u);
-                if (q < KBBQ_NQ && (!R.rg || R.rg[r] == 0))
-                    count((R.flags ? (R.flags[r] & 1) : 0) * ns * ccap, q, cyc, er, cyc >= 1 && q >= minscore && !(nn | pn), (pb << 2) | b);
+                if (!R.rg || R.rg[r] == 0)
+                    count(R.flags ? (R.flags[r] & 1) : 0, q, cyc, er, cyc >= 1 && q >= minscore && !(nn | pn), (pb << 2) | b);
             }
         }
         if ((it + 1) % flush_every == 0 || it + 1 == iters) {      // block-uniform
@@ -1121,32 +1152,43 @@ __global__ void __launch_bounds__(1024) k_tally_uniform(ReadsDev R, HistDev H, c
     }
 }
 
+// quality values of a batch that was not seen by pass 2 (--fixed mode, pass 3 on its own): 256 bits, the same set k_infer leaves
+__global__ void __launch_bounds__(256) k_qpresence(const uint8_t *qual, uint64_t n_bases, uint32_t *qpresent) {
+    __shared__ uint32_t qseen[8];
+    if (threadIdx.x < 8) qseen[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_bases; i += (uint64_t)gridDim.x * blockDim.x)
+        qseen_note(qseen, qual[i]);
+    __syncthreads();
+    if (threadIdx.x < 8 && qseen[threadIdx.x]) atomicOr(&qpresent[threadIdx.x], qseen[threadIdx.x]);
+}
+
 // ---- pass 4: delta-Q apply -------------------------------------------------------
 // CReadData::recalibrate (readutils.cc:572-595).  One lane per 16 consecutive
 // bases of the batch: 16-byte quality load and store, 4-byte base load.
 struct DqDev {
-    const int16_t *base;   // [n_rg][94]  meanq + rgdq + qscoredq
-    const int8_t *cycle;   // [n_rg][94][2][n_cycle]
-    const int8_t *dinuc;   // [n_rg][94][16]
-    const uint8_t *qslot;  // [94] slot of a quality in the LDS tables (255 = it has no cycle / dinucleotide delta anywhere)
+    const int16_t *base;   // [n_rg][256]  meanq + rgdq + qscoredq
+    const int8_t *cycle;   // [n_rg][256][2][n_cycle]
+    const int8_t *dinuc;   // [n_rg][256][16]
+    const uint8_t *qslot;  // [256] slot of a quality in the LDS tables (255 = it has no cycle / dinucleotide delta anywhere)
     int n_rg, n_cycle, n_slots;
 };
 
 __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8_t *out, int minqual, int vec_ok, int lds_rgs,
-                                                       const uint32_t *read_index, uint32_t *qflag, uint64_t base0, uint64_t base1) {
+                                                       const uint32_t *read_index, uint64_t base0, uint64_t base1) {
     // The delta-Q tables of the first `lds_rgs` read groups sit in LDS, compacted over the quality axis: only the
     // D.n_slots quality values that have a non-zero cycle or dinucleotide delta anywhere get a slot (D.qslot; a
     // handful for binned qualities, so a dozen read groups fit), holding per (slot, second, cycle) one int16 with
     // meanq + rg + q delta-Q + cycle delta-Q already summed and the int8 dinucleotide delta-Q; every other
     // quality only needs its base value.  Two or three dependent LDS reads per base instead of three global ones.
     extern __shared__ uint8_t l_tab[];
-    uint8_t *l_qslot = l_tab;                                   // [96]: slot of a quality, 255 = none
+    uint8_t *l_qslot = l_tab;                                   // [256]: slot of a quality, 255 = none
     const int ns = D.n_slots;
     const int cyc_cells = ns * 2 * D.n_cycle, di_bytes = ns * 16, base_bytes = KBBQ_NQ * 2;
     const int cyc_bytes = 2 * cyc_cells;
     const int per_rg = (cyc_bytes + di_bytes + base_bytes + 3) & ~3;
-    uint8_t *l_rg = l_tab + 96;
-    if (threadIdx.x < 96) l_qslot[threadIdx.x] = threadIdx.x < KBBQ_NQ ? D.qslot[threadIdx.x] : 255;
+    uint8_t *l_rg = l_tab + 256;
+    if (threadIdx.x < 256) l_qslot[threadIdx.x] = D.qslot[threadIdx.x];
     __syncthreads();
     for (int i = threadIdx.x; i < lds_rgs * KBBQ_NQ; i += blockDim.x) {
         const int rg = i / KBBQ_NQ, q = i % KBBQ_NQ;
@@ -1205,15 +1247,6 @@ __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8
         end2 = R.offsets ? R.offsets[r + 2] : end + R.read_len;
     }
     const int c0 = (int)(g0 - start);
-    // a quality above KBBQ_MAXQ = 93 among the 16 (bytes past the batch are 0): q + 34 >= 128, four bytes at a time.  The
-    // reference's tables would grow for it; the engine leaves the base out of the model, clamps it and says so (qflag).
-    uint32_t beyond = 0;
-    {
-        uint32_t w4[4];
-        memcpy(w4, qv, 16);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) beyond |= (((w4[j] & 0x7F7F7F7Fu) + 0x22222222u) | w4[j]) & 0x80808080u;
-    }
     const bool plain = n == 16 && rg < lds_rgs && rg2 < lds_rgs && (bpos == 16 || (r + 1 < R.n_reads && end2 >= g0 + 16)) &&
                        c0 + bpos <= D.n_cycle && 16 - bpos <= D.n_cycle;
     if (plain) {
@@ -1230,7 +1263,7 @@ __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8
             const int b = (int)((bw >> (2 * i)) & 3), nn = (int)((nw >> i) & 1);
             const int q = qv[i];
             int v = q;
-            if (q >= minqual && q < KBBQ_NQ) {
+            if (q >= minqual) {
                 const int sl = l_qslot[q];
                 if (sl != 255) {
                     v = (in2 ? tb : ta)[sl * qstride + i];
@@ -1260,7 +1293,7 @@ __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8
         const int b = (int)((bw >> (2 * i)) & 3), nn = (int)((nw >> i) & 1);
         const int q = qv[i];
         int v = q;
-        if (i < n && q >= minqual && q < KBBQ_NQ && rg < D.n_rg && cyc < D.n_cycle) {
+        if (i < n && q >= minqual && rg < D.n_rg && cyc < D.n_cycle) {
             const int cell = rg * KBBQ_NQ + q;
             const bool use_di = cyc > 0 && !nn && !prev_n;
             if (rg < lds_rgs) {
@@ -1289,7 +1322,6 @@ __global__ void __launch_bounds__(1024) k_recalibrate(ReadsDev R, DqDev D, uint8
     } else {
         for (int i = 0; i < n; ++i) out[g0 + i] = res[i];
     }
-    if (beyond && !(*qflag & 1u)) atomicOr(qflag, 1u);
     }
 }
 

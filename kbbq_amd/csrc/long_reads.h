@@ -77,8 +77,10 @@ __global__ void __launch_bounds__(256) k_infer_long(ReadsDev R, KParams K, FiltD
     using St = Stage<NW>;
     __shared__ uint32_t lds[4][St::LDS_U32];
     __shared__ int thr_lds[KBBQ_MAX_KMER + 1];
+    __shared__ uint32_t qseen[8];                  // quality values this block has met (k_infer)
     const int lane = threadIdx.x & 63;
     if (threadIdx.x <= KBBQ_MAX_KMER) thr_lds[threadIdx.x] = thr.v[threadIdx.x];
+    if (threadIdx.x < 8) qseen[threadIdx.x] = 0;
     __syncthreads();
     uint32_t *L32 = lds[threadIdx.x >> 6];
     uint32_t *PW = L32 + 2 * St::WORDS;            // present bits: dword 0 = 0, dwords 1..2NW, then zeros
@@ -117,9 +119,7 @@ __global__ void __launch_bounds__(256) k_infer_long(ReadsDev R, KParams K, FiltD
                 const int s = c * 64 + lane;
                 if (c * 64 < wlen && s < wlen) {
                     q[c] = R.qual[woff + s];
-                    const uint32_t bit = 1u << (q[c] & 31);
-                    if (q[c] < 96 && !(qpresent[q[c] >> 5] & bit)) atomicOr(&qpresent[q[c] >> 5], bit);
-                    if (q[c] >= KBBQ_NQ && !(qpresent[3] & 1u)) atomicOr(&qpresent[3], 1u);
+                    qseen_note(qseen, q[c]);
                 }
                 bool valid = false, present = false;
                 if (c * 64 < wnk && s < wnk) {
@@ -181,6 +181,8 @@ __global__ void __launch_bounds__(256) k_infer_long(ReadsDev R, KParams K, FiltD
     for (int o = 32; o > 0; o >>= 1) looked += __shfl_down(looked, o);
     if (lane == 0 && mine) atomicAdd(inserted, mine);
     if (lane == 0 && looked) atomicAdd(lookups, looked);
+    __syncthreads();
+    if (threadIdx.x < 8 && qseen[threadIdx.x]) atomicOr(&qpresent[threadIdx.x], qseen[threadIdx.x]);
 }
 
 // ---- pass 3a ----------------------------------------------------------------------------------------------

@@ -27,6 +27,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from ._lib import NQ
+
 
 def world(group=None):
     if not dist.is_available() or not dist.is_initialized():
@@ -47,6 +49,10 @@ def or_allreduce_(t, or_into, slab_words=1 << 26, group=None, or_pieces=None, fo
     is made current for the whole exchange: work.wait() then orders that stream behind a collective and every
     collective behind the kernels queued on it so far -- no host-side synchronisation inside the loop.  On gloo
     (CPU tensors) wait() blocks the host and the same code is simply sequential.
+
+    Device tensors WITHOUT `stream`: the caller's OR kernel runs on a stream this function knows nothing about, so
+    nothing orders it against the collectives (which follow torch's current stream).  The loop then falls back to
+    the host-synchronised sequence: the device is drained after every collective wait and after every OR.
     """
     rank, n = world(group)
     if n == 1 and not force:      # force: run the collectives anyway (single-rank plumbing check)
@@ -58,6 +64,7 @@ def or_allreduce_(t, or_into, slab_words=1 << 26, group=None, or_pieces=None, fo
     slab = piece * n
     n_slabs = (total + slab - 1) // slab
     ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+    host_fence = (lambda: torch.cuda.synchronize(t.device)) if (t.is_cuda and stream is None) else (lambda: None)
     with ctx:
         recv = [torch.empty(slab, dtype=torch.int64, device=t.device) for _ in range(min(2, n_slabs))]
         mine = [torch.empty(piece, dtype=torch.int64, device=t.device) for _ in range(min(2, n_slabs))]
@@ -82,16 +89,19 @@ def or_allreduce_(t, or_into, slab_words=1 << 26, group=None, or_pieces=None, fo
                 gathers.pop(0).wait()      # (RCCL: a stream dependency, no host wait -- and already implied by the
             r, m = recv[s & 1], mine[s & 1]    #  communicator's issue order; gloo runs its collectives on several threads)
             m.copy_(r[rank * piece:(rank + 1) * piece])
+            host_fence()                   # (no stream given: the received pieces and the copy are complete before the OR kernel starts)
             if or_pieces is not None:
                 or_pieces(m, r, piece, n, rank)
             else:
                 for j in range(n):
                     if j != rank:
                         or_into(m, r[j * piece:(j + 1) * piece])
+            host_fence()                   # (... and the OR kernel before the all_gather reads its result)
             gathers.append(dist.all_gather_into_tensor(view_of(s), m, group=group, async_op=True))
             w = w_next
         for g in gathers:
             g.wait()
+        host_fence()
         if pad is not None:
             t[total - tail:].copy_(pad[:tail])
     return t
@@ -259,7 +269,7 @@ class EnginePeer:
 
     def dq_shapes(self):
         R, C = self.e.n_rg, self.e.max_read_len
-        return [(R,), (R,), (R, 94), (R, 94, 2, C), (R, 94, 16)]
+        return [(R,), (R,), (R, NQ), (R, NQ, 2, C), (R, NQ, 16)]
 
     def set_dq(self, dq):
         self.e.set_dq(dq)

@@ -87,7 +87,8 @@ class DeviceReads:
 
 class Engine:
     def __init__(self, k, alpha, seed, approx_kmers, n_rg=1, max_read_len=160, device=0, fpr_sampled=None,
-                 fpr_trusted=None, bloom_seed=_lib.DEFAULT_BLOOM_SEED, profile=False):
+                 fpr_trusted=None, bloom_seed=_lib.DEFAULT_BLOOM_SEED, profile=False, flags=0, tune=None):
+        """flags: KBBQ_F_* switches OR-ed together; tune: {"bucket_records": n, "pass4_piece": n} (kbbq_engine_tune)."""
         self.L = _lib.lib()
         fs, ft = default_fprs()
         self.alpha_ld = np.longdouble(alpha)
@@ -102,7 +103,7 @@ class Engine:
         p.fpr_trusted = ft if fpr_trusted is None else fpr_trusted
         p.bloom_seed = bloom_seed
         p.max_read_len = max_read_len
-        p.flags = _lib.KBBQ_F_PROFILE if profile else 0
+        p.flags = (_lib.KBBQ_F_PROFILE if profile else 0) | int(flags)
         self.params = p
         self.k = k
         self.n_rg = n_rg
@@ -110,6 +111,8 @@ class Engine:
         h = _lib.c_vp()
         _lib.check(self.L.kbbq_engine_create(ctypes.byref(p), ctypes.byref(h)))
         self.h = h
+        for name, value in (tune or {}).items():
+            _lib.check(self.L.kbbq_engine_tune(self.h, name.encode(), int(value)))
 
     def close(self):
         if getattr(self, "h", None):

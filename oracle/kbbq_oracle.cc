@@ -55,8 +55,10 @@ const char *const g_count_names[C_COUNT] = {
     "right_fix", "offcase_fix_candidate", "offcase_fix_won", "offcase_adjust_candidate", "offcase_adjust_multiple"};
 
 constexpr size_t NPOS = static_cast<size_t>(-1);
-constexpr int MAXQ = 93;            // covariateutils.hh:3  KBBQ_MAXQ
-constexpr int NQ = MAXQ + 1;
+constexpr int MAXQ = 93;            // covariateutils.hh:3  KBBQ_MAXQ: the largest quality the model proposes, and the output clamp
+// Quality rows of the dense tables.  The reference's tables grow with the largest quality seen (`resize(q+1)`,
+// covariateutils.cc:70,108,156) and a quality is a uint8_t (readutils.hh), so 256 rows hold whatever it can hold.
+constexpr int NQ = 256;
 constexpr int BAD_QUAL = 2;         // readutils.hh:16  INFER_ERROR_BAD_QUAL
 
 // ---------------------------------------------------------------------------
@@ -829,8 +831,8 @@ void get_errors(Read &rd, const Filter &t, int k, int minqual, bool first_call) 
 // Covariate tallies (dense restatement of covariateutils.cc:30-42, 65-76,
 // 102-116, 147-164, 193-202) and the delta-Q model (:204-230).
 // Dense layout (shared with the engine's C ABI, see include/kbbq_engine.h):
-//   rg   [R][2]            q     [R][94][2]
-//   cyc  [R][94][2][C][2]  dinuc [R][94][16][2]      (last index: 0=errors 1=total)
+//   rg   [R][2]             q     [R][256][2]
+//   cyc  [R][256][2][C][2]  dinuc [R][256][16][2]      (last index: 0=errors 1=total)
 // ---------------------------------------------------------------------------
 struct Cov {
     size_t R = 0, C = 0;
@@ -858,13 +860,11 @@ struct Cov {
     void consume(const Read &rd, int minscore) {
         ensure((size_t)rd.rg + 1, rd.seq.size());
         const size_t r = (size_t)rd.rg;
-        // A quality above KBBQ_MAXQ = 93 (possible in a BAM, not in printable FASTQ): the reference's tables grow with
-        // the largest quality seen (covariateutils.cc:108-112) and would model it; this restatement and the engine keep
-        // 94 quality rows and leave such a base out of EVERY covariate, the read-group totals included (a departure,
-        // DESIGN.md section 7; the engine reports it, kbbq_stats_get [8]).
+        // Any quality 0..255 is counted (a BAM can hold values above KBBQ_MAXQ = 93, 0xFF for "missing"): the
+        // reference's tables grow to q + 1 rows (covariateutils.cc:70,108,156) and model such a base like any other;
+        // only the OUTPUT is clamped to 93 (readutils.cc:592-594).
         for (size_t i = 0; i < rd.seq.size(); ++i) {
             const size_t qq = rd.qual[i];
-            if (qq >= (size_t)NQ) continue;
             rg[r * 2] += rd.err[i];
             rg[r * 2 + 1] += 1;
             q[(r * NQ + qq) * 2] += rd.err[i];
@@ -944,7 +944,7 @@ void recalibrate(const Read &rd, const Dq &d, int minqual, uint8_t *out) {
     for (size_t i = 0; i < rd.seq.size(); ++i) {
         const int q = rd.qual[i];
         int v = q;
-        if (q >= minqual && q < NQ && r < d.R && i < d.C) {
+        if (q >= minqual && r < d.R && i < d.C) {
             v = d.meanq[r] + d.rgdq[r] + d.qdq[r * NQ + q] + d.cydq[((r * NQ + q) * 2 + (rd.second ? 1 : 0)) * d.C + i];
             if (i > 0) {
                 const int a = rd.seq[i - 1], b = rd.seq[i];

@@ -20,7 +20,7 @@ u64p = ctypes.POINTER(ctypes.c_uint64)
 c_u64 = ctypes.c_uint64
 c_u32 = ctypes.c_uint32
 c_dbl = ctypes.c_double
-NQ = 94
+NQ = 256
 
 
 _NATIVE = False

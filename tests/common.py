@@ -13,6 +13,8 @@ from kbbq_amd.engine import Engine, plan_parameters  # noqa: E402
 from kbbq_amd.reads import ReadBatch  # noqa: E402
 from oracle import pyoracle  # noqa: E402  (tests are allowed to use the oracle)
 
+NQ = pyoracle.NQ      # quality rows of every covariate / delta-Q table (include/kbbq_engine.h: KBBQ_NQ)
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

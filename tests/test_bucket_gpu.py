@@ -91,48 +91,3 @@ def test_bucketed_equals_direct_on_a_filter_of_many_level1_buckets(records, monk
     assert int(b[2].ne(0).sum()) > 0
     if records:
         assert b[5]["bucket_flushes"][1] >= 2
-
-
-def test_level1_regions_per_xcd_give_the_same_filters():
-    """KBBQ_BUCKET_SHARED=1: one level-1 region per (XCD, bucket) filled through global atomics instead of one per
-    emitting workgroup (bucket.h) -- read once per process, hence the child process."""
-    import os
-    import subprocess
-    import sys
-    code = ("import sys; sys.path.insert(0, 'tests'); import common\n"
-            "for name in ('uniform_150', 'ragged_2rg_paired', 'reads_400'):\n"
-            "    build, dkw, rkw, ekw = common.PARITY_CASES[name]\n"
-            "    d = build(**dkw)\n"
-            "    eng = common.run_engine(d, **rkw, **dict(ekw, n_batches=3))\n"
-            "    common.assert_same_run(eng, common.run_oracle(d, **rkw))\n"
-            "    assert eng['stats']['bucket_capacity'] > 0\n"
-            "print('shared regions ok')\n")
-    env = dict(os.environ, KBBQ_BUCKET="1", KBBQ_BUCKET_SHARED="1")
-    out = subprocess.run([sys.executable, "-c", code], cwd=common.ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "shared regions ok" in out.stdout, out.stdout + out.stderr
-
-
-def test_bucketed_lookup_chain_reproduces_k_infer():
-    """kbbq_amd/csrc/lookup.h is a measurement harness (the chain loses to the direct kernel, profiles/r02_lookup_probe.txt),
-    but what it measures must be the real work: with KBBQ_LOOKUP_PROBE=2 every uniform batch of pass 2 also goes through
-    emit -> split -> slice test in LDS -> ids -> bits -> deferred k_infer, and the insert decisions are compared with the
-    product kernel's.  The switch is read once per process, hence the child process."""
-    import os
-    import subprocess
-    import sys
-
-    code = (
-        "import sys; sys.path.insert(0, %r); import common\n"
-        "maker, dkw, rkw, ekw = common.PARITY_CASES['uniform_150']\n"
-        "d = maker(**dict(dkw, genome_len=120000))\n"
-        "eng = common.run_engine(d, **rkw, **dict(ekw, n_batches=3))\n"
-        "ora = common.run_oracle(d, **rkw)\n"
-        "common.assert_same_run(eng, ora)\n" % os.path.dirname(os.path.abspath(__file__))
-    )
-    env = dict(os.environ, KBBQ_LOOKUP_PROBE="2", KBBQ_BUCKET="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stderr.splitlines() if "insert decisions differing" in l]
-    assert len(lines) == 3, r.stderr[-2000:]
-    assert all("k_infer's: 0;" in l for l in lines), lines
-    assert lines[-1].rstrip().endswith("so far 0"), lines      # (sized for its batches: no record took the overflow path)

@@ -112,7 +112,7 @@ class OraclePeer:
     def dq_shapes(self):
         c = self.cov
         R, C = c["R"], c["C"]
-        return [(R,), (R,), (R, 94), (R, 94, 2, C), (R, 94, 16)]
+        return [(R,), (R,), (R, common.NQ), (R, common.NQ, 2, C), (R, common.NQ, 16)]
 
     def set_dq(self, dq):
         a = [np.ascontiguousarray(dq[k], dtype=np.int32) for k in ("meanq", "rg", "q", "cycle", "dinuc")]

@@ -55,7 +55,7 @@ int main(void) {
 def test_pack_bases_and_bits():
     rng = np.random.RandomState(0)
     seq = rng.choice(np.frombuffer(b"ACGTNacgtRYn=0123", dtype=np.uint8), size=1003).astype(np.uint8)
-    qual = rng.randint(0, 94, size=1003).astype(np.uint8)
+    qual = rng.randint(0, 256, size=1003).astype(np.uint8)
     off = np.array([0, 100, 100, 400, 1003], dtype=np.uint64)
     b = ReadBatch(seq, qual, off)
     L = pyoracle.lib()
@@ -178,10 +178,11 @@ def test_host_model_equals_oracle_on_random_histograms():
     L = _lib.lib()
     rng = np.random.RandomState(11)
     R, C = 2, 40
-    cyc = np.zeros((R, 94, 2, C, 2), dtype=np.uint64)
-    di = np.zeros((R, 94, 16, 2), dtype=np.uint64)
+    NQ = _lib.NQ
+    cyc = np.zeros((R, NQ, 2, C, 2), dtype=np.uint64)
+    di = np.zeros((R, NQ, 16, 2), dtype=np.uint64)
     for r in range(R):
-        for q in (2, 7, 12, 22, 33, 37, 41):
+        for q in (2, 7, 12, 22, 33, 37, 41, 93, 94, 130, 255):      # (above KBBQ_MAXQ = 93: rows the reference's growing tables would hold too)
             for s in range(2):
                 n_c = rng.randint(5, C + 1)
                 tot = rng.randint(0, 5000, size=n_c)
@@ -200,8 +201,8 @@ def test_host_model_equals_oracle_on_random_histograms():
     c = _lib.Covariates()
     c.n_rg, c.n_cycle = R, C
     c.cycle, c.dinuc = cyc.ctypes.data, di.ctypes.data
-    out = dict(meanq=np.zeros(R, np.int32), rg=np.zeros(R, np.int32), q=np.zeros((R, 94), np.int32),
-               cycle=np.zeros((R, 94, 2, C), np.int32), dinuc=np.zeros((R, 94, 16), np.int32))
+    out = dict(meanq=np.zeros(R, np.int32), rg=np.zeros(R, np.int32), q=np.zeros((R, NQ), np.int32),
+               cycle=np.zeros((R, NQ, 2, C), np.int32), dinuc=np.zeros((R, NQ, 16), np.int32))
     d = _lib.Dq()
     d.meanq, d.rgdq, d.qdq, d.cycledq, d.dinucdq = (out[k].ctypes.data for k in ("meanq", "rg", "q", "cycle", "dinuc"))
     _lib.check(L.kbbq_host_train(ctypes.byref(c), ctypes.byref(d)))

@@ -556,23 +556,39 @@ def test_overlapped_and_in_order_pass3_agree_on_device_batches():
     assert outs[0] == outs[1]
 
 
-def test_qualities_above_93_are_reported_and_handled_like_the_oracle():
-    """The reference's covariate tables end at KBBQ_MAXQ = 93 and a larger quality (a BAM can hold 255) indexes past them;
-    oracle and engine leave such a base out of the model, write it as 93 (the clamp of readutils.cc:592-594) and the
-    engine says that it met one (kbbq_stats_get [8])."""
+def test_qualities_above_93_are_modelled_like_the_reference_s_growing_tables():
+    """A quality is a uint8_t and a BAM can hold up to 255 (0xFF = "missing").  The reference's covariate tables grow
+    with the largest quality seen (covariateutils.cc:65-76,102-116,147-164), so such a base is tallied, gets delta-Q
+    rows of its own (the model's candidates stay 0..93, :49,85,128,175) and only the OUTPUT is clamped to 93
+    (readutils.cc:592-594).  Engine and oracle carry 256 quality rows: histograms, delta-Q tables and qualities equal."""
     d = common.make_dataset(seed=919, genome_len=15000, coverage=24, extra_errors=40)
-    plain = common.run_engine(d, uniform=True, n_batches=2)
-    assert plain["stats"]["quality_above_93"] is False
     rng = np.random.RandomState(3)
     q = d["qual"].copy()
-    at = rng.choice(len(q), size=300, replace=False)
+    at = rng.choice(len(q), size=3000, replace=False)
     q[at] = rng.choice([94, 95, 96, 120, 200, 255], size=len(at)).astype(np.uint8)
     d2 = dict(d, qual=np.ascontiguousarray(q))
-    eng = common.run_engine(d2, uniform=True, n_batches=2)
     ora = common.run_oracle(d2)
-    common.assert_same_run(eng, ora)
-    assert eng["stats"]["quality_above_93"] is True
-    assert (np.asarray(eng["recal"])[at] == 93).all()
+    assert int(ora["cov"]["q"][0, 94:, 1].sum()) == len(at)          # the oracle did count them
+    assert int(np.abs(ora["dq"]["cycle"][0, 94:]).sum()) > 0         # ... and trained rows for them
+    for kw in (dict(uniform=True, n_batches=2), dict(uniform=False, n_batches=3)):
+        eng = common.run_engine(d2, **kw)
+        common.assert_same_run(eng, ora)
+        assert eng["stats"]["quality_above_93"] is False             # (the rounds-1/2 "left out of the model" flag is gone)
+    assert (np.asarray(eng["recal"]) <= 93).all()
+    # the command line's flow: batches uploaded once, hint arrays, pass 3 on two streams
+    import fuzz_parity
+    fuzz_parity.same_resident(fuzz_parity.run_resident(d2, 32, None, 1, True, 3), ora)
+    # pass 3 on its own (--fixed mode: no pass 2 has announced the quality values): same histograms
+    from kbbq_amd.reads import pack_bits
+    alpha_ld, cov, approx = plan_parameters(d2["genome_len"], d2["coverage"], None)
+    for uniform in (True, False):
+        e = Engine(32, alpha_ld, 777, approx, n_rg=1, max_read_len=150)
+        b = ReadBatch(d2["seq"], d2["qual"], d2["off"], d2["rg"], d2["second"], uniform=uniform)
+        e.tally(b, pack_bits(np.asarray(ora["errors"], dtype=np.uint8)))
+        ec = e.covariates()
+        e.close()
+        for key in ("rg", "q", "cycle", "dinuc"):
+            assert np.array_equal(ec[key], ora["cov"][key]), key
 
 
 @pytest.mark.parametrize("piece", ["64", "4160", "70000"])
