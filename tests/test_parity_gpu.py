@@ -564,12 +564,14 @@ def test_qualities_above_93_are_modelled_like_the_reference_s_growing_tables():
     d = common.make_dataset(seed=919, genome_len=15000, coverage=24, extra_errors=40)
     rng = np.random.RandomState(3)
     q = d["qual"].copy()
-    at = rng.choice(len(q), size=3000, replace=False)
-    q[at] = rng.choice([94, 95, 96, 120, 200, 255], size=len(at)).astype(np.uint8)
+    cand = np.nonzero(q == 37)[0]                  # two fifths of the best bases get a quality above 93: enough of them for
+    at = rng.choice(cand, size=len(cand) * 2 // 5, replace=False)      # the model to give those rows deltas of their own
+    q[at] = rng.choice([94, 95, 120, 200, 255], size=len(at)).astype(np.uint8)
     d2 = dict(d, qual=np.ascontiguousarray(q))
     ora = common.run_oracle(d2)
     assert int(ora["cov"]["q"][0, 94:, 1].sum()) == len(at)          # the oracle did count them
-    assert int(np.abs(ora["dq"]["cycle"][0, 94:]).sum()) > 0         # ... and trained rows for them
+    assert int(np.abs(ora["dq"]["q"][0, 94:]).sum()) > 0             # ... and trained rows for them
+    assert (ora["recal"][at] < 93).all()                             # ... so they are not simply clamped
     for kw in (dict(uniform=True, n_batches=2), dict(uniform=False, n_batches=3)):
         eng = common.run_engine(d2, **kw)
         common.assert_same_run(eng, ora)
@@ -580,15 +582,20 @@ def test_qualities_above_93_are_modelled_like_the_reference_s_growing_tables():
     fuzz_parity.same_resident(fuzz_parity.run_resident(d2, 32, None, 1, True, 3), ora)
     # pass 3 on its own (--fixed mode: no pass 2 has announced the quality values): same histograms
     from kbbq_amd.reads import pack_bits
+    from oracle import pyoracle
     alpha_ld, cov, approx = plan_parameters(d2["genome_len"], d2["coverage"], None)
+    flags = np.asarray(ora["errors"], dtype=np.uint8)
+    o = pyoracle.Oracle(32, alpha_ld, 777, approx)
+    o.tally(d2["seq"], d2["qual"], d2["off"], np.ascontiguousarray(d2["rg"], np.int32), d2["second"], flags)
+    want = o.covariates()
     for uniform in (True, False):
         e = Engine(32, alpha_ld, 777, approx, n_rg=1, max_read_len=150)
         b = ReadBatch(d2["seq"], d2["qual"], d2["off"], d2["rg"], d2["second"], uniform=uniform)
-        e.tally(b, pack_bits(np.asarray(ora["errors"], dtype=np.uint8)))
+        e.tally(b, pack_bits(flags))
         ec = e.covariates()
         e.close()
         for key in ("rg", "q", "cycle", "dinuc"):
-            assert np.array_equal(ec[key], ora["cov"][key]), key
+            assert np.array_equal(ec[key], want[key]), key
 
 
 @pytest.mark.parametrize("piece", ["64", "4160", "70000"])
