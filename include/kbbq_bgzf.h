@@ -1,0 +1,70 @@
+/* kbbq_bgzf.h -- C ABI of the MI355X BGZF writer (libkbbq_engine.so): record assembly, DEFLATE and CRC-32 as HIP
+ * kernels, compressed blocks back to the host in file order.
+ *
+ * What it replaces: the reference hands every output record to htslib's BGZF layer -- FastqFile::write builds
+ * "@name\nseq\n+comment\nqual\n" and calls bgzf_write (htsiter.cc:75-86; the comment goes on the '+' line),
+ * BamFile::write calls sam_write1 on a BGZF handle (htsiter.cc:45) -- which deflates the stream in blocks of 0xff00
+ * payload bytes on the host.  At the engine's rate the host deflate is 85 % of the command line's wall time, so the
+ * writer moves to the GPU: the caller submits a payload (bytes it has formatted itself, or the pieces of FASTQ
+ * records whose text the device assembles around the recalibrated qualities it already holds) and gets back finished
+ * BGZF blocks to write out in order.  The DECOMPRESSED stream is byte-identical to what the host writer produces; the
+ * compressed bytes are this encoder's own (a valid RFC 1951 / RFC 1952 / SAM-spec BGZF stream, any inflater reads it).
+ *
+ * Plain pointers and sizes; 0 or a negative errno-style code; kbbq_last_error() (kbbq_engine.h) has the text.
+ * One host thread per kbbq_bgzf.  Up to two submissions may be in flight: submit(i + 1) is queued while the caller
+ * writes the blocks of collect(i).
+ */
+#ifndef KBBQ_BGZF_H
+#define KBBQ_BGZF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KBBQ_BGZF_PAYLOAD 0xff00   /* payload bytes per block: htslib's BGZF_BLOCK_SIZE */
+
+typedef struct kbbq_bgzf kbbq_bgzf;
+
+int kbbq_bgzf_create(int32_t device, kbbq_bgzf **out);
+void kbbq_bgzf_destroy(kbbq_bgzf *z);
+
+/* Queue the compression of n payload bytes (n > 0) as consecutive BGZF blocks of KBBQ_BGZF_PAYLOAD bytes, the last one
+ * shorter (no EOF block: kbbq_bgzf_eof_block).  payload is device memory if payload_on_device, host memory otherwise
+ * (page-locked memory, kbbq_host_alloc, is copied by DMA); a host payload is the caller's again when the call returns.
+ * after_stream: a hipStream_t (or NULL) whose work queued so far must finish first -- e.g. kbbq_engine_stream(e)
+ * when the payload is produced by the engine.  KBBQ_ESTATE when two submissions are already in flight. */
+int kbbq_bgzf_submit(kbbq_bgzf *z, const void *payload, uint64_t n, int32_t payload_on_device, void *after_stream);
+
+/* One batch of FASTQ records whose text the device assembles (FastqFile::write, htsiter.cc:75-86):
+ *   blob   host memory: for every record its name, comment and sequence text back to back (no separators)
+ *   lens   host memory: 3 x n_records lengths (name, comment, sequence)
+ *   d_qual DEVICE memory: the batch's new qualities as phred values, read r at d_qual[qual_offset(r)]; the text gets q + 33
+ *   d_qual_offsets DEVICE memory: n_records + 1 base offsets, or NULL for equally long reads of uniform_len bases
+ * The record text is "@" name "\n" seq "\n+" comment "\n" qual "\n".  Then as kbbq_bgzf_submit. */
+int kbbq_bgzf_submit_fastq(kbbq_bgzf *z, const char *blob, const uint32_t *lens, uint64_t n_records, const uint8_t *d_qual,
+                           const uint64_t *d_qual_offsets, uint32_t uniform_len, void *after_stream);
+
+/* Wait for the oldest submission: *blocks points at its BGZF blocks, back to back in file order, *n_bytes long, in
+ * page-locked memory of the writer, valid until the next kbbq_bgzf_submit* call that reuses the slot (i.e. the second
+ * one from now).  *payload_bytes (optional) = the uncompressed size. */
+int kbbq_bgzf_collect(kbbq_bgzf *z, const uint8_t **blocks, uint64_t *n_bytes, uint64_t *payload_bytes);
+
+/* The 28-byte empty block that ends a BGZF file. */
+const uint8_t *kbbq_bgzf_eof_block(void);
+/* Upper bound of the compressed size of n payload bytes (every block stored). */
+uint64_t kbbq_bgzf_bound(uint64_t n);
+
+/* Milliseconds the device spent in the writer's kernels since creation (format, deflate, gather), for reports. */
+int kbbq_bgzf_kernel_ms(kbbq_bgzf *z, double *format_ms, double *deflate_ms, double *gather_ms);
+
+/* ---- host-only twin (no GPU touched): the same scalar pieces (Huffman lengths, header, token bits, CRC chaining,
+ * framing) around a serial match finder; lets the CPU test-suite inflate what those pieces produce. */
+int kbbq_host_bgzf_compress(const uint8_t *payload, uint64_t n, uint8_t *out, uint64_t out_capacity, uint64_t *out_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KBBQ_BGZF_H */

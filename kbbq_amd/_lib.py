@@ -130,6 +130,16 @@ SYMBOLS = {
     "kbbq_host_train": (ctypes.c_int, [ctypes.POINTER(Covariates), ctypes.POINTER(Dq)]),
     "kbbq_host_bernoulli_threshold": (c_u64, [ctypes.c_double, c_i32p]),
     "kbbq_rng_state_at": (ctypes.c_int, [ctypes.c_uint32, c_u64, c_u64p]),
+    # include/kbbq_bgzf.h: the BGZF writer on the device
+    "kbbq_bgzf_create": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(c_vp)]),
+    "kbbq_bgzf_destroy": (None, [c_vp]),
+    "kbbq_bgzf_submit": (ctypes.c_int, [c_vp, c_vp, c_u64, ctypes.c_int32, c_vp]),
+    "kbbq_bgzf_submit_fastq": (ctypes.c_int, [c_vp, c_vp, c_vp, c_u64, c_vp, c_vp, ctypes.c_uint32, c_vp]),
+    "kbbq_bgzf_collect": (ctypes.c_int, [c_vp, ctypes.POINTER(c_vp), c_u64p, c_u64p]),
+    "kbbq_bgzf_eof_block": (c_vp, []),
+    "kbbq_bgzf_bound": (c_u64, [c_u64]),
+    "kbbq_bgzf_kernel_ms": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "kbbq_host_bgzf_compress": (ctypes.c_int, [c_vp, c_u64, c_vp, c_u64, c_u64p]),
 }
 
 _LIB = None

@@ -1,0 +1,367 @@
+// bgzf_device.h -- the BGZF writer's kernels (gfx950): FASTQ record assembly, one DEFLATE block + CRC-32 per
+// wavefront, and the gather of the finished blocks into file order.  Included once by bgzf_device.hip.
+//
+//   k_fastq_text   "@name\nseq\n+comment\nqual\n" per record (FastqFile::write, htsiter.cc:75-86), one wavefront per
+//                  record, the quality line straight from the recalibrated qualities in HBM (+33, htsiter.cc:61-65)
+//   k_deflate      one BGZF block of <= 0xff00 payload bytes per wavefront: LZ77 matches over a hash table in LDS,
+//                  64 positions per step; dynamic Huffman codes from the block's own counts; the bits of 64 tokens per step
+//                  placed by a wave prefix sum; CRC-32 of 64 slices chained by their x^(8 n) factors
+//   k_block_offsets / k_gather   exclusive sum of the block sizes, blocks copied back to back
+//
+// Integer / byte work, no MFMA.  The encoder is built for HBM-resident text that never visits the host uncompressed:
+// what leaves the GPU is the compressed stream (about a quarter of the text).  A wavefront works through its block at its
+// own pace -- the chip holds a couple of thousand of them -- so the per-block algorithms are simple and mostly serial
+// within the wave; the scalar pieces (Huffman lengths, header, token bits) are shared with the host twin
+// (deflate_common.h) and run on lane 0.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "deflate_common.h"
+
+namespace kbbq {
+namespace dfl {
+
+constexpr int HASH_BITS = 13;                       // 8192 most-recent positions per wave: 16 KB of LDS
+constexpr int HASH_SIZE = 1 << HASH_BITS;
+constexpr int DFL_WAVES = 1;                        // wavefronts per workgroup: each works alone (no workgroup barrier anywhere), 18 KB of LDS
+constexpr int MIN_TAKE = 4;                         // shortest match the 4-byte hash can find
+constexpr uint32_t SLOT_BYTES = 65536 + 64;         // one finished block per slot; its bytes start at SLOT_SHIFT so that
+constexpr uint32_t SLOT_SHIFT = 6;                  // the DEFLATE stream (behind the 18-byte header) is 8-byte aligned
+constexpr uint32_t TOKENS_PER_WAVE = 65536;
+
+struct DeflateArgs {
+    const uint8_t *payload;     // n bytes (+ 16 readable bytes behind them)
+    uint64_t n;
+    uint32_t n_blocks;
+    uint8_t *slots;             // n_blocks x SLOT_BYTES, zeroed
+    uint32_t *sizes;            // n_blocks: bytes of every finished block
+    uint32_t *tokens;           // per wavefront of the grid: TOKENS_PER_WAVE words
+};
+
+__device__ __forceinline__ uint64_t load8(const uint8_t *p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ uint32_t hash4(uint32_t v) { return (v * 2654435761u) >> (32 - HASH_BITS); }
+
+// length of the common prefix of in[a..] and in[b..], at most lim (a < b; reads stay inside [0, len + 8))
+__device__ __forceinline__ int match_length(const uint8_t *in, int a, int b, int lim) {
+    int n = 0;
+    while (n < lim) {
+        const uint64_t x = load8(in + a + n) ^ load8(in + b + n);
+        if (x) { n += (int)(__builtin_ctzll(x) >> 3); break; }
+        n += 8;
+    }
+    return n < lim ? n : lim;
+}
+
+// LDS of one wavefront.  The Huffman scratch of the second phase lies over the hash table of the first.
+struct WaveLds {
+    union {
+        uint16_t htab[HASH_SIZE];
+        struct {
+            uint8_t head[HEAD_BYTES];
+            uint16_t order[N_LL];
+            uint32_t w[N_LL];
+            uint16_t runs[N_LL + N_D];
+        } hs;
+    } u;
+    uint32_t ll_freq[N_LL];
+    uint32_t d_freq[N_D];
+    BlockCodes codes;
+};
+
+__global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
+    __shared__ WaveLds lds_all[DFL_WAVES];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    WaveLds &S = lds_all[wv];
+    const uint32_t wave = blockIdx.x * DFL_WAVES + wv, n_waves = gridDim.x * DFL_WAVES;
+    uint32_t *tokens = A.tokens + (size_t)wave * TOKENS_PER_WAVE;
+    const uint64_t lane_lt = (1ull << lane) - 1;
+    for (uint32_t blk = wave; blk < A.n_blocks; blk += n_waves) {
+        const uint8_t *in = A.payload + (uint64_t)blk * BGZF_PAYLOAD;
+        const int len = (int)min((uint64_t)BGZF_PAYLOAD, A.n - (uint64_t)blk * BGZF_PAYLOAD);
+        uint8_t *slot = A.slots + (size_t)blk * SLOT_BYTES;
+        uint8_t *block = slot + SLOT_SHIFT;                    // BGZF header here, the DEFLATE stream 18 bytes on
+        unsigned long long *body64 = reinterpret_cast<unsigned long long *>(block + BGZF_HEAD);
+
+        // ---- reset
+        for (int i = lane; i < HASH_SIZE; i += 64) S.u.htab[i] = 0xFFFFu;
+        for (int i = lane; i < N_LL; i += 64) S.ll_freq[i] = 0;
+        if (lane < N_D) S.d_freq[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- CRC-32: 64 slices, one per lane, chained below
+        const int slice = (len + 63) / 64;
+        uint32_t crc_r = 0;
+        int my_len = 0;
+        {
+            const int a = min(len, lane * slice), b = min(len, a + slice);
+            my_len = b - a;
+            int i = a;
+            for (; i + 8 <= b; i += 8) {
+                uint64_t v = load8(in + i);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    crc_r ^= (uint32_t)(v & 0xFF);
+                    v >>= 8;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) crc_r = (crc_r >> 1) ^ (0xEDB88320u & (0u - (crc_r & 1u)));
+                }
+            }
+            for (; i < b; ++i) {
+                crc_r ^= in[i];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) crc_r = (crc_r >> 1) ^ (0xEDB88320u & (0u - (crc_r & 1u)));
+            }
+        }
+        const uint32_t my_xpow = crc_xpow8((uint64_t)my_len);
+
+        // ---- LZ77, 64 positions per step
+        int next_free = 0;       // first position not covered by a token yet
+        uint32_t n_tok = 0;
+        for (int b0 = 0; b0 < len; b0 += 64) {
+            const int p = b0 + lane;
+            const bool in_block = p < len;
+            const bool hashed = p + 4 <= len;
+            uint64_t cur = 0;
+            uint32_t h = 0;
+            int L = 0, D = 0;
+            if (in_block) cur = load8(in + p);
+            if (hashed) {
+                h = hash4((uint32_t)cur);
+                const int cand = S.u.htab[h];
+                const int lim = min((int)MAX_MATCH, len - p);
+                if (cand != 0xFFFF && p - cand <= MAX_DIST) {
+                    const int n = match_length(in, cand, p, lim);
+                    if (n >= MIN_TAKE) { L = n; D = p - cand; }
+                }
+                // a run of one byte (the candidate the table cannot hold: the position just before, inside this step)
+                if (p > 0 && in[p - 1] == (uint8_t)cur) {
+                    const int n = match_length(in, p - 1, p, lim);
+                    if (n >= MIN_TAKE && n > L) { L = n; D = 1; }
+                }
+            }
+            // the step's positions go into the table; of several lanes with one hash the highest position stays
+            if (hashed) S.u.htab[h] = (uint16_t)p;
+            __builtin_amdgcn_wave_barrier();
+            for (;;) {
+                const bool lose = hashed && S.u.htab[h] < (uint16_t)p;
+                if (!__ballot(lose)) break;
+                if (lose) S.u.htab[h] = (uint16_t)p;
+                __builtin_amdgcn_wave_barrier();
+            }
+            // greedy parse with one step of lazy evaluation: the positions where a token starts, and which are matches
+            const uint64_t valid = __ballot(in_block);
+            const uint64_t mm = __ballot(L >= MIN_TAKE);
+            uint64_t starts = 0, taken = 0;
+            int rel = next_free - b0;
+            while (rel < 64) {
+                const uint64_t from = ~0ull << rel;
+                const uint64_t ahead = mm & from;
+                if (!ahead) { starts |= from & valid; rel = 64; break; }
+                const int m = (int)__builtin_ctzll(ahead);
+                starts |= from & ((1ull << m) - 1);              // literals up to the match
+                const int Lm = __builtin_amdgcn_readlane(L, m);
+                if (m + 1 < 64 && ((mm >> (m + 1)) & 1) && __builtin_amdgcn_readlane(L, m + 1) > Lm) {
+                    starts |= 1ull << m;                         // a longer match starts one byte on: this byte is a literal
+                    rel = m + 1;
+                    continue;
+                }
+                starts |= 1ull << m;
+                taken |= 1ull << m;
+                rel = m + Lm;
+            }
+            next_free = b0 + rel;
+            const bool start = (starts >> lane) & 1, is_match = (taken >> lane) & 1;
+            if (start) {
+                uint32_t t;
+                if (is_match) {
+                    t = token_match(L, D);
+                    int ls, e, v, ds;
+                    length_symbol(L, ls, e, v);
+                    distance_symbol(D, ds, e, v);
+                    atomicAdd(&S.ll_freq[ls], 1u);
+                    atomicAdd(&S.d_freq[ds], 1u);
+                } else {
+                    t = token_literal((uint8_t)cur);
+                    atomicAdd(&S.ll_freq[(uint8_t)cur], 1u);
+                }
+                tokens[n_tok + (uint32_t)__popcll(starts & lane_lt)] = t;
+            }
+            n_tok += (uint32_t)__popcll(starts);
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- codes and header (lane 0; the scratch lies over the hash table, which is done with)
+        for (int i = lane; i < HEAD_BYTES; i += 64) S.u.hs.head[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            S.ll_freq[256] += 1;      // end of block
+            build_block_codes(S.ll_freq, S.d_freq, S.codes, S.u.hs.head, S.u.hs.order, S.u.hs.w, S.u.hs.runs);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t head_bits = S.codes.head_bits;
+
+        // ---- how long is the dynamic form?  counts x code lengths (+ extra bits) over the two alphabets; the end-of-block
+        // symbol is in the counts
+        uint64_t my_bits = 0;
+        for (int s = lane; s < N_LL; s += 64) {
+            const int eb = (s >= 265 && s < 285) ? (s - 261) >> 2 : 0;
+            my_bits += (uint64_t)S.ll_freq[s] * (uint64_t)(S.codes.ll_len[s] + eb);
+        }
+        if (lane < N_D) my_bits += (uint64_t)S.d_freq[lane] * (uint64_t)(S.codes.d_len[lane] + (lane >= 4 ? (lane >> 1) - 1 : 0));
+        for (int o = 32; o > 0; o >>= 1) my_bits += __shfl_xor(my_bits, o);
+        const uint64_t total_bits = (uint64_t)head_bits + my_bits;
+        const uint32_t dyn_bytes = (uint32_t)((total_bits + 7) >> 3), stored_bytes = (uint32_t)len + 5;
+        uint32_t body_bytes;
+        if (dyn_bytes < stored_bytes && dyn_bytes + BGZF_HEAD + BGZF_TAIL <= (uint32_t)BGZF_MAX_BLOCK) {
+            // header bits, then the tokens 64 at a time: exclusive prefix sum of their lengths, bits OR-ed into the zeroed slot
+            for (uint32_t i = lane; i * 8 < head_bits; i += 64) {
+                uint64_t v = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v |= (uint64_t)S.u.hs.head[i * 8 + k] << (8 * k);
+                if (v) atomicOr(&body64[i], (unsigned long long)v);
+            }
+            uint64_t base = head_bits;
+            for (uint32_t i0 = 0; i0 < n_tok; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                uint64_t v = 0;
+                int nb = 0;
+                if (i < n_tok) token_bits(tokens[i], S.codes, v, nb);
+                int incl = nb;
+                for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+                const uint64_t at = base + (uint64_t)(incl - nb);
+                if (nb) {
+                    const uint32_t word = (uint32_t)(at >> 6), sh = (uint32_t)(at & 63);
+                    atomicOr(&body64[word], (unsigned long long)(v << sh));
+                    if (sh + (uint32_t)nb > 64) atomicOr(&body64[word + 1], (unsigned long long)(v >> (64 - sh)));
+                }
+                base += (uint64_t)__shfl(incl, 63);
+            }
+            if (lane == 0) {
+                const uint64_t v = S.codes.ll_code[256];
+                const uint32_t word = (uint32_t)(base >> 6), sh = (uint32_t)(base & 63), nb = S.codes.ll_len[256];
+                atomicOr(&body64[word], (unsigned long long)(v << sh));
+                if (sh + nb > 64) atomicOr(&body64[word + 1], (unsigned long long)(v >> (64 - sh)));
+            }
+            body_bytes = dyn_bytes;
+        } else {
+            // stored block: BFINAL = 1, BTYPE = 00, LEN, ~LEN, the bytes as they are
+            uint8_t *body = block + BGZF_HEAD;
+            if (lane == 0) {
+                body[0] = 1;
+                body[1] = (uint8_t)(len & 0xFF); body[2] = (uint8_t)(len >> 8);
+                body[3] = (uint8_t)(~len & 0xFF); body[4] = (uint8_t)((~len >> 8) & 0xFF);
+            }
+            for (int i = lane; i < len; i += 64) body[5 + i] = in[i];
+            body_bytes = stored_bytes;
+        }
+        // ---- CRC chain, framing
+        uint32_t reg = 0xFFFFFFFFu;
+        for (int l = 0; l < 64; ++l) {
+            const uint32_t r = __builtin_amdgcn_readlane(crc_r, l), x = __builtin_amdgcn_readlane(my_xpow, l);
+            const int n = __builtin_amdgcn_readlane(my_len, l);
+            if (n) reg = crc_chain(reg, r, x);
+        }
+        // (atomic / plain stores of this wave to its own slot: complete before the kernel ends, nobody else reads them earlier)
+        if (lane == 0) {
+            const uint32_t total = BGZF_HEAD + body_bytes + BGZF_TAIL;
+            bgzf_header(block, total);
+            A.sizes[blk] = total;
+        }
+        // (the trailer may share an 8-byte word with the last bits of the stream: a byte store and an atomic OR of zeros
+        // into those bytes give the same word in either order)
+        if (lane == 0) bgzf_trailer(block + BGZF_HEAD + body_bytes, reg ^ 0xFFFFFFFFu, (uint32_t)len);
+    }
+}
+
+// exclusive sum of the block sizes (one workgroup; a batch has a few thousand blocks), total in offsets[n]
+__global__ void __launch_bounds__(1024) k_block_offsets(const uint32_t *sizes, uint32_t n, uint64_t *offsets) {
+    __shared__ uint64_t part[1024];
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t a = min(n, per * threadIdx.x), b = min(n, a + per);
+    uint64_t s = 0;
+    for (uint32_t i = a; i < b; ++i) s += sizes[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t run = 0;
+        for (int i = 0; i < 1024; ++i) { const uint64_t v = part[i]; part[i] = run; run += v; }
+        offsets[n] = run;
+    }
+    __syncthreads();
+    uint64_t run = part[threadIdx.x];
+    for (uint32_t i = a; i < b; ++i) { offsets[i] = run; run += sizes[i]; }
+}
+
+// one workgroup per block: slot -> its place in the output
+__global__ void __launch_bounds__(256) k_gather(const uint8_t *slots, const uint32_t *sizes, const uint64_t *offsets, uint8_t *out) {
+    const uint32_t blk = blockIdx.x;
+    const uint8_t *src = slots + (size_t)blk * SLOT_BYTES + SLOT_SHIFT;
+    uint8_t *dst = out + offsets[blk];
+    const uint32_t n = sizes[blk];
+    // (source 2 bytes off an 8-byte boundary, destination anywhere: bytes up to the destination's first 8-byte boundary,
+    // 8-byte stores from unaligned 8-byte loads, bytes for the tail)
+    const uint32_t lead = min(n, (uint32_t)((8 - ((uintptr_t)dst & 7)) & 7));
+    for (uint32_t i = threadIdx.x; i < lead; i += blockDim.x) dst[i] = src[i];
+    const uint32_t words = (n - lead) >> 3;
+    for (uint32_t w = threadIdx.x; w < words; w += blockDim.x)
+        *reinterpret_cast<uint64_t *>(dst + lead + (size_t)w * 8) = load8(src + lead + (size_t)w * 8);
+    for (uint32_t i = lead + words * 8 + threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
+// ---- FASTQ record text ------------------------------------------------------------------------------------------------
+struct FastqArgs {
+    const uint8_t *blob;          // name | comment | sequence of every record, back to back
+    const uint32_t *lens;         // 3 per record
+    const uint64_t *blob_off;     // n + 1: where a record's pieces start in blob
+    const uint64_t *text_off;     // n + 1: where its text starts
+    const uint8_t *qual;          // new qualities (phred) of the batch
+    const uint64_t *qual_off;     // n + 1, or null: record r at r * uniform_len
+    uint32_t uniform_len;
+    uint64_t n_records;
+    uint8_t *text;
+};
+
+// per-record sizes of blob and text (the scans turn them into offsets)
+__global__ void k_fastq_sizes(const uint32_t *lens, uint64_t n, uint64_t *blob_sz, uint64_t *text_sz) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint64_t nl = lens[3 * r], cl = lens[3 * r + 1], sl = lens[3 * r + 2];
+    blob_sz[r] = nl + cl + sl;
+    text_sz[r] = nl + cl + 2 * sl + 6;      // '@' '\n' '\n' '+' '\n' '\n'
+}
+
+__global__ void __launch_bounds__(256) k_fastq_text(FastqArgs F) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * 4;
+    for (uint64_t r = wave; r < F.n_records; r += n_waves) {
+        const uint32_t nl = F.lens[3 * r], cl = F.lens[3 * r + 1], sl = F.lens[3 * r + 2];
+        const uint8_t *name = F.blob + F.blob_off[r], *comment = name + nl, *seq = comment + cl;
+        const uint8_t *q = F.qual + (F.qual_off ? F.qual_off[r] : r * (uint64_t)F.uniform_len);
+        uint8_t *out = F.text + F.text_off[r];
+        // "@" name "\n" seq "\n+" comment "\n" qual "\n"
+        const uint32_t a_seq = 1 + nl + 1, a_plus = a_seq + sl, a_com = a_plus + 2, a_q = a_com + cl + 1, total = a_q + sl + 1;
+        for (uint32_t i = lane; i < total; i += 64) {
+            uint8_t c;
+            if (i == 0) c = '@';
+            else if (i < 1 + nl) c = name[i - 1];
+            else if (i < a_seq) c = '\n';
+            else if (i < a_plus) c = seq[i - a_seq];
+            else if (i == a_plus) c = '\n';
+            else if (i == a_plus + 1) c = '+';
+            else if (i < a_com + cl) c = comment[i - a_com];
+            else if (i < a_q) c = '\n';
+            else if (i < a_q + sl) c = (uint8_t)(q[i - a_q] + 33);
+            else c = '\n';
+            out[i] = c;
+        }
+    }
+}
+
+}  // namespace dfl
+}  // namespace kbbq

@@ -75,13 +75,17 @@ DFL_HD void huffman_lengths(const uint32_t *freq, int n, int max_bits, uint8_t *
             if (!used) order[m++] = (uint16_t)s;
         }
         auto count_of = [&](int s) -> uint32_t { const uint32_t f = freq[s] ? freq[s] : 1u; return f < floor_count ? floor_count : f; };
-        // insertion sort by (count, symbol): at most 286 entries, mostly a few dozen
-        for (int i = 1; i < m; ++i) {
-            const uint16_t s = order[i];
-            const uint32_t c = count_of(s);
-            int j = i - 1;
-            while (j >= 0 && (count_of(order[j]) > c || (count_of(order[j]) == c && order[j] > s))) { order[j + 1] = order[j]; --j; }
-            order[j + 1] = s;
+        // Shell sort by (count, symbol): at most 286 entries, a few dozen for text
+        const int gaps[6] = {132, 57, 23, 10, 4, 1};
+        for (int g = 0; g < 6; ++g) {
+            const int gap = gaps[g];
+            for (int i = gap; i < m; ++i) {
+                const uint16_t s = order[i];
+                const uint32_t c = count_of(s);
+                int j = i - gap;
+                while (j >= 0 && (count_of(order[j]) > c || (count_of(order[j]) == c && order[j] > s))) { order[j + gap] = order[j]; j -= gap; }
+                order[j + gap] = s;
+            }
         }
         for (int i = 0; i < m; ++i) w[i] = count_of(order[i]);
         if (m == 2) {
@@ -164,7 +168,7 @@ DFL_HD int cl_order(int i) {
 struct BitSink {
     uint8_t *p;
     uint64_t bitpos;
-    DFL_HD void put(uint32_t value, int nbits) {
+    DFL_HD void put(uint64_t value, int nbits) {
         for (int i = 0; i < nbits; ++i, ++bitpos)
             if ((value >> i) & 1) p[bitpos >> 3] |= (uint8_t)(1u << (bitpos & 7));
     }

@@ -208,6 +208,47 @@ __device__ __forceinline__ void qseen_note(uint32_t *lds_mask, uint32_t q) {
     if (!(lds_mask[q >> 5] & bit)) atomicOr(&lds_mask[q >> 5], bit);
 }
 
+// ---- dynamic distribution of a batch's reads over the wavefronts of a launch --------------------------------------
+// A grid-stride loop gives every wavefront the same number of reads, so the launch runs in rounds of "as many
+// workgroups as the chip holds" and its last round leaves CUs idle (4096 workgroups over 1536 resident ones: 2.67
+// rounds of work in the time of 3).  Here the reads are handed out in chunks of CH consecutive ones by a global
+// counter (zeroed before the launch): a wavefront that starts late, or got cheap reads, simply takes fewer chunks.
+// The next chunk is requested one chunk ahead, so the counter's round trip is hidden, and the caller can still
+// prefetch the read after the current one (peek()).
+template <int CH>
+struct ReadChunks {
+    unsigned int *counter;
+    uint64_t n_reads, cur, end;
+    uint32_t next_chunk;
+    __device__ __forceinline__ uint32_t grab(int lane) {
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(counter, 1u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+    }
+    // first read of this wavefront (>= n_reads: none)
+    __device__ __forceinline__ uint64_t begin(unsigned int *counter_, uint64_t n_reads_, int lane) {
+        counter = counter_;
+        n_reads = n_reads_;
+        const uint32_t c = grab(lane);
+        next_chunk = grab(lane);
+        cur = (uint64_t)c * CH;
+        end = cur + CH < n_reads ? cur + CH : n_reads;
+        return cur;
+    }
+    // the read after `cur` (>= n_reads: none); call once per read, before processing it, then advance with the value
+    __device__ __forceinline__ uint64_t peek(int lane) {
+        if (cur + 1 < end) return cur + 1;
+        const uint64_t nb = (uint64_t)next_chunk * CH;
+        return nb;
+    }
+    __device__ __forceinline__ void advance(int lane) {
+        if (cur + 1 < end) { ++cur; return; }
+        cur = (uint64_t)next_chunk * CH;
+        end = cur + CH < n_reads ? cur + CH : n_reads;
+        if (cur < n_reads) next_chunk = grab(lane);
+    }
+};
+
 // select W[idx] from a small wave-uniform array without dynamic indexing
 template <int NW>
 __device__ __forceinline__ uint64_t sel_word(const uint64_t (&W)[NW], int idx) {

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/kbbq_engine.h"
+#include "abi_internal.h"
 #include "correct.h"
 #include "correct_wave.h"
 #include "device_common.h"
@@ -23,13 +24,14 @@ using namespace kbbq;
 
 // ============================================================ error plumbing
 static thread_local char g_err[512] = "";
-static int fail(int code, const char *fmt, ...) {
+int kbbq_fail(int code, const char *fmt, ...) {      // (abi_internal.h: shared with bgzf_device.hip)
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
     return code;
 }
+#define fail kbbq_fail
 #define HIP_TRY(expr)                                                                                  \
     do {                                                                                               \
         hipError_t _e = (expr);                                                                        \
@@ -133,6 +135,7 @@ struct kbbq_engine {
     void *scratch[24] = {};
     size_t scratch_bytes[24] = {};
     unsigned long long *d_counters = nullptr;   // [0] work-list length, [1] correction queries, [2] scan total
+    unsigned int *d_tickets = nullptr;          // chunk counters of the kernels that hand their reads out dynamically (ReadChunks): [0] k_infer, [1 + side] k_scan_trusted, [3 + side] k_correct_wave
     // Host batches: a ring of device staging slots owned by the engine and a copy stream.  A host batch is copied
     // into the next slot with hipMemcpyAsync on the copy stream (DMA straight from the caller's memory when that is
     // page-locked), the pass's kernels wait for the copy by event, and the entry point returns as soon as the COPY
@@ -314,20 +317,8 @@ struct HostBatchDone {
     }
 };
 
-// Every ABI entry that takes an engine works on the engine's device and leaves the calling thread's current device
-// as it found it (a process that drives several GPUs, or torch with another current device, is not disturbed).
-struct DeviceGuard {
-    int prev = -1;
-    hipError_t err = hipSuccess;
-    explicit DeviceGuard(int device) {
-        err = hipGetDevice(&prev);
-        if (err == hipSuccess && prev != device) err = hipSetDevice(device);
-        else if (err == hipSuccess) prev = -1;      // nothing to restore
-    }
-    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-    DeviceGuard(const DeviceGuard &) = delete;
-    DeviceGuard &operator=(const DeviceGuard &) = delete;
-};
+// (KbbqDeviceGuard, abi_internal.h: the engine's device for the call, the caller's current device restored after it)
+typedef KbbqDeviceGuard DeviceGuard;
 #define ENGINE_DEVICE(e)                                                                              \
     if (!(e)) return fail(KBBQ_EINVAL, "null engine");                                                \
     DeviceGuard engine_device_guard((e)->p.device);                                                   \
@@ -785,6 +776,8 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
     } while (0)
     CREATE_TRY(hipMalloc(&e->d_counters, 64));
     CREATE_TRY(hipMemset(e->d_counters, 0, 64));
+    CREATE_TRY(hipMalloc(&e->d_tickets, 64));
+    CREATE_TRY(hipMemset(e->d_tickets, 0, 64));
     e->cur_cnt = e->d_counters;
     CREATE_TRY(hipMalloc(&e->d_dq_qslot, KBBQ_NQ));
     CREATE_TRY(hipMalloc(&e->d_qpresent, 32));
@@ -847,6 +840,7 @@ void kbbq_engine_destroy(kbbq_engine *e) {
     hipFree(e->d_dq_cycle);
     hipFree(e->d_dq_dinuc);
     hipFree(e->d_counters);
+    hipFree(e->d_tickets);
     hipFree(e->d_dq_qslot);
     hipFree(e->d_qpresent);
     hipFree(e->d_rg_present[0]);
@@ -1436,15 +1430,16 @@ template <int NW> struct LaunchTrusted {
         Thresholds thr;
         memset(&thr, 0, sizeof thr);
         for (size_t i = 0; i < e->thresholds.size() && i <= KBBQ_MAX_KMER; ++i) thr.v[i] = e->thresholds[i];
+        HIP_TRY(hipMemsetAsync(e->d_tickets, 0, 4, e->stream));      // the kernel's chunk counter (ReadChunks)
         {
             Timed t(e, "k_infer");
             // NK: chunks of 64 lanes that can hold a k-mer start (150-base reads, k = 32: 119 starts, two of the three chunks)
             if (std::max(1, max_len - e->p.k + 1) <= (NW - 1) * 64)
                 hipLaunchKernelGGL((k_infer<NW, NW - 1>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
-                                   e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3);
+                                   e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3, e->d_tickets);
             else
                 hipLaunchKernelGGL((k_infer<NW, NW>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
-                                   e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3);
+                                   e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3, e->d_tickets);
             HIP_TRY(hipGetLastError());
         }
         if (bucket_on(e, 1)) {
@@ -1584,13 +1579,15 @@ int kbbq_trusted_finish(kbbq_engine *e, uint64_t *inserted) {
 
 template <int NW> struct LaunchScan {
     static int go(kbbq_engine *e, ReadsDev R, uint64_t *tmask, uint8_t *dirty, uint32_t *err_bits, int fast, int max_len) {
+        unsigned int *ticket = e->d_tickets + 1 + (e->cur_cnt != e->d_counters ? 1 : 0);      // per side of pass 3
+        HIP_TRY(hipMemsetAsync(ticket, 0, 4, e->cur));
         Timed t(e, "k_scan_trusted", e->cur);
         if (std::max(1, max_len - e->p.k + 1) <= (NW - 1) * 64)      // (NK: see k_infer)
             hipLaunchKernelGGL((k_scan_trusted<NW, NW - 1>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->cur, R, e->K,
-                               e->filt[1].dev(), tmask, dirty, err_bits, e->cur_cnt, fast);
+                               e->filt[1].dev(), tmask, dirty, err_bits, e->cur_cnt, fast, ticket);
         else
             hipLaunchKernelGGL((k_scan_trusted<NW, NW>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->cur, R, e->K,
-                               e->filt[1].dev(), tmask, dirty, err_bits, e->cur_cnt, fast);
+                               e->filt[1].dev(), tmask, dirty, err_bits, e->cur_cnt, fast, ticket);
         HIP_TRY(hipGetLastError());
         return KBBQ_OK;
     }

@@ -256,7 +256,7 @@ struct Thresholds { int v[KBBQ_MAX_KMER + 1]; };
 template <int NW, int NK, int MINW = 1>
 __global__ void __launch_bounds__(256, MINW) k_infer(ReadsDev R, KParams K, FiltDev S, Thresholds thr, uint32_t *take_bits,
                                                 unsigned long long *inserted, uint32_t *err_out, uint32_t *qpresent,
-                                                unsigned long long *lookups) {
+                                                unsigned long long *lookups, unsigned int *ticket) {
     using St = Stage<NW>;
     __shared__ uint32_t lds[4][St::LDS_U32];
     __shared__ int thr_lds[KBBQ_MAX_KMER + 1];
@@ -268,27 +268,28 @@ __global__ void __launch_bounds__(256, MINW) k_infer(ReadsDev R, KParams K, Filt
     uint32_t *L32 = lds[threadIdx.x >> 6];
     uint32_t *PW = L32 + 2 * St::WORDS;            // present bits: dword 0 = 0, dwords 1..2NW, then zeros
     uint32_t *EW = PW + St::RES;                   // error bits, same shape
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t *hint = reinterpret_cast<const uint64_t *>(R.hint_sampled);
     const int k = K.k;
     unsigned long long mine = 0, looked = 0;
     if (lane < St::RES) { PW[lane] = 0; EW[lane] = 0; }
     uint64_t off = 0, word = 0;
     uint32_t len = 0;
-    if (wave < R.n_reads) {
-        read_span(R, wave, off, len);
+    ReadChunks<32> Q;      // reads in chunks of 32 from a global counter: no idle last round (device_common.h)
+    uint64_t r = Q.begin(ticket, R.n_reads, lane);
+    if (r < R.n_reads) {
+        read_span(R, r, off, len);
         word = stage_fetch<NW>(R, hint, nullptr, 0, 0, off, lane);
     }
-    for (uint64_t r = wave; r < R.n_reads; r += n_waves) {
+    for (; r < R.n_reads; Q.advance(lane), r = Q.cur) {
         __builtin_amdgcn_wave_barrier();
         if (lane < St::WORDS) stage_store(L32, lane, word);
         __builtin_amdgcn_wave_barrier();
         const uint64_t cur = off;
         const int o31 = (int)(off & 31), o63 = (int)(off & 63);
         const int Lr = (int)len, nk = Lr - k + 1;
-        if (r + n_waves < R.n_reads) {   // the next read's words travel while this one is processed
-            read_span(R, r + n_waves, off, len);
+        const uint64_t r_next = Q.peek(lane);
+        if (r_next < R.n_reads) {   // the next read's words travel while this one is processed
+            read_span(R, r_next, off, len);
             word = stage_fetch<NW>(R, hint, nullptr, 0, 0, off, lane);
         }
         if (nk <= 0) continue;           // engine-defined: the reference underflows size_t here
@@ -508,32 +509,33 @@ __device__ __forceinline__ bool fast_path(const uint32_t *L32, const KParams &K,
 template <int NW, int NK, int MINW = 1>
 __global__ void __launch_bounds__(256, MINW) k_scan_trusted(ReadsDev R, KParams K, FiltDev T, uint64_t *tmask,
                                                        uint8_t *dirty, uint32_t *err_bits, unsigned long long *stats,
-                                                       int fast) {
+                                                       int fast, unsigned int *ticket) {
     using S = Stage<NW>;
     __shared__ uint32_t lds[4][2 * S::WORDS];
     const int lane = threadIdx.x & 63;
     uint32_t *L32 = lds[threadIdx.x >> 6];
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t *hint = reinterpret_cast<const uint64_t *>(R.hint_trusted);
     const int k = K.k;
     unsigned long long q_total = 0;
     uint64_t off = 0, word = 0;
     uint32_t len = 0;
     const uint64_t oc_max = R.n_bases / 64 + 1;
-    if (wave < R.n_reads) {
-        read_span(R, wave, off, len);
+    ReadChunks<32> Q;      // reads in chunks of 32 from a global counter (device_common.h)
+    uint64_t r = Q.begin(ticket, R.n_reads, lane);
+    if (r < R.n_reads) {
+        read_span(R, r, off, len);
         word = stage_fetch<NW>(R, hint, R.offcase, off, oc_max, off, lane);
     }
-    for (uint64_t r = wave; r < R.n_reads; r += n_waves) {
+    for (; r < R.n_reads; Q.advance(lane), r = Q.cur) {
         __builtin_amdgcn_wave_barrier();
         if (lane < S::WORDS) stage_store(L32, lane, word);
         __builtin_amdgcn_wave_barrier();
         const uint64_t cur = off;
         const int o31 = (int)(off & 31), o63 = (int)(off & 63);
         const int Lr = (int)len, nk = Lr - k + 1;
-        if (r + n_waves < R.n_reads) {   // the next read's words travel while this one is processed
-            read_span(R, r + n_waves, off, len);
+        const uint64_t r_next = Q.peek(lane);
+        if (r_next < R.n_reads) {   // the next read's words travel while this one is processed
+            read_span(R, r_next, off, len);
             word = stage_fetch<NW>(R, hint, R.offcase, off, oc_max, off, lane);
         }
         if (nk <= 0) { if (lane == 0) dirty[r] = 0; continue; }
