@@ -200,6 +200,10 @@ int kbbq_reads_free(kbbq_engine *e, kbbq_reads *dev);
  * true DMA at the link's rate.  kbbq_measure_host_link times one `bytes`-sized copy each way from such memory. */
 int kbbq_host_alloc(size_t bytes, void **out);
 int kbbq_host_free(void *p);
+/* Plain device memory on the engine's device (e.g. the output array of kbbq_recalibrate_batch for a resident batch
+ * whose new qualities stay on the GPU for the BGZF writer, kbbq_bgzf.h). */
+int kbbq_device_alloc(kbbq_engine *e, size_t bytes, void **out);
+int kbbq_device_free(kbbq_engine *e, void *p);
 int kbbq_measure_host_link(int32_t device, uint64_t bytes, double *h2d_gbps, double *d2h_gbps);
 /* For both, e may be NULL (current device): a driver can make its batches resident in HBM while it is
  * still counting the bases that size the engine (kbbq.cc:229-264), then run every pass from HBM.

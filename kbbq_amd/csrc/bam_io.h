@@ -108,12 +108,12 @@ private:
 
 class BamWriter {
 public:
-    explicit BamWriter(BgzfWriter &out) : out_(out) {}
+    explicit BamWriter(ByteSink &out) : out_(out) {}
     bool write_header(const BamHeader &h);
     bool write(const BamRecord &rec);
 
 private:
-    BgzfWriter &out_;
+    ByteSink &out_;
 };
 
 }  // namespace kbbq

@@ -1148,6 +1148,24 @@ int kbbq_host_free(void *p) {
     return KBBQ_OK;
 }
 
+int kbbq_device_alloc(kbbq_engine *e, size_t bytes, void **out) {
+    ENGINE_DEVICE(e);
+    if (!out || !bytes) return fail(KBBQ_EINVAL, "bad argument");
+    *out = nullptr;
+    HIP_TRY(hipMalloc(out, bytes));
+    return KBBQ_OK;
+}
+
+int kbbq_device_free(kbbq_engine *e, void *p) {
+    ENGINE_DEVICE(e);
+    if (p) {
+        int rc = sync_engine(e);      // nothing queued may still use it
+        if (rc) return rc;
+        HIP_TRY(hipFree(p));
+    }
+    return KBBQ_OK;
+}
+
 int kbbq_measure_host_link(int32_t device, uint64_t bytes, double *h2d_gbps, double *d2h_gbps) {
     if (!bytes) return fail(KBBQ_EINVAL, "bad argument");
     int cur_dev = 0;

@@ -157,15 +157,24 @@ private:
 // reference would throw (name shorter than two characters, readutils.cc:90).
 bool parse_read_name(const std::string &fullname, std::string &rg, bool &second, std::string &first_name);
 
+// Where output bytes go: a BGZF writer -- host zlib (BgzfWriter below) or the device encoder (kbbq_cli.cc:
+// DeviceBgzfWriter over include/kbbq_bgzf.h).  The decompressed stream is the same through either.
+class ByteSink {
+public:
+    virtual ~ByteSink() {}
+    virtual bool write(const char *data, size_t n) = 0;
+    virtual bool close() = 0;   // flushes and appends the 28-byte EOF block; idempotent
+};
+
 // BGZF output.  Blocks are cut at fixed input boundaries (0xff00 bytes, htslib's BGZF_BLOCK_SIZE), so the
 // compressed stream does not depend on the number of threads: with threads > 1 the blocks are deflated by a
 // small pool (what hts_set_thread_pool buys the reference, htsiter.cc:69) and written in order.
-class BgzfWriter {
+class BgzfWriter : public ByteSink {
 public:
     explicit BgzfWriter(FILE *out, int threads = 1);
-    ~BgzfWriter();
-    bool write(const char *data, size_t n);
-    bool close();   // flushes and appends the 28-byte EOF block; idempotent
+    ~BgzfWriter() override;
+    bool write(const char *data, size_t n) override;
+    bool close() override;
 
 private:
     static constexpr size_t kBlock = 0xff00;   // BGZF_BLOCK_SIZE of htslib
@@ -188,7 +197,7 @@ private:
     bool stop_ = false;
 };
 
-inline bool write_fastq_record(BgzfWriter &w, const FastqRecord &r, const std::string &qual) {
+inline bool write_fastq_record(ByteSink &w, const FastqRecord &r, const std::string &qual) {
     std::string s;
     s.reserve(r.name.size() + r.seq.size() + r.comment.size() + qual.size() + 8);
     s += '@'; s += r.name; s += '\n'; s += r.seq; s += "\n+"; s += r.comment; s += '\n'; s += qual; s += '\n';

@@ -36,6 +36,7 @@
 #include <thread>
 #include <vector>
 
+#include "../../include/kbbq_bgzf.h"
 #include "../../include/kbbq_engine.h"
 #include "bam_io.h"
 #include "fastq_io.h"
@@ -172,6 +173,97 @@ static std::unique_ptr<Source> open_source(const std::string &path, bool is_bam,
     if (is_bam) return std::unique_ptr<Source>(new BamSource(path, use_oq, g_io_threads));
     return std::unique_ptr<Source>(new FastqSource(path, g_io_threads));
 }
+
+// BGZF output through the encoder on the GPU (include/kbbq_bgzf.h): what the reference leaves to htslib's bgzf_write /
+// sam_write1 (htsiter.cc:45,75-86).  Bytes written here are gathered in page-locked memory, a chunk of 2048 whole
+// blocks at a time, copied to the device and deflated there; up to two chunks are in flight, so the kernels of one
+// overlap the write(2) of the one before.  fastq_batch() hands over a batch whose record text the device assembles
+// itself around the recalibrated qualities it already holds.  The decompressed stream is the host writer's, byte for byte.
+class DeviceBgzfWriter : public ByteSink {
+public:
+    DeviceBgzfWriter(FILE *out, int device) : out_(out) {
+        if (kbbq_bgzf_create(device, &z_) < 0) { z_ = nullptr; failed_ = true; return; }
+        void *p = nullptr;
+        if (kbbq_host_alloc(kChunk, &p) < 0) { failed_ = true; return; }
+        buf_ = (char *)p;
+    }
+    ~DeviceBgzfWriter() override {
+        close();
+        if (buf_) kbbq_host_free(buf_);
+        if (z_) kbbq_bgzf_destroy(z_);
+    }
+    bool ok() const { return !failed_; }
+    bool write(const char *data, size_t n) override {
+        while (n && !failed_) {
+            const size_t take = std::min(n, kChunk - fill_);
+            memcpy(buf_ + fill_, data, take);
+            fill_ += take; data += take; n -= take;
+            if (fill_ == kChunk && !flush_host()) return false;
+        }
+        return !failed_;
+    }
+    // One batch of FASTQ records (RecordStore layout) whose quality lines come from device memory.
+    bool fastq_batch(const char *blob, const uint32_t *lens, uint64_t n_records, const uint8_t *d_qual, const uint64_t *d_qual_offsets,
+                     uint32_t uniform_len, void *after_stream) {
+        if (!flush_host()) return false;      // bytes written before this batch come first
+        if (!make_room()) return false;
+        if (kbbq_bgzf_submit_fastq(z_, blob, lens, n_records, d_qual, d_qual_offsets, uniform_len, after_stream) < 0) return fail_here();
+        ++in_flight_;
+        return true;
+    }
+    // every submission so far has been written out (a caller may then reuse device memory the submissions read)
+    bool drain() {
+        while (in_flight_ > 0) if (!collect_one()) return false;
+        return !failed_;
+    }
+    bool close() override {
+        if (closed_) return !failed_;
+        closed_ = true;
+        if (failed_ || !flush_host() || !drain()) return false;
+        if (fwrite(kbbq_bgzf_eof_block(), 1, 28, out_) != 28) return fail_here();
+        return fflush(out_) == 0;
+    }
+    int in_flight() const { return in_flight_; }
+    uint64_t payload_bytes = 0, compressed_bytes = 0;
+    void kernel_ms(double &format, double &deflate, double &gather) const { format = deflate = gather = 0; if (z_) kbbq_bgzf_kernel_ms(z_, &format, &deflate, &gather); }
+
+private:
+    static constexpr size_t kChunk = (size_t)2048 * KBBQ_BGZF_PAYLOAD;      // whole blocks: no short block inside the stream
+    bool fail_here() {
+        if (!failed_) std::cerr << "BGZF writer: " << kbbq_last_error() << std::endl;
+        failed_ = true;
+        return false;
+    }
+    bool collect_one() {
+        const uint8_t *blocks = nullptr;
+        uint64_t n = 0, raw = 0;
+        if (kbbq_bgzf_collect(z_, &blocks, &n, &raw) < 0) return fail_here();
+        --in_flight_;
+        payload_bytes += raw;
+        compressed_bytes += n;
+        if (fwrite(blocks, 1, n, out_) != n) { failed_ = true; return false; }
+        return true;
+    }
+    bool make_room() {
+        while (in_flight_ >= 2) if (!collect_one()) return false;
+        return !failed_;
+    }
+    bool flush_host() {
+        if (failed_) return false;
+        if (!fill_) return true;
+        if (!make_room()) return false;
+        if (kbbq_bgzf_submit(z_, buf_, fill_, 0, nullptr) < 0) return fail_here();      // (returns when the chunk has left buf_)
+        ++in_flight_;
+        fill_ = 0;
+        return true;
+    }
+    FILE *out_;
+    kbbq_bgzf *z_ = nullptr;
+    char *buf_ = nullptr;
+    size_t fill_ = 0;
+    int in_flight_ = 0;
+    bool failed_ = false, closed_ = false;
+};
 
 // What the output pass needs of one batch besides the new qualities, kept from the first scan when it fits in
 // host memory, so that the input is decoded once instead of twice: FASTQ name / comment / sequence text, or
@@ -821,8 +913,21 @@ int main(int argc, char *argv[]) {
     // pass 4, kbbq.cc:455-457: recalibrate_and_write(file, dqs, "-")
     clock.mark("model");
     std::cerr << put_now << " Recalibrating file" << std::endl;
+    uint64_t out_payload = 0, out_compressed = 0;
+    double ms_format = 0, ms_deflate = 0, ms_gather = 0;
     {
-        BgzfWriter out(stdout, out_threads);
+        // The BGZF layer: the encoder on the GPU (DeviceBgzfWriter), or -- KBBQ_HOST_DEFLATE=1, the A/B switch -- zlib on
+        // a pool of host threads as in rounds 1-2.  Same decompressed stream.
+        const bool host_deflate = getenv("KBBQ_HOST_DEFLATE") && atoi(getenv("KBBQ_HOST_DEFLATE")) != 0;
+        std::unique_ptr<DeviceBgzfWriter> dev_out;
+        std::unique_ptr<BgzfWriter> host_out;
+        if (host_deflate) {
+            host_out.reset(new BgzfWriter(stdout, out_threads));
+        } else {
+            dev_out.reset(new DeviceBgzfWriter(stdout, 0));
+            if (!dev_out->ok()) return fail_engine("cannot create the BGZF writer");
+        }
+        ByteSink &out = host_deflate ? static_cast<ByteSink &>(*host_out) : static_cast<ByteSink &>(*dev_out);
         BamWriter bam_out(out);
         if (is_bam && !bam_out.write_header(bam_header)) return 1;      // BamFile::open_out, htsiter.cc:35-42
         std::vector<uint8_t> newq;
@@ -853,7 +958,33 @@ int main(int argc, char *argv[]) {
             else std::copy(q, q + len, b.qual());
             return bam_out.write(b) ? 0 : -1;
         };
-        if (resident.on && resident.keep_recs) {
+        if (resident.on && resident.keep_recs && !is_bam && dev_out) {
+            // FASTQ, every batch in HBM, its record text in host memory: the new qualities never leave the GPU.  Pass 4
+            // writes them to a device array, the writer assembles "@name\nseq\n+comment\nqual\n" there (FastqFile::write,
+            // htsiter.cc:75-86), deflates and hands back finished blocks; two batches are in flight, so the kernels of
+            // one run while the blocks of the one before are written out.
+            void *d_q[2] = {nullptr, nullptr};
+            size_t d_q_bytes[2] = {0, 0};
+            struct FreeQ { kbbq_engine *e; void **p; ~FreeQ() { for (int i = 0; i < 2; ++i) if (p[i]) kbbq_device_free(e, p[i]); } } free_q{e, d_q};
+            for (size_t bi = 0; bi < resident.dev.size(); ++bi) {
+                const kbbq_reads &d = resident.dev[bi];
+                const RecordStore &st = resident.recs[bi];
+                const int t = (int)(bi & 1);
+                // the array this batch writes was read by the submission two batches ago: that one must be through
+                while (dev_out->in_flight() >= 2) if (!dev_out->drain()) return 1;
+                if (d_q_bytes[t] < d.n_bases + 16) {
+                    if (d_q[t] && kbbq_device_free(e, d_q[t]) < 0) return fail_engine("recalibrating");
+                    d_q[t] = nullptr;
+                    d_q_bytes[t] = d.n_bases + d.n_bases / 8 + 4096;
+                    if (kbbq_device_alloc(e, d_q_bytes[t], &d_q[t]) < 0) return fail_engine("recalibrating");
+                }
+                if (kbbq_recalibrate_batch(e, &d, (uint8_t *)d_q[t]) < 0) return fail_engine("recalibrating");
+                if (!dev_out->fastq_batch(st.blob.data(), st.lens.data(), d.n_reads, (const uint8_t *)d_q[t], d.offsets, d.read_len,
+                                          kbbq_engine_stream(e)))
+                    return 1;
+            }
+            if (!dev_out->drain()) return 1;
+        } else if (resident.on && resident.keep_recs) {
             // every batch is in HBM and its records are in host memory: nothing is decoded again
             BamRecord b;
             for (size_t bi = 0; bi < resident.dev.size(); ++bi) {
@@ -907,8 +1038,16 @@ int main(int argc, char *argv[]) {
             if (batch.fatal) return 1;
         }
         if (!out.close()) return 1;
+        if (dev_out) {
+            out_payload = dev_out->payload_bytes; out_compressed = dev_out->compressed_bytes;
+            dev_out->kernel_ms(ms_format, ms_deflate, ms_gather);
+        }
     }
     clock.mark("pass4+format+deflate+write");
+    if (clock.on && out_payload)
+        std::cerr << "[timing] BGZF writer on the GPU: " << out_payload << " bytes -> " << out_compressed << " (ratio "
+                  << (double)out_payload / (double)std::max<uint64_t>(1, out_compressed) << "); kernels: format " << ms_format
+                  << " ms, deflate " << ms_deflate << " ms, gather " << ms_gather << " ms" << std::endl;
     resident.drop();
     kbbq_engine_destroy(e);
     return 0;
