@@ -88,6 +88,39 @@ def run_step(e, xch, batches, ordinals, out_buf, hints):
     return dict(sampled_inserted=sampled, trusted_inserted=trusted, fpr=fpr, fpr_too_high=too_high)
 
 
+def exchange_one_rank(e, xch, steps, device):
+    """--force-exchange: what the exchange steps cost on one rank at full size (the transport itself needs the 8-GPU node),
+    the rate of the OR kernel at an 8-rank slab shape, and the HBM left beside filters, reads and record buffers."""
+    import ctypes
+    out = {"exchange_ms_per_step": {k: round(v / steps, 2) for k, v in xch.ms.items()},
+           "filter_bytes": [e.filter_info(0)["table_bytes"], e.filter_info(1)["table_bytes"]],
+           "slab_bytes": xch.slab_words * 8}
+    # the reduce step of an 8-rank exchange: 7 received pieces of a 512 MB slab OR-ed into the rank's own piece
+    n, piece = 8, (xch.slab_words // 8) & ~1
+    recv = torch.randint(0, 2 ** 62, (n * piece,), dtype=torch.int64, device="cuda")
+    mine = torch.zeros(piece, dtype=torch.int64, device="cuda")
+    peer = xch.peer
+    with torch.cuda.stream(peer.torch_stream()):
+        peer.or_pieces(mine, recv, piece, n, 3)
+        e.sync()
+        t0 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            peer.or_pieces(mine, recv, piece, n, 3)
+        e.sync()
+        dt = (time.perf_counter() - t0) / reps
+    out["or_pieces_8_ranks"] = {"piece_bytes": piece * 8, "ms": round(dt * 1e3, 4),
+                                "GBps_read_and_written": round(((n - 1) + 2) * piece * 8 / dt / 1e9, 1)}
+    del recv, mine
+    free_b, total_b = ctypes.c_uint64(), ctypes.c_uint64()
+    e.L.kbbq_device_memory(device, ctypes.byref(free_b), ctypes.byref(total_b))
+    out["hbm_free_GB"] = round(free_b.value / 1e9, 1)
+    out["hbm_total_GB"] = round(total_b.value / 1e9, 1)
+    out["note"] = ("one rank: all_to_all and all_gather move every slab through RCCL to the rank itself, so exchange_ms shows the "
+                   "software path at full size (slab loop, event ordering, OR launches), not xGMI transport")
+    return out
+
+
 def emulate_rank(e, batches, ordinals, mine, out_buf, hints, emu, args, G, cov):
     """Per-rank compute of rank R in an N-rank strong-scaling job, measured on ONE GPU (diagnostic, not the metric).
 
@@ -253,10 +286,39 @@ def pcie_inclusive(genome_len, coverage, local_rank):
     out_pin = _lib.PinnedArray(PB * READ_LEN + 16, np.uint8)
     out = out_pin.array
     _lib.check(e.L.kbbq_engine_reset(e.h))
-    t_sub = passes([lambda: ([e.subsample_kmers(b, o) for b, o in zip(host, ordinals)], e.sample_finish(), e.compute_thresholds()),
-                    lambda: ([e.find_trusted_kmers(b) for b in host], e.trusted_finish()),
-                    lambda: ([e.get_covariatedata(b) for b in host], e.get_dqs()),
-                    lambda: [_lib.check(e.L.kbbq_recalibrate_batch(e.h, ctypes.byref(b.c), out.ctypes.data)) for b in host]])
+    # The asynchronous form of the boundary (kbbq_*_batch_submit + kbbq_batch_wait): a caller that cycles through DEPTH
+    # page-locked batches waits for batch i - DEPTH (its memory free again, its qualities back) before it hands over
+    # batch i, so the copies of consecutive batches are queued back to back and pass 4's two directions overlap.
+    DEPTH = 3
+    outs = [_lib.PinnedArray(PB * READ_LEN + 16, np.uint8) for _ in range(DEPTH)]
+
+    def in_flight(submit):
+        tickets = []
+        for i, b in enumerate(host):
+            if len(tickets) >= DEPTH:
+                _lib.check(e.L.kbbq_batch_wait(e.h, tickets.pop(0)))
+            t = ctypes.c_uint64()
+            _lib.check(submit(i, b, ctypes.byref(t)))
+            tickets.append(t.value)
+        for t in tickets:
+            _lib.check(e.L.kbbq_batch_wait(e.h, t))
+
+    t_sub = passes([lambda: (in_flight(lambda i, b, t: e.L.kbbq_sample_batch_submit(e.h, ctypes.byref(b.c), ordinals[i], t)), e.sample_finish(), e.compute_thresholds()),
+                    lambda: (in_flight(lambda i, b, t: e.L.kbbq_trusted_batch_submit(e.h, ctypes.byref(b.c), t)), e.trusted_finish()),
+                    lambda: (in_flight(lambda i, b, t: e.L.kbbq_errors_batch_submit(e.h, ctypes.byref(b.c), t)), e.get_dqs()),
+                    lambda: in_flight(lambda i, b, t: e.L.kbbq_recalibrate_batch_submit(e.h, ctypes.byref(b.c), outs[i % DEPTH].array.ctypes.data, t))])
+    e.sync()
+    sub_digest = int(outs[(len(host) - 1) % DEPTH].array[:host[-1].c.n_bases].astype(np.int64).sum())
+    # the same four passes through the plain (synchronous) calls, for the record and as a check of the asynchronous ones
+    _lib.check(e.L.kbbq_engine_reset(e.h))
+    t_sync = passes([lambda: ([e.subsample_kmers(b, o) for b, o in zip(host, ordinals)], e.sample_finish(), e.compute_thresholds()),
+                     lambda: ([e.find_trusted_kmers(b) for b in host], e.trusted_finish()),
+                     lambda: ([e.get_covariatedata(b) for b in host], e.get_dqs()),
+                     lambda: [_lib.check(e.L.kbbq_recalibrate_batch(e.h, ctypes.byref(b.c), out.ctypes.data)) for b in host]])
+    if int(out[:host[-1].c.n_bases].astype(np.int64).sum()) != sub_digest:
+        raise SystemExit("bench.py: asynchronous and synchronous host-batch passes disagree")
+    for o in outs:
+        o.free()
     _lib.check(e.L.kbbq_engine_reset(e.h))
     resident = []
 
@@ -303,7 +365,8 @@ def pcie_inclusive(genome_len, coverage, local_rank):
                 sample="%d reads x %d bp = %.3g bases as page-locked host batches of %d reads (the command line's batch size)" % (n_reads, READ_LEN, nb, PB),
                 resident_pass_seconds=[round(x, 3) for x in t_res],
                 bound="per mode: sum over the four passes of max(bytes up / measured H2D rate + bytes down / measured D2H rate, the pass's resident time); duplex bound: the two directions of a pass overlapped",
-                resubmit=mode(t_sub, sub_bytes, "4.5 B/base H2D (pass 1 sends no qualities), 1 B/base D2H"),
+                resubmit=mode(t_sub, sub_bytes, "4.5 B/base H2D (pass 1 sends no qualities), 1 B/base D2H; asynchronous submission, three batches in flight"),
+                resubmit_synchronous_calls=mode(t_sync, sub_bytes, "the same through the plain calls (each returns when its batch's copy has landed)"),
                 upload_once=mode(t_once, once_bytes, "1.4 B/base H2D, 1 B/base D2H"))
 
 
@@ -406,6 +469,10 @@ def main():
     ap.add_argument("--emulate-shard", default=None, metavar="R/N",
                     help="diagnostic: one process runs rank R's shard of an N-rank job (fresh filters, no collectives) -- "
                          "the per-rank compute of the strong-scaling curve, measured on one GPU")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="diagnostic (N = 1): a one-rank RCCL group and every exchange step at full size -- all_to_all, OR "
+                         "kernel and all_gather over the whole 6.3 + 10.4 GB of filters in 512 MB slabs, histogram sum, delta-Q "
+                         "broadcast -- beside the record buffers of the bucketed inserts; adds an `exchange_one_rank` object")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -430,9 +497,13 @@ def main():
     if os.environ.get("KBBQ_BENCH_ONE_GPU"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_exchange:
         import torch.distributed as dist
-        if backend == "nccl":
+        if world == 1:      # --force-exchange: a group of one
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29561")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        elif backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
@@ -470,7 +541,7 @@ def main():
             mine.append(bool(emu) and emu_range[0] <= s < emu_range[1])
     out_buf = torch.empty(min(BATCH_READS, n_local) * READ_LEN + 16, dtype=torch.uint8, device="cuda")
     xch = Exchange(EnginePeer(e), device=torch.device("cuda", local_rank) if backend == "nccl" else None,
-                   stage_host=backend != "nccl")
+                   stage_host=backend != "nccl", force=args.force_exchange)
 
     def barrier():
         e.sync()
@@ -596,6 +667,8 @@ def main():
             "bucketed_inserts": {"records_per_flush": stats["bucket_capacity"], "flushes_per_step": list(stats["bucket_flushes"]),
                                  "direct_fallback_records": stats["bucket_direct"]},
         }
+        if args.force_exchange:
+            line["exchange_one_rank"] = exchange_one_rank(e, xch, args.steps, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(e, args.cpu_genome_len, cov)
         if world == 1 and not args.no_pcie:
@@ -606,7 +679,7 @@ def main():
     if shard is not None:
         shard.free()
     e.close()
-    if world > 1:
+    if world > 1 or args.force_exchange:
         dist.destroy_process_group()
 
 

@@ -292,6 +292,22 @@ int kbbq_recalibrate_batch(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qua
 /* Same, but qual_out is always HOST memory (a device-resident batch whose new qualities go to a writer). */
 int kbbq_recalibrate_batch_host(kbbq_engine *e, const kbbq_reads *reads, uint8_t *host_qual_out);
 
+/* ---- asynchronous submission of host batches --------------------------------
+ * The calls above return when their host batch has left the caller's memory, so batch i+1 is copied only after batch i
+ * has landed: a bubble per batch on the link.  The *_submit forms only QUEUE the batch -- copy into a staging slot,
+ * kernels, and for pass 4 the copy of the new qualities back to qual_out -- and return a ticket; kbbq_batch_wait(ticket)
+ * returns when the batch's arrays are the caller's again and (pass 4) qual_out is complete.  A caller that cycles through
+ * two or three page-locked batches keeps the host link busy back to back in both directions (bench.py: pcie_inclusive).
+ * Up to three host batches are in flight (the staging ring); a fourth submit waits inside the call for the oldest batch's
+ * kernels.  Device batches are queued exactly as by the plain calls and get ticket 0.  The optional outputs of passes 2
+ * and 3 (flag arrays) are not available in this form. */
+typedef uint64_t kbbq_ticket;
+int kbbq_sample_batch_submit(kbbq_engine *e, const kbbq_reads *reads, uint64_t first_kmer_ordinal, kbbq_ticket *ticket);
+int kbbq_trusted_batch_submit(kbbq_engine *e, const kbbq_reads *reads, kbbq_ticket *ticket);
+int kbbq_errors_batch_submit(kbbq_engine *e, const kbbq_reads *reads, kbbq_ticket *ticket);
+int kbbq_recalibrate_batch_submit(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qual_out, kbbq_ticket *ticket);
+int kbbq_batch_wait(kbbq_engine *e, kbbq_ticket ticket);
+
 /* ---- synthetic input and measurement ------------------------------------- */
 
 typedef struct kbbq_synth_params {

@@ -110,6 +110,11 @@ SYMBOLS = {
     "kbbq_set_dq": (ctypes.c_int, [c_vp, ctypes.POINTER(Dq)]),
     "kbbq_recalibrate_batch": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads), c_vp]),
     "kbbq_recalibrate_batch_host": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads), c_vp]),
+    "kbbq_sample_batch_submit": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads), c_u64, c_u64p]),
+    "kbbq_trusted_batch_submit": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads), c_u64p]),
+    "kbbq_errors_batch_submit": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads), c_u64p]),
+    "kbbq_recalibrate_batch_submit": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads), c_vp, c_u64p]),
+    "kbbq_batch_wait": (ctypes.c_int, [c_vp, c_u64]),
     "kbbq_reads_alloc_hints": (ctypes.c_int, [ctypes.POINTER(Reads)]),
     "kbbq_reads_free_hints": (ctypes.c_int, [ctypes.POINTER(Reads)]),
     "kbbq_device_memory": (ctypes.c_int, [ctypes.c_int32, c_u64p, c_u64p]),

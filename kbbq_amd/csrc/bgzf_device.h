@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
         uint32_t body_bytes;
         if (dyn_bytes < stored_bytes && dyn_bytes + BGZF_HEAD + BGZF_TAIL <= (uint32_t)BGZF_MAX_BLOCK) {
             // header bits, then the tokens 64 at a time: exclusive prefix sum of their lengths, bits OR-ed into the zeroed slot
-            for (uint32_t i = lane; i * 8 < head_bits; i += 64) {
+            for (uint32_t i = lane; i * 64 < head_bits; i += 64) {      // 8-byte word i holds the header's bits [64 i, 64 i + 64)
                 uint64_t v = 0;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v |= (uint64_t)S.u.hs.head[i * 8 + k] << (8 * k);

@@ -145,11 +145,18 @@ struct kbbq_engine {
         char *dev = nullptr;
         size_t bytes = 0;
         hipEvent_t h2d = nullptr, done[2] = {nullptr, nullptr};     // done[0]: main stream, done[1]: side stream
+        hipEvent_t d2h = nullptr;        // a result of this batch has landed in the caller's host memory (pass 4, asynchronous form)
         bool busy[2] = {false, false};
+        bool d2h_pending = false;
+        uint32_t gen = 0;                // how often the slot has been handed out: part of a batch's ticket
     } slot[3];
     int slot_turn = 0, cur_slot = -1;
     bool cur_slot_side = false;      // the batch in cur_slot is also read on the side stream (pass 3)
     bool cur_h2d_recorded = false;   // the slot's h2d event stands for THIS batch's copies (HostBatchDone)
+    // the asynchronous form of the batch entry points (kbbq_*_batch_submit + kbbq_batch_wait): the entry point does not
+    // wait for its batch's copy; the ticket names the staging slot and its generation
+    bool async_call = false;
+    uint64_t last_ticket = 0;
     hipStream_t copy = nullptr;
     uint64_t stats[4] = {0, 0, 0, 0};
     // profiling
@@ -303,16 +310,24 @@ int sync_engine(kbbq_engine *e) {
 // guard waits for the batch's copy into its staging slot -- not for the kernels -- and notes when the slot is free.
 struct HostBatchDone {
     kbbq_engine *e;
-    HostBatchDone(kbbq_engine *e_, const kbbq_reads *) : e(e_) { e->cur_slot = -1; e->cur_slot_side = false; e->cur_h2d_recorded = false; }
+    HostBatchDone(kbbq_engine *e_, const kbbq_reads *) : e(e_) { e->cur_slot = -1; e->cur_slot_side = false; e->cur_h2d_recorded = false; e->last_ticket = 0; }
     ~HostBatchDone() {
         if (e->cur_slot < 0) return;
         kbbq_engine::StageSlot &s = e->slot[e->cur_slot];
         if (hipEventRecord(s.done[0], e->stream) == hipSuccess) s.busy[0] = true;
         if (e->cur_slot_side && hipEventRecord(s.done[1], e->stream2) == hipSuccess) s.busy[1] = true;
-        // the event of THIS batch's copies -- or, when an error came before it could be recorded (the event then still
-        // carries the batch before), everything queued on the copy stream
-        if (e->cur_h2d_recorded) hipEventSynchronize(s.h2d);
-        else hipStreamSynchronize(e->copy);
+        if (e->async_call && e->cur_h2d_recorded) {
+            // asynchronous form: the caller waits with kbbq_batch_wait when it wants the batch's memory back; the next
+            // batch's copy is queued straight behind this one's
+            e->last_ticket = ((uint64_t)s.gen << 8) | (uint64_t)(e->cur_slot + 1);
+        } else if (e->cur_h2d_recorded) {
+            // the event of THIS batch's copies
+            hipEventSynchronize(s.h2d);
+        } else {
+            // an error came before the event could be recorded (it still carries the batch before): everything
+            // queued on the copy stream
+            hipStreamSynchronize(e->copy);
+        }
         e->cur_slot = -1;
     }
 };
@@ -343,6 +358,8 @@ int acquire_slot(kbbq_engine *e, size_t need, kbbq_engine::StageSlot **out) {
     kbbq_engine::StageSlot &s = e->slot[e->slot_turn];
     for (int t = 0; t < 2; ++t)
         if (s.busy[t]) { HIP_TRY(hipEventSynchronize(s.done[t])); s.busy[t] = false; }
+    if (s.d2h_pending) { HIP_TRY(hipEventSynchronize(s.d2h)); s.d2h_pending = false; }
+    s.gen += 1;
     if (s.bytes < need) {
         if (s.dev) HIP_TRY(hipFree(s.dev));
         s.dev = nullptr; s.bytes = 0;
@@ -363,11 +380,19 @@ struct DeferredCopy {
     char *d_bases = nullptr, *d_nmask = nullptr, *d_qual = nullptr;
     kbbq_engine::StageSlot *slot = nullptr;
 };
+// a host batch whose result goes back to host memory without the call waiting for it: the device copy of the result
+// lives in the batch's staging slot (two such batches may be in flight)
+struct SlotOutput {
+    size_t bytes = 0;            // in: bytes wanted
+    char *dev = nullptr;         // out
+    kbbq_engine::StageSlot *slot = nullptr;
+};
 
 // device view of a batch; host batches are copied (freed at the next sync)
 // need_qual = false (pass 1: k-mers only): a host batch's qualities are not copied
 // defer (host batches): the three big arrays are NOT copied and the engine's stream does not wait: the caller does both
-int device_view(kbbq_engine *e, const kbbq_reads *in, ReadsDev *out, int *max_len, bool need_qual = true, DeferredCopy *defer = nullptr) {
+int device_view(kbbq_engine *e, const kbbq_reads *in, ReadsDev *out, int *max_len, bool need_qual = true, DeferredCopy *defer = nullptr,
+                SlotOutput *slot_out = nullptr) {
     if (!in) return fail(KBBQ_EINVAL, "null batch");
     if (in->n_reads == 0) return fail(KBBQ_EINVAL, "empty batch");
     if (!in->offsets && in->read_len == 0) return fail(KBBQ_EINVAL, "batch has neither offsets nor read_len");
@@ -407,11 +432,13 @@ int device_view(kbbq_engine *e, const kbbq_reads *in, ReadsDev *out, int *max_le
         const size_t nb_o = in->offsets ? (in->n_reads + 1) * 8 : 0, nb_f = in->flags ? in->n_reads : 0, nb_g = in->rg ? in->n_reads * 2 : 0;
         const size_t nb_c = in->offcase ? nb_m : 0;
         const size_t o_b = 0, o_m = align256(o_b + nb_b + 8), o_q = align256(o_m + nb_m + 8), o_o = align256(o_q + nb_q + 16),
-                     o_f = align256(o_o + nb_o), o_g = align256(o_f + nb_f), o_c = align256(o_g + nb_g), total = align256(o_c + nb_c + 8);
+                     o_f = align256(o_o + nb_o), o_g = align256(o_f + nb_f), o_c = align256(o_g + nb_g), o_r = align256(o_c + nb_c + 8),
+                     total = align256(o_r + (slot_out ? slot_out->bytes : 0));
         kbbq_engine::StageSlot *sl;
         int rc = acquire_slot(e, total, &sl);
         if (rc) return rc;
         char *d = sl->dev;
+        if (slot_out) { slot_out->dev = d + o_r; slot_out->slot = sl; }
         HIP_TRY(hipMemsetAsync(d + o_b + nb_b, 0, 8, e->copy));
         HIP_TRY(hipMemsetAsync(d + o_m + nb_m, 0, 8, e->copy));
         HIP_TRY(hipMemsetAsync(d + o_q + nb_q, 0, 16, e->copy));
@@ -760,6 +787,7 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
     if (he == hipSuccess) he = hipHostMalloc((void **)&e->bk.h_inserted, 64, hipHostMallocDefault);
     for (int i = 0; i < 3 && he == hipSuccess; ++i) {
         he = hipEventCreateWithFlags(&e->slot[i].h2d, hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&e->slot[i].d2h, hipEventDisableTiming);
         for (int t = 0; t < 2 && he == hipSuccess; ++t) he = hipEventCreateWithFlags(&e->slot[i].done[t], hipEventDisableTiming);
     }
     e->cur = e->stream;
@@ -822,6 +850,7 @@ void kbbq_engine_destroy(kbbq_engine *e) {
     for (int i = 0; i < 3; ++i) {
         hipFree(e->slot[i].dev);
         if (e->slot[i].h2d) hipEventDestroy(e->slot[i].h2d);
+        if (e->slot[i].d2h) hipEventDestroy(e->slot[i].d2h);
         for (int t = 0; t < 2; ++t) if (e->slot[i].done[t]) hipEventDestroy(e->slot[i].done[t]);
     }
     if (e->copy) hipStreamDestroy(e->copy);
@@ -1977,10 +2006,17 @@ static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qu
     const uint64_t piece = piece_env ? ((piece_env + 63) >> 6) << 6 : std::max<uint64_t>(1ull << 23, ((reads->n_bases / 4 + 65535) >> 16) << 16);
     const bool pipelined = !reads->on_device && out_on_host && !no_pipe && reads->n_bases >= 2 * piece;
     DeferredCopy dc;
-    int rc = device_view(e, reads, &R, &max_len, true, pipelined ? &dc : nullptr);
+    // the asynchronous form (kbbq_recalibrate_batch_submit) of a host batch keeps its result in the batch's staging slot
+    // until the copy back has landed: two such batches may be in flight
+    const bool deferred_out = e->async_call && !reads->on_device && out_on_host;
+    SlotOutput so;
+    so.bytes = reads->n_bases + 16;
+    int rc = device_view(e, reads, &R, &max_len, true, pipelined ? &dc : nullptr, deferred_out ? &so : nullptr);
     if (rc) return rc;
     uint8_t *d_out = qual_out;
-    if (out_on_host) {
+    if (deferred_out) {
+        d_out = (uint8_t *)so.dev;
+    } else if (out_on_host) {
         if ((rc = ensure_scratch(e, 2, R.n_bases + 16))) return rc;
         d_out = (uint8_t *)e->scratch[2];
     }
@@ -2016,10 +2052,11 @@ static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qu
         // stream, the kernel on the engine's, device -> host on the side stream (the link carries both directions at
         // once); the kernel reads the base before its first one, which an earlier piece brought
         const uint64_t nb = R.n_bases;
-        struct SideDone {      // the caller's output buffer is its own again on every return path
+        struct SideDone {      // the caller's output buffer is its own again on every return path (synchronous form)
             hipStream_t st;
-            ~SideDone() { (void)hipStreamSynchronize(st); }
-        } side_done{e->stream2};
+            bool wait;
+            ~SideDone() { if (wait) (void)hipStreamSynchronize(st); }
+        } side_done{e->stream2, !deferred_out};
         for (uint64_t b0 = 0; b0 < nb; b0 += piece) {
             const uint64_t b1 = std::min(nb, b0 + piece);
             const uint64_t w0 = b0 / 32, w1 = b1 == nb ? nb / 32 + 1 : b1 / 32, m0 = b0 / 64, m1 = b1 == nb ? nb / 64 + 1 : b1 / 64;
@@ -2033,14 +2070,83 @@ static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qu
             HIP_TRY(hipStreamWaitEvent(e->stream2, e->ev_main, 0));
             HIP_TRY(hipMemcpyAsync(qual_out + b0, d_out + b0, b1 - b0, hipMemcpyDeviceToHost, e->stream2));
         }
+        if (deferred_out) {
+            // kbbq_batch_wait waits for this; the slot is not handed out again before it either (acquire_slot)
+            HIP_TRY(hipEventRecord(so.slot->d2h, e->stream2));
+            so.slot->d2h_pending = true;
+            e->cur_slot_side = true;
+            return KBBQ_OK;
+        }
         HIP_TRY(hipStreamSynchronize(e->stream2));      // (reports a failed copy; the guard's wait is then a no-op)
         return KBBQ_OK;
     }
     if ((rc = launch(0, R.n_bases))) return rc;
     if (out_on_host) {
         HIP_TRY(hipMemcpyAsync(qual_out, d_out, R.n_bases, hipMemcpyDeviceToHost, e->stream));
+        if (deferred_out) {
+            HIP_TRY(hipEventRecord(so.slot->d2h, e->stream));
+            so.slot->d2h_pending = true;
+            return KBBQ_OK;
+        }
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
+    return KBBQ_OK;
+}
+
+// ---- the asynchronous form of the batch entry points ------------------------------------------------------------------
+// The synchronous calls return when their host batch has left the caller's memory, so the next batch's copy is queued
+// only after the previous one has landed and every pass has a bubble per batch (0.64-0.77 of the link's bound in round
+// 2).  Here the call only queues -- copy, kernels, copy back -- and the caller, with two or three page-locked batches in
+// flight, asks for a batch's memory back when it needs it.
+namespace {
+struct AsyncCall {
+    kbbq_engine *e;
+    explicit AsyncCall(kbbq_engine *e_) : e(e_) { e->async_call = true; }
+    ~AsyncCall() { e->async_call = false; }
+};
+}  // namespace
+
+int kbbq_sample_batch_submit(kbbq_engine *e, const kbbq_reads *reads, uint64_t first_kmer_ordinal, kbbq_ticket *ticket) {
+    if (!e || !ticket) return fail(KBBQ_EINVAL, "null argument");
+    AsyncCall a(e);
+    const int rc = kbbq_sample_batch(e, reads, first_kmer_ordinal);
+    *ticket = e->last_ticket;
+    return rc;
+}
+
+int kbbq_trusted_batch_submit(kbbq_engine *e, const kbbq_reads *reads, kbbq_ticket *ticket) {
+    if (!e || !ticket) return fail(KBBQ_EINVAL, "null argument");
+    AsyncCall a(e);
+    const int rc = kbbq_trusted_batch(e, reads, nullptr);
+    *ticket = e->last_ticket;
+    return rc;
+}
+
+int kbbq_errors_batch_submit(kbbq_engine *e, const kbbq_reads *reads, kbbq_ticket *ticket) {
+    if (!e || !ticket) return fail(KBBQ_EINVAL, "null argument");
+    AsyncCall a(e);
+    const int rc = kbbq_errors_batch(e, reads, nullptr);
+    *ticket = e->last_ticket;
+    return rc;
+}
+
+int kbbq_recalibrate_batch_submit(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qual_out, kbbq_ticket *ticket) {
+    if (!e || !ticket) return fail(KBBQ_EINVAL, "null argument");
+    AsyncCall a(e);
+    const int rc = kbbq_recalibrate_batch(e, reads, qual_out);
+    *ticket = e->last_ticket;
+    return rc;
+}
+
+int kbbq_batch_wait(kbbq_engine *e, kbbq_ticket ticket) {
+    ENGINE_DEVICE(e);
+    if (!ticket) return KBBQ_OK;      // a device batch, or a call that had waited itself
+    const int idx = (int)(ticket & 0xFF) - 1;
+    if (idx < 0 || idx > 2) return fail(KBBQ_EINVAL, "not a ticket of this engine");
+    kbbq_engine::StageSlot &s = e->slot[idx];
+    if (s.gen != (uint32_t)(ticket >> 8)) return KBBQ_OK;      // the slot has been handed out again since: that waited for all of it
+    HIP_TRY(hipEventSynchronize(s.h2d));
+    if (s.d2h_pending) { HIP_TRY(hipEventSynchronize(s.d2h)); s.d2h_pending = false; }
     return KBBQ_OK;
 }
 

@@ -50,6 +50,9 @@ PAYLOADS = {
     "fastq": fastq_text(1500),
     "runs": b"".join(bytes([c]) * n for c, n in zip(range(256), np.random.RandomState(2).randint(1, 900, 256))),
     "two_symbols": b"ab" * 40000,
+    # every byte value, short matches, many symbols: a long code-length header (BAM-like binary content)
+    "binary_records": b"".join(bytes(np.random.RandomState(100 + i).randint(0, 256, 40).astype(np.uint8)) + bytes([i & 255] * (i % 9)) + b"\x00\x01\x00\x00RG:Z:grp%d\x00" % (i % 4)
+                               for i in range(4000)),
     "skewed": bytes(np.random.RandomState(9).choice(np.arange(40, dtype=np.uint8), 150000, p=np.array([2.0 ** -i for i in range(1, 40)] + [2.0 ** -39]))),
 }
 

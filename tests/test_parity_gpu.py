@@ -208,6 +208,90 @@ def test_host_batches_in_reused_page_locked_memory():
     assert ref["sampled_inserted"] >= sub["sampled_inserted"]
 
 
+def test_asynchronous_submission_of_host_batches():
+    """kbbq_*_batch_submit + kbbq_batch_wait: the call only queues the batch; the caller cycles through three sets of
+    page-locked buffers and waits for a batch's ticket before it refills that set (and, in pass 4, before it reads the new
+    qualities).  Filters, histograms and qualities equal the synchronous run's -- twelve batches, so every staging slot is
+    handed out several times, with ragged and uniform layouts."""
+    import ctypes
+    import torch
+    d = common.make_dataset(seed=4141, genome_len=40000, coverage=24, extra_errors=60)
+    alpha_ld, cov, approx = plan_parameters(d["genome_len"], d["coverage"], None)
+    full = ReadBatch(d["seq"], d["qual"], d["off"], d["rg"], d["second"], uniform=True)
+    nparts = 12
+    n = full.n_reads // nparts // 32 * 32
+    used = dict(d, seq=d["seq"][:nparts * n * 150], qual=d["qual"][:nparts * n * 150], off=d["off"][:nparts * n + 1],
+                rg=d["rg"][:nparts * n], second=d["second"][:nparts * n])
+    want = common.run_engine(used, uniform=True)
+    parts = [full.slice(i * n, (i + 1) * n) for i in range(nparts)]
+    arrays = [(p.bases.copy(), p.nmask.copy(), p.qual.copy()) for p in parts]
+    keep = []
+
+    def pinned(nbytes, dtype):
+        t = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        keep.append(t)
+        return t.numpy().view(dtype)
+
+    DEPTH = 3
+    sets = []
+    for j in range(DEPTH):
+        shell = full.slice(0, n)
+        pb, pm, pq = pinned(parts[0].bases.nbytes, np.uint64), pinned(parts[0].nmask.nbytes, np.uint64), pinned(parts[0].qual.nbytes, np.uint8)
+        shell.c.bases, shell.c.nmask, shell.c.qual = pb.ctypes.data, pm.ctypes.data, pq.ctypes.data
+        sets.append((shell, pb, pm, pq, pinned(n * 150 + 16, np.uint8)))
+    e = Engine(32, alpha_ld, 777, approx, n_rg=1, max_read_len=150)
+    L = e.L
+    recal = np.zeros(nparts * n * 150, dtype=np.uint8)
+
+    def cycle(submit, collect=None):
+        tickets = [None] * DEPTH
+        for i in range(nparts + DEPTH):
+            j = i % DEPTH
+            if tickets[j] is not None:                      # the set's previous batch: wait before touching its memory
+                _lib.check(L.kbbq_batch_wait(e.h, tickets[j][1]))
+                if collect:
+                    collect(tickets[j][0], sets[j])
+                tickets[j] = None
+            if i < nparts:
+                shell, pb, pm, pq, out = sets[j]
+                pb[:], pm[:], pq[:] = arrays[i]
+                t = ctypes.c_uint64()
+                _lib.check(submit(i, sets[j], ctypes.byref(t)))
+                assert t.value != 0
+                tickets[j] = (i, t.value)
+
+    cycle(lambda i, st, t: L.kbbq_sample_batch_submit(e.h, ctypes.byref(st[0].c), i * n * (150 - 32 + 1), t))
+    assert e.sample_finish() == want["sampled_inserted"]
+    assert np.array_equal(e.filter_table(0), want["sampled_table"])
+    e.compute_thresholds()
+    cycle(lambda i, st, t: L.kbbq_trusted_batch_submit(e.h, ctypes.byref(st[0].c), t))
+    assert e.trusted_finish() == want["trusted_inserted"]
+    assert np.array_equal(e.filter_table(1), want["trusted_table"])
+    cycle(lambda i, st, t: L.kbbq_errors_batch_submit(e.h, ctypes.byref(st[0].c), t))
+    c = e.covariates()
+    assert np.array_equal(c["cycle"], want["cov"]["cycle"]) and np.array_equal(c["dinuc"], want["cov"]["dinuc"])
+    e.get_dqs()
+
+    def take(i, st):
+        recal[i * n * 150:(i + 1) * n * 150] = st[4][:n * 150]
+
+    for piece in (0, 4160):      # pass 4 in one piece per batch and through the piece pipeline
+        if piece:
+            _lib.check(L.kbbq_engine_tune(e.h, b"pass4_piece", piece))
+        recal[:] = 0
+        cycle(lambda i, st, t: L.kbbq_recalibrate_batch_submit(e.h, ctypes.byref(st[0].c), st[4].ctypes.data, t), take)
+        assert np.array_equal(recal, want["recal"])
+    # a device batch gets ticket 0; waiting for it, or for a ticket whose slot has moved on, returns at once
+    db = e.upload(parts[0])
+    t = ctypes.c_uint64(77)
+    _lib.check(L.kbbq_errors_batch_submit(e.h, ctypes.byref(db.c), ctypes.byref(t)))
+    assert t.value == 0
+    _lib.check(L.kbbq_batch_wait(e.h, 0))
+    e.sync()
+    db.free()
+    e.close()
+
+
 def test_hint_arrays_do_not_change_results():
     """kbbq_reads.hint_sampled / hint_trusted only skip lookups whose answer is known."""
     import torch
