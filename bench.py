@@ -56,11 +56,26 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def kernel_source_sha16():
+    """Identity of the kernels a PMC summary belongs to: the sources of the pass kernels (a counter summary taken on other
+    sources must not be quoted next to fresh timings)."""
+    import hashlib
+    h = hashlib.sha256()
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kbbq_amd", "csrc")
+    for f in ("kernels.h", "device_common.h", "bucket.h", "correct_wave.h", "long_reads.h"):
+        try:
+            h.update(open(os.path.join(here, f), "rb").read())
+        except OSError:
+            h.update(b"missing:" + f.encode())
+    return h.hexdigest()[:16]
+
+
 # kernels that share the chip with a kernel of the neighbouring batch on the other stream (pass 1: draw beside insert;
 # pass 3: walk + tally beside scan): their event durations are not exclusive costs
 PASS3_KERNELS = ("k_draw_mask", "k_insert_sampled", "k_emit_sampled", "k_scan_trusted", "k_compact", "k_correct_wave", "k_correct", "k_tally")
-# with KBBQ_PASS2_SIDE=1 the insert side of pass 2 runs on the side stream beside k_infer: then pass 2's durations are shared too
-if os.environ.get("KBBQ_PASS2_SIDE", "0") not in ("", "0"):
+# the insert side of pass 2 runs on the side stream beside k_infer (default since round 3; KBBQ_PASS2_SIDE=0 puts it behind):
+# pass 2's durations are shared too
+if os.environ.get("KBBQ_PASS2_SIDE", "1") not in ("", "0"):
     PASS3_KERNELS += ("k_infer", "k_emit_trusted", "k_split_trusted", "k_apply_trusted")
 
 
@@ -469,6 +484,8 @@ def main():
     ap.add_argument("--emulate-shard", default=None, metavar="R/N",
                     help="diagnostic: one process runs rank R's shard of an N-rank job (fresh filters, no collectives) -- "
                          "the per-rank compute of the strong-scaling curve, measured on one GPU")
+    ap.add_argument("--no-exclusive-step", action="store_true",
+                    help="skip the extra untimed in-order step that gives the exclusive kernel durations of the roofline object")
     ap.add_argument("--force-exchange", action="store_true",
                     help="diagnostic (N = 1): a one-rank RCCL group and every exchange step at full size -- all_to_all, OR "
                          "kernel and all_gather over the whole 6.3 + 10.4 GB of filters in 512 MB slabs, histogram sum, delta-Q "
@@ -574,6 +591,18 @@ def main():
 
     prof = e.profile()
     stats = e.stats()
+    # Untimed, same process, same resident reads: one more step with every kernel in order on one stream.  In the timed
+    # region passes 1-3 keep two streams busy, so a kernel's event duration there includes time it shared the chip; the
+    # roofline line of the dominant kernel is quoted on its EXCLUSIVE duration from this step (both are printed).
+    prof_excl = None
+    if not os.environ.get("KBBQ_NO_OVERLAP") and not args.no_exclusive_step:
+        from kbbq_amd import _lib as _l
+        _l.check(e.L.kbbq_engine_tune(e.h, b"no_overlap", 1))
+        e.profile_reset()
+        run_step(e, xch, batches, ordinals, out_buf, hints)
+        barrier()
+        prof_excl = e.profile()
+        _l.check(e.L.kbbq_engine_tune(e.h, b"no_overlap", 0))
     # untimed: digest of the recalibrated qualities (rank-count invariant)
     digest = 0
     for bt in batches:
@@ -609,22 +638,39 @@ def main():
             if name in PASS3_KERNELS and not os.environ.get("KBBQ_NO_OVERLAP"):
                 ent["overlapped"] = True
             kernels[name] = ent
-        dom = max((k for k in kernels if "achieved_GBps" in kernels[k] and not kernels[k].get("overlapped")),
-                  key=lambda k: kernels[k]["total_ms"])
+        # exclusive durations (the in-order step above) beside the timed region's
+        if prof_excl:
+            for name, (launches, ms) in prof_excl.items():
+                if launches and name in kernels:
+                    kernels[name]["exclusive_avg_ms"] = round(ms / launches, 4)
+                    if "alg_bytes_per_launch" in kernels[name]:
+                        kernels[name]["exclusive_GBps"] = round(kernels[name]["alg_bytes_per_launch"] / (ms / launches) / 1e6, 1)
+            dom = max((k for k in kernels if "exclusive_GBps" in kernels[k]), key=lambda k: kernels[k]["exclusive_avg_ms"] * kernels[k]["launches"])
+            dom_ms, dom_GBps = kernels[dom]["exclusive_avg_ms"], kernels[dom]["exclusive_GBps"]
+            dom_how = "exclusive: an untimed in-order step of this same run (kbbq_engine_tune no_overlap), HIP events on the engine's stream"
+        else:
+            dom = max((k for k in kernels if "achieved_GBps" in kernels[k] and not kernels[k].get("overlapped")),
+                      key=lambda k: kernels[k]["total_ms"])
+            dom_ms, dom_GBps = kernels[dom]["avg_ms"], kernels[dom]["achieved_GBps"]
+            dom_how = "the timed region (every kernel in order on one stream: KBBQ_NO_OVERLAP)"
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
         # is the committed rocprofv3 --pmc summary of this same command at the same launch size
         traffic, traffic_note = None, "no PMC summary for this launch size"
         try:
-            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_latest.json")))
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_latest.json")))
             k = pmc["kernels"].get(dom)
             launches_per_step = kernels[dom]["launches"] // args.steps
             full_launches = (n_local // BATCH_READS) >= 1 and READ_LEN == 150 and BATCH_READS == 1 << 22
-            if k and full_launches:
+            if pmc.get("kernel_source_sha16") != kernel_source_sha16():
+                traffic_note = ("the committed PMC summary (%s) was taken on other kernel sources than the ones this run was built from: "
+                                "not quoted" % pmc.get("summary_file"))
+            elif k and full_launches:
                 # gfx950: FETCH_SIZE tallies the L2's 128-byte memory requests at 64 bytes each (MI355X_MICROARCH.md, HBM
                 # section; tools/probe_req: every random lookup is one TCC_EA0_RDREQ_128B) -- doubled here
                 traffic = round((2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0)
-                traffic_note = ("2 x FETCH_SIZE + WRITE_SIZE per launch of %d reads, %s (%d launches per step here, the last one partial); "
-                                "FETCH_SIZE counts the 128-byte requests of gfx950's L2 as 64 bytes" % (BATCH_READS, pmc["summary_file"], launches_per_step))
+                traffic_note = ("2 x FETCH_SIZE + WRITE_SIZE per launch of %d reads, %s (rocprofv3 --pmc of this command on these kernel sources; "
+                                "%d launches per step here, the last one partial); FETCH_SIZE counts the 128-byte requests of gfx950's L2 as "
+                                "64 bytes" % (BATCH_READS, pmc["summary_file"], launches_per_step))
         except (OSError, ValueError, KeyError):
             pass
         # bytes the dominant kernel NEEDS: its share of the reads plus 16 bytes (one 128-bit block) per Bloom lookup it
@@ -633,11 +679,15 @@ def main():
         if dom == "k_infer" and stats.get("infer_lookups"):
             per_launch = kernels[dom]["launches"] // args.steps
             useful = round(n_local * READ_LEN * 1.25 / per_launch + 16.0 * stats["infer_lookups"] / per_launch)
-        roof = dict(bound="hbm", kernel=dom, useful_bytes=useful, achieved=kernels[dom]["achieved_GBps"], peak=HBM_PEAK_GBPS, unit="GB/s",
-                    frac=round(kernels[dom]["achieved_GBps"] / HBM_PEAK_GBPS, 4), traffic=traffic,
-                    algorithmic_bytes_per_launch=kernels[dom]["alg_bytes_per_launch"], avg_launch_ms=kernels[dom]["avg_ms"],
+        roof = dict(bound="hbm", kernel=dom, useful_bytes=useful, achieved=dom_GBps, peak=HBM_PEAK_GBPS, unit="GB/s",
+                    frac=round(dom_GBps / HBM_PEAK_GBPS, 4), traffic=traffic,
+                    algorithmic_bytes_per_launch=kernels[dom]["alg_bytes_per_launch"], avg_launch_ms=dom_ms,
+                    duration_measured_in=dom_how,
+                    timed_region_avg_launch_ms=kernels[dom]["avg_ms"],
+                    timed_region_note="in the timed region the kernel shares the chip with the insert side of pass 2 on the side stream; "
+                                      "its event duration there is not its own cost",
                     traffic_note=traffic_note,
-                    traffic_GBps=None if traffic is None else round(traffic / kernels[dom]["avg_ms"] / 1e6, 1),
+                    traffic_GBps=None if traffic is None else round(traffic / dom_ms / 1e6, 1),
                     note="achieved = SURVEY 8d's algorithmic bytes (64 per Bloom query) over the launch time.  The engine's blocks are 16 bytes, "
                          "but the L2 fetches a whole 128-byte line per random lookup (tools/probe_req: TCC_EA0_RDREQ_128B = lookups), so the "
                          "HBM traffic is above the algorithmic figure although 23 % of the queries are answered by hint bits; in those real "

@@ -20,6 +20,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "kbbq_engine.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -59,6 +61,41 @@ uint64_t kbbq_bgzf_bound(uint64_t n);
 
 /* Milliseconds the device spent in the writer's kernels since creation (format, deflate, gather), for reports. */
 int kbbq_bgzf_kernel_ms(kbbq_bgzf *z, double *format_ms, double *deflate_ms, double *gather_ms);
+
+/* ---- the input side: a BGZF-compressed four-line FASTQ file read on the device ---------------------------------------
+ * What it replaces: kseq_read over bgzf_read (htsiter.hh:101-126, htsiter.cc:49-60) and the FASTQ constructor of
+ * CReadData (readutils.cc:64-104), once per chunk of the file instead of once per record and pass.  The caller feeds the
+ * file's bytes in chunks; the device inflates every BGZF block (one wavefront each), finds the lines, checks that the
+ * records have kseq's four-line shape, and packs them into the engine's read layout.  The same chunks fed again in pass 4
+ * give the output: the records' text re-assembled on the device around the new qualities and deflated by a kbbq_bgzf.
+ * Shapes this path does not take -- multi-line records, FASTA, empty reads, carriage returns, "RG:" fields in read names,
+ * a file that is not BGZF -- are reported (flags bit 0) and left to the caller's serial reader, which stays the definition. */
+typedef struct kbbq_fastq_reader kbbq_fastq_reader;
+typedef struct kbbq_fastq_chunk {
+    uint64_t consumed;      /* bytes of the input that were taken: whole BGZF blocks (feed the rest again with the next chunk) */
+    uint64_t n_records;     /* complete records of this chunk (a record cut by the chunk's end is carried into the next one) */
+    uint64_t n_bases;
+    uint32_t longest, shortest;
+    uint32_t flags;         /* bit 0: a shape the device path does not take; bit 1: a read name shorter than 2 characters
+                             * (readutils.cc:90 throws); bit 2: the input ended inside a record */
+    uint32_t n_blocks;      /* BGZF blocks inflated */
+    uint64_t text_bytes;    /* inflated bytes of this chunk */
+} kbbq_fastq_chunk;
+int kbbq_fastq_reader_create(int32_t device, kbbq_fastq_reader **out);
+void kbbq_fastq_reader_destroy(kbbq_fastq_reader *r);
+/* Restart at the beginning of a file (pass 4 feeds the same chunks again). */
+int kbbq_fastq_reader_rewind(kbbq_fastq_reader *r);
+/* The next bytes of the file (host memory; page-locked memory is copied by DMA).  last != 0: nothing follows. */
+int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uint64_t n_bytes, int32_t last, kbbq_fastq_chunk *info);
+/* The current chunk's records as a device batch (arrays owned by the library: kbbq_reads_free): bases, N mask, qualities,
+ * offsets (NULL and read_len for equally long reads), second-in-pair flags, off-case bits when a base is not upper-case. */
+int kbbq_fastq_reader_batch(kbbq_fastq_reader *r, kbbq_reads *dev);
+/* Pass 4: the current chunk's records as "@name\nseq\n+comment\nqual\n" (FastqFile::write, htsiter.cc:75-86) with
+ * d_qual (device: the batch's new qualities, in the batch's base order) on the quality lines, submitted to writer z
+ * (kbbq_bgzf_collect returns the blocks).  after_stream as in kbbq_bgzf_submit. */
+int kbbq_fastq_reader_write(kbbq_fastq_reader *r, kbbq_bgzf *z, const uint8_t *d_qual, void *after_stream);
+/* Milliseconds the device spent inflating / indexing + packing since creation. */
+int kbbq_fastq_reader_kernel_ms(kbbq_fastq_reader *r, double *inflate_ms, double *index_ms);
 
 /* ---- host-only twin (no GPU touched): the same scalar pieces (Huffman lengths, header, token bits, CRC chaining,
  * framing) around a serial match finder; lets the CPU test-suite inflate what those pieces produce. */

@@ -150,7 +150,9 @@ int kbbq_engine_reset(kbbq_engine *e);
 int kbbq_engine_sync(kbbq_engine *e);
 /* Numeric knobs of an engine (tests and measurements; none changes a result): "bucket_records" = records gathered per
  * flush of the slice-bucketed inserts (before the first batch; KBBQ_BUCKET_RECORDS), "pass4_piece" = bases per piece of
- * the pass-4 pipeline of a host batch (KBBQ_PASS4_PIECE).  KBBQ_EINVAL for an unknown name. */
+ * the pass-4 pipeline of a host batch (KBBQ_PASS4_PIECE), "no_overlap" = 1 / 0: KBBQ_F_NO_OVERLAP switched on or off between
+ * two runs (the call waits for everything queued; bench.py takes its exclusive kernel durations this way).  KBBQ_EINVAL for
+ * an unknown name. */
 int kbbq_engine_tune(kbbq_engine *e, const char *name, uint64_t value);
 /* hipStream_t of the engine, as void*. */
 void *kbbq_engine_stream(kbbq_engine *e);

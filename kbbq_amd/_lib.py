@@ -67,6 +67,11 @@ class SynthParams(ctypes.Structure):
                 ("n_rg", ctypes.c_uint32), ("paired", ctypes.c_uint32), ("n_per_million", ctypes.c_uint32)]
 
 
+class FastqChunk(ctypes.Structure):
+    _fields_ = [("consumed", c_u64), ("n_records", c_u64), ("n_bases", c_u64), ("longest", ctypes.c_uint32),
+                ("shortest", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("n_blocks", ctypes.c_uint32), ("text_bytes", c_u64)]
+
+
 class ProfileEntry(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 48), ("launches", c_u64), ("total_ms", ctypes.c_double)]
 
@@ -147,6 +152,13 @@ SYMBOLS = {
     "kbbq_bgzf_bound": (c_u64, [c_u64]),
     "kbbq_bgzf_kernel_ms": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "kbbq_host_bgzf_compress": (ctypes.c_int, [c_vp, c_u64, c_vp, c_u64, c_u64p]),
+    "kbbq_fastq_reader_create": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(c_vp)]),
+    "kbbq_fastq_reader_destroy": (None, [c_vp]),
+    "kbbq_fastq_reader_rewind": (ctypes.c_int, [c_vp]),
+    "kbbq_fastq_reader_chunk": (ctypes.c_int, [c_vp, c_vp, c_u64, ctypes.c_int32, ctypes.POINTER(FastqChunk)]),
+    "kbbq_fastq_reader_batch": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads)]),
+    "kbbq_fastq_reader_write": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "kbbq_fastq_reader_kernel_ms": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }
 
 _LIB = None

@@ -64,3 +64,38 @@ def host_compress(payload):
     n = ctypes.c_uint64()
     _lib.check(L.kbbq_host_bgzf_compress(a.ctypes.data if a.size else None, a.size, out.ctypes.data, cap, ctypes.byref(n)))
     return out[:n.value].tobytes()
+
+
+class FastqReader:
+    """A BGZF-compressed four-line FASTQ file read on the device (include/kbbq_bgzf.h: kbbq_fastq_reader)."""
+
+    def __init__(self, device=0):
+        self.L = _lib.lib()
+        self.h = _lib.c_vp()
+        _lib.check(self.L.kbbq_fastq_reader_create(device, ctypes.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.kbbq_fastq_reader_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def rewind(self):
+        _lib.check(self.L.kbbq_fastq_reader_rewind(self.h))
+
+    def chunk(self, data, last):
+        """Feed bytes of the file; returns the kbbq_fastq_chunk as a dict."""
+        a = np.frombuffer(data, dtype=np.uint8)
+        info = _lib.FastqChunk()
+        _lib.check(self.L.kbbq_fastq_reader_chunk(self.h, a.ctypes.data if a.size else None, a.size, 1 if last else 0, ctypes.byref(info)))
+        return {k: getattr(info, k) for k, _ in _lib.FastqChunk._fields_}
+
+    def batch(self):
+        d = _lib.Reads()
+        _lib.check(self.L.kbbq_fastq_reader_batch(self.h, ctypes.byref(d)))
+        return d
+
+    def write(self, writer, d_qual, after_stream=None):
+        _lib.check(self.L.kbbq_fastq_reader_write(self.h, writer.h, d_qual, after_stream))

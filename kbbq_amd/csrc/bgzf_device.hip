@@ -11,6 +11,7 @@
 #include "../../include/kbbq_engine.h"
 #include "abi_internal.h"
 #include "bgzf_device.h"
+#include "bgzf_inflate.h"
 
 using namespace kbbq::dfl;
 
@@ -294,6 +295,350 @@ int kbbq_bgzf_kernel_ms(kbbq_bgzf *z, double *format_ms, double *deflate_ms, dou
     if (format_ms) *format_ms = z->ms_format;
     if (deflate_ms) *deflate_ms = z->ms_deflate;
     if (gather_ms) *gather_ms = z->ms_gather;
+    return KBBQ_OK;
+}
+
+}  // extern "C"
+
+// ============================================================ the input side: BGZF FASTQ read on the device
+
+struct kbbq_fastq_reader {
+    int device = 0;
+    hipStream_t st = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr, t2 = nullptr;
+    Buf comp, text, status;                 // compressed chunk, inflated text (carry first), per-block status
+    Buf blk_meta, h_meta;                   // per block: c_off, o_off (u64), c_len, o_len (u32) -- device and page-locked host copies
+    Buf tile_counts, tile_sums, nl_pos;     // newline index
+    Buf idx_u32, idx_second, base_sz, text_sz, flags;      // record index (FastqIndex)
+    Buf carry;                              // text of the record the previous chunk's end cut (device)
+    Buf h_small;                            // page-locked scratch for small read-backs
+    uint64_t carry_bytes = 0;
+    // the current chunk
+    uint64_t text_bytes = 0, n_records = 0, n_bases = 0;
+    uint32_t longest = 0, shortest = 0;
+    bool have_chunk = false;
+    double ms_inflate = 0, ms_index = 0;
+};
+
+namespace {
+
+int device_scan(kbbq_fastq_reader *r, uint64_t *d, uint64_t n, uint64_t *d_total /* device */) {
+    const uint64_t n_tiles = (n + DSCAN_TILE - 1) / DSCAN_TILE;
+    int rc = r->tile_sums.reserve((n_tiles + 1) * 8);
+    if (rc) return rc;
+    uint64_t *ts = (uint64_t *)r->tile_sums.p;
+    hipLaunchKernelGGL(k_dscan_tiles, dim3((unsigned)n_tiles), dim3(256), 0, r->st, d, n, ts);
+    hipLaunchKernelGGL(k_dscan_sums, dim3(1), dim3(1024), 0, r->st, ts, n_tiles, d_total);
+    hipLaunchKernelGGL(k_dscan_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, r->st, d, n, (const uint64_t *)ts);
+    HIP_TRY(hipGetLastError());
+    return KBBQ_OK;
+}
+
+FastqIndex index_of(kbbq_fastq_reader *r, uint64_t cap) {
+    FastqIndex X;
+    uint32_t *u = (uint32_t *)r->idx_u32.p;
+    X.name_off = u; X.name_len = u + cap; X.com_off = u + 2 * cap; X.com_len = u + 3 * cap;
+    X.seq_off = u + 4 * cap; X.seq_len = u + 5 * cap; X.qual_off = u + 6 * cap;
+    X.second = (uint8_t *)r->idx_second.p;
+    X.base_sz = (uint64_t *)r->base_sz.p;
+    X.text_sz = (uint64_t *)r->text_sz.p;
+    X.flags = (uint32_t *)r->flags.p;
+    return X;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kbbq_fastq_reader_create(int32_t device, kbbq_fastq_reader **out) {
+    if (!out) return fail(KBBQ_EINVAL, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(KBBQ_ENODEV, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(KBBQ_ENODEV, "device %d of %d", device, ndev);
+    KbbqDeviceGuard guard(device);
+    HIP_TRY(guard.err);
+    kbbq_fastq_reader *r = new kbbq_fastq_reader;
+    r->device = device;
+    r->h_meta.host = r->h_small.host = true;
+    hipError_t he = hipStreamCreateWithFlags(&r->st, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipEventCreate(&r->t0);
+    if (he == hipSuccess) he = hipEventCreate(&r->t1);
+    if (he == hipSuccess) he = hipEventCreate(&r->t2);
+    if (he != hipSuccess) {
+        kbbq_fastq_reader_destroy(r);
+        return fail(KBBQ_EIO, "creating the reader's stream: %s", hipGetErrorString(he));
+    }
+    *out = r;
+    return KBBQ_OK;
+}
+
+void kbbq_fastq_reader_destroy(kbbq_fastq_reader *r) {
+    if (!r) return;
+    KbbqDeviceGuard guard(r->device);
+    if (r->st) (void)hipStreamSynchronize(r->st);
+    Buf *all[] = {&r->comp, &r->text, &r->status, &r->blk_meta, &r->h_meta, &r->tile_counts, &r->tile_sums, &r->nl_pos, &r->idx_u32,
+                  &r->idx_second, &r->base_sz, &r->text_sz, &r->flags, &r->carry, &r->h_small};
+    for (Buf *b : all) b->release();
+    hipEvent_t evs[] = {r->t0, r->t1, r->t2};
+    for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+    if (r->st) (void)hipStreamDestroy(r->st);
+    delete r;
+}
+
+int kbbq_fastq_reader_rewind(kbbq_fastq_reader *r) {
+    if (!r) return fail(KBBQ_EINVAL, "null argument");
+    r->carry_bytes = 0;
+    r->have_chunk = false;
+    return KBBQ_OK;
+}
+
+int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uint64_t n_bytes, int32_t last, kbbq_fastq_chunk *info) {
+    if (!r || !info || (!file_bytes && n_bytes)) return fail(KBBQ_EINVAL, "bad argument");
+    KbbqDeviceGuard guard(r->device);
+    HIP_TRY(guard.err);
+    memset(info, 0, sizeof *info);
+    r->have_chunk = false;
+    // ---- the block boundaries: hop from header to header (RFC 1952 member with the 'BC' extra subfield, SAM spec 4.1)
+    std::vector<uint64_t> c_off, o_off;
+    std::vector<uint32_t> c_len, o_len;
+    uint64_t at = 0, text = r->carry_bytes;
+    const uint64_t text_cap = 3500000000ull;      // record offsets travel in 32 bits
+    while (at + 18 <= n_bytes) {
+        const uint8_t *h = file_bytes + at;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { info->flags |= 1; break; }      // not BGZF
+        const uint32_t xlen = h[10] | (h[11] << 8);
+        if (at + 12 + xlen > n_bytes) break;
+        uint32_t bsize = 0;
+        for (uint32_t x = 0; x + 4 <= xlen;) {
+            const uint8_t *sf = h + 12 + x;
+            const uint32_t slen = sf[2] | (sf[3] << 8);
+            if (sf[0] == 66 && sf[1] == 67 && slen == 2 && x + 6 <= xlen) bsize = (sf[4] | (sf[5] << 8)) + 1u;
+            x += 4 + slen;
+        }
+        if (!bsize || bsize < 12 + xlen + 8) { info->flags |= 1; break; }
+        if (at + bsize > n_bytes) break;      // the chunk ends inside this block
+        const uint8_t *tail = h + bsize - 8;
+        const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+        if (isize > 65536) { info->flags |= 1; break; }
+        if (text + isize > text_cap) break;
+        if (isize) {
+            c_off.push_back(at + 12 + xlen);
+            c_len.push_back(bsize - (12 + xlen) - 8);
+            o_off.push_back(text);
+            o_len.push_back(isize);
+            text += isize;
+        }
+        at += bsize;
+    }
+    info->consumed = at;
+    info->n_blocks = (uint32_t)c_off.size();
+    if (info->flags & 1) return KBBQ_OK;
+    if (at == 0 && n_bytes && !last && c_off.empty()) return fail(KBBQ_EINVAL, "the chunk holds no complete BGZF block");
+    const uint32_t nb = (uint32_t)c_off.size();
+    int rc;
+    // ---- compressed bytes and block table to the device, inflate
+    if ((rc = r->comp.reserve(at + 4096))) return rc;
+    if ((rc = r->text.reserve(text + 4096))) return rc;
+    if ((rc = r->status.reserve((size_t)nb * 4 + 64))) return rc;
+    const size_t meta_bytes = (size_t)nb * 24 + 64;
+    if ((rc = r->blk_meta.reserve(meta_bytes))) return rc;
+    if ((rc = r->h_meta.reserve(meta_bytes))) return rc;
+    if ((rc = r->h_small.reserve(4096))) return rc;
+    uint64_t *hm = (uint64_t *)r->h_meta.p;
+    if (nb) {
+        memcpy(hm, c_off.data(), (size_t)nb * 8);
+        memcpy(hm + nb, o_off.data(), (size_t)nb * 8);
+        memcpy((uint32_t *)(hm + 2 * (size_t)nb), c_len.data(), (size_t)nb * 4);
+        memcpy((uint32_t *)(hm + 2 * (size_t)nb) + nb, o_len.data(), (size_t)nb * 4);
+    }
+    HIP_TRY(hipEventRecord(r->t0, r->st));
+    if (r->carry_bytes) HIP_TRY(hipMemcpyAsync(r->text.p, r->carry.p, r->carry_bytes, hipMemcpyDeviceToDevice, r->st));
+    if (nb) {
+        HIP_TRY(hipMemcpyAsync(r->comp.p, file_bytes, at, hipMemcpyHostToDevice, r->st));
+        HIP_TRY(hipMemsetAsync((char *)r->comp.p + at, 0, 4096, r->st));
+        HIP_TRY(hipMemcpyAsync(r->blk_meta.p, hm, (size_t)nb * 24, hipMemcpyHostToDevice, r->st));
+        InflateArgs A;
+        A.comp = (const uint8_t *)r->comp.p;
+        A.c_off = (const uint64_t *)r->blk_meta.p;
+        A.o_off = A.c_off + nb;
+        A.c_len = (const uint32_t *)(A.c_off + 2 * (size_t)nb);
+        A.o_len = A.c_len + nb;
+        A.out = (uint8_t *)r->text.p;
+        A.n_blocks = nb;
+        A.status = (uint32_t *)r->status.p;
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, r->device));
+        const unsigned grid = std::min<unsigned>(nb, (unsigned)std::max(1, prop.multiProcessorCount) * 4);      // 33 KB of LDS each: four per CU
+        hipLaunchKernelGGL(k_inflate, dim3(grid), dim3(64 * INF_WAVES), 0, r->st, A);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemsetAsync((char *)r->text.p + text, 0, 64, r->st));
+    HIP_TRY(hipEventRecord(r->t1, r->st));
+    // ---- lines
+    const uint64_t n_tiles = (text + NL_TILE - 1) / NL_TILE;
+    uint64_t n_lines = 0;
+    if (text) {
+        if ((rc = r->tile_counts.reserve((n_tiles + 2) * 8))) return rc;
+        uint64_t *tc = (uint64_t *)r->tile_counts.p;
+        hipLaunchKernelGGL(k_count_newlines, dim3((unsigned)n_tiles), dim3(256), 0, r->st, (const uint8_t *)r->text.p, text, tc);
+        HIP_TRY(hipGetLastError());
+        if ((rc = device_scan(r, tc, n_tiles, tc + n_tiles))) return rc;
+        HIP_TRY(hipMemcpyAsync(r->h_small.p, tc + n_tiles, 8, hipMemcpyDeviceToHost, r->st));
+        // (and whether every block inflated: one word per block, OR-ed on the host -- a few thousand words)
+        HIP_TRY(hipStreamSynchronize(r->st));
+        n_lines = *(const uint64_t *)r->h_small.p;
+        if (nb) {
+            std::vector<uint32_t> stt(nb);
+            HIP_TRY(hipMemcpy(stt.data(), r->status.p, (size_t)nb * 4, hipMemcpyDeviceToHost));
+            for (uint32_t b = 0; b < nb; ++b)
+                if (stt[b] != INF_OK) return fail(KBBQ_EIO, "BGZF block %u of the chunk does not inflate (code %u)", b, stt[b]);
+        }
+    }
+    const uint64_t n_rec = n_lines / 4;
+    info->text_bytes = text - r->carry_bytes;
+    uint64_t rec_end = 0;      // first byte behind the last complete record
+    if (n_rec) {
+        if ((rc = r->nl_pos.reserve((n_lines + 4) * 4))) return rc;
+        hipLaunchKernelGGL(k_newline_positions, dim3((unsigned)n_tiles), dim3(256), 0, r->st, (const uint8_t *)r->text.p, text,
+                           (const uint64_t *)r->tile_counts.p, (uint32_t *)r->nl_pos.p, n_lines);
+        HIP_TRY(hipGetLastError());
+        // ---- records
+        if ((rc = r->idx_u32.reserve(n_rec * 7 * 4))) return rc;
+        if ((rc = r->idx_second.reserve(n_rec))) return rc;
+        if ((rc = r->base_sz.reserve((n_rec + 2) * 8))) return rc;
+        if ((rc = r->text_sz.reserve((n_rec + 2) * 8))) return rc;
+        if ((rc = r->flags.reserve(64))) return rc;
+        const uint32_t init_flags[4] = {0, 0, 0xFFFFFFFFu, 0};
+        HIP_TRY(hipMemcpyAsync(r->flags.p, init_flags, 16, hipMemcpyHostToDevice, r->st));
+        const FastqIndex X = index_of(r, n_rec);
+        hipLaunchKernelGGL(k_fastq_records, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, r->st, (const uint8_t *)r->text.p,
+                           (const uint32_t *)r->nl_pos.p, n_rec, X);
+        HIP_TRY(hipGetLastError());
+        if ((rc = device_scan(r, X.base_sz, n_rec, X.base_sz + n_rec))) return rc;
+        if ((rc = device_scan(r, X.text_sz, n_rec, X.text_sz + n_rec))) return rc;
+        uint64_t *hs = (uint64_t *)r->h_small.p;
+        HIP_TRY(hipMemcpyAsync(hs, X.base_sz + n_rec, 8, hipMemcpyDeviceToHost, r->st));
+        HIP_TRY(hipMemcpyAsync(hs + 1, X.flags, 16, hipMemcpyDeviceToHost, r->st));
+        HIP_TRY(hipMemcpyAsync(hs + 4, (const uint32_t *)r->nl_pos.p + (4 * n_rec - 1), 4, hipMemcpyDeviceToHost, r->st));
+        HIP_TRY(hipStreamSynchronize(r->st));
+        r->n_bases = hs[0];
+        const uint32_t *fl = (const uint32_t *)(hs + 1);
+        info->flags |= fl[0];
+        r->longest = fl[1];
+        r->shortest = fl[2];
+        rec_end = (uint64_t)(*(const uint32_t *)(hs + 4)) + 1;
+    }
+    HIP_TRY(hipEventRecord(r->t2, r->st));
+    // ---- what the chunk's end cut: kept for the next chunk
+    const uint64_t left = text - rec_end;
+    if (left) {
+        if (last) info->flags |= 4;      // the file ends inside a record (or without a final newline): the serial reader's case
+        if ((rc = r->carry.reserve(left + 64))) return rc;
+        HIP_TRY(hipMemcpyAsync(r->carry.p, (const char *)r->text.p + rec_end, left, hipMemcpyDeviceToDevice, r->st));
+    }
+    HIP_TRY(hipStreamSynchronize(r->st));
+    r->carry_bytes = left;
+    r->text_bytes = text;
+    r->n_records = n_rec;
+    r->have_chunk = true;
+    info->n_records = n_rec;
+    info->n_bases = n_rec ? r->n_bases : 0;
+    info->longest = n_rec ? r->longest : 0;
+    info->shortest = n_rec ? r->shortest : 0;
+    float a = 0, b = 0;
+    if (hipEventElapsedTime(&a, r->t0, r->t1) == hipSuccess) r->ms_inflate += a;
+    if (hipEventElapsedTime(&b, r->t1, r->t2) == hipSuccess) r->ms_index += b;
+    return KBBQ_OK;
+}
+
+int kbbq_fastq_reader_batch(kbbq_fastq_reader *r, kbbq_reads *dev) {
+    if (!r || !dev) return fail(KBBQ_EINVAL, "null argument");
+    if (!r->have_chunk || !r->n_records) return fail(KBBQ_ESTATE, "no records in the current chunk");
+    KbbqDeviceGuard guard(r->device);
+    HIP_TRY(guard.err);
+    const uint64_t n = r->n_records, nbases = r->n_bases;
+    const FastqIndex X = index_of(r, n);
+    memset(dev, 0, sizeof *dev);
+    dev->n_reads = n;
+    dev->n_bases = nbases;
+    dev->on_device = 1;
+    void *b = nullptr, *m = nullptr, *q = nullptr, *oc = nullptr, *off = nullptr, *fl = nullptr, *seq_text = nullptr, *cnt = nullptr;
+    auto release = [&]() { hipFree(b); hipFree(m); hipFree(q); hipFree(oc); hipFree(off); hipFree(fl); hipFree(seq_text); hipFree(cnt); };
+#define RB_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { release(); return fail(_e == hipErrorOutOfMemory ? KBBQ_ENOMEM : KBBQ_EIO, "%s: %s", #expr, hipGetErrorString(_e)); } } while (0)
+    const uint64_t words = nbases / 64 + 1;
+    RB_TRY(hipMalloc(&b, (2 * words + 2) * 8));
+    RB_TRY(hipMalloc(&m, (words + 2) * 8));
+    RB_TRY(hipMalloc(&oc, (words + 2) * 8));
+    RB_TRY(hipMalloc(&q, nbases + 16));
+    RB_TRY(hipMalloc(&fl, n));
+    RB_TRY(hipMalloc(&seq_text, nbases + 64));
+    RB_TRY(hipMalloc(&cnt, 8));
+    const bool uniform = r->longest == r->shortest;
+    if (!uniform) RB_TRY(hipMalloc(&off, (n + 1) * 8));
+    RB_TRY(hipMemsetAsync(cnt, 0, 8, r->st));
+    RB_TRY(hipMemsetAsync((char *)b + 2 * words * 8, 0, 16, r->st));
+    RB_TRY(hipMemsetAsync((char *)m + words * 8, 0, 16, r->st));
+    RB_TRY(hipMemsetAsync((char *)oc + words * 8, 0, 16, r->st));
+    RB_TRY(hipMemsetAsync((char *)q + nbases, 0, 16, r->st));
+    hipLaunchKernelGGL(k_fastq_gather, dim3((unsigned)std::min<uint64_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, r->st, (const uint8_t *)r->text.p, X,
+                       (const uint64_t *)X.base_sz, n, (uint8_t *)seq_text, (uint8_t *)q);
+    hipLaunchKernelGGL(k_pack_text, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, r->st, (const uint8_t *)seq_text, nbases, (uint64_t *)b,
+                       (uint64_t *)m, (uint64_t *)oc, (unsigned long long *)cnt);
+    RB_TRY(hipGetLastError());
+    RB_TRY(hipMemcpyAsync(fl, X.second, n, hipMemcpyDeviceToDevice, r->st));
+    if (!uniform) RB_TRY(hipMemcpyAsync(off, X.base_sz, (n + 1) * 8, hipMemcpyDeviceToDevice, r->st));
+    unsigned long long n_off = 0;
+    RB_TRY(hipMemcpyAsync(&n_off, cnt, 8, hipMemcpyDeviceToHost, r->st));
+    RB_TRY(hipStreamSynchronize(r->st));
+#undef RB_TRY
+    hipFree(seq_text);
+    hipFree(cnt);
+    if (!n_off) { hipFree(oc); oc = nullptr; }
+    dev->bases = (const uint64_t *)b;
+    dev->nmask = (const uint64_t *)m;
+    dev->qual = (const uint8_t *)q;
+    dev->offsets = (const uint64_t *)off;
+    dev->flags = (const uint8_t *)fl;
+    dev->rg = nullptr;
+    dev->read_len = uniform ? r->longest : 0;
+    dev->offcase = (const uint64_t *)oc;
+    return KBBQ_OK;
+}
+
+int kbbq_fastq_reader_write(kbbq_fastq_reader *r, kbbq_bgzf *z, const uint8_t *d_qual, void *after_stream) {
+    if (!r || !z || !d_qual) return fail(KBBQ_EINVAL, "null argument");
+    if (!r->have_chunk || !r->n_records) return fail(KBBQ_ESTATE, "no records in the current chunk");
+    if (r->device != z->device) return fail(KBBQ_EINVAL, "reader and writer are on different devices");
+    KbbqDeviceGuard guard(z->device);
+    HIP_TRY(guard.err);
+    Submission *sp;
+    int rc = begin_submission(z, after_stream, &sp);
+    if (rc) return rc;
+    Submission &s = *sp;
+    const uint64_t n = r->n_records;
+    const FastqIndex X = index_of(r, n);
+    // the size of the text: the scanned sizes' total sits behind the offsets
+    uint64_t t = 0;
+    HIP_TRY(hipMemcpy(&t, X.text_sz + n, 8, hipMemcpyDeviceToHost));
+    s.n = t;
+    s.formatted = true;
+    if ((rc = s.payload.reserve(t + 16))) return rc;
+    HIP_TRY(hipMemsetAsync((char *)s.payload.p + t, 0, 16, z->st));
+    HIP_TRY(hipEventRecord(s.t0, z->st));
+    hipLaunchKernelGGL(k_fastq_text_indexed, dim3((unsigned)std::min<uint64_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, z->st, (const uint8_t *)r->text.p, X,
+                       (const uint64_t *)X.text_sz, (const uint64_t *)X.base_sz, d_qual, n, (uint8_t *)s.payload.p);
+    HIP_TRY(hipGetLastError());
+    if ((rc = launch_deflate(z, s))) return rc;
+    // the reader's text and index are read by the kernel just queued: the next kbbq_fastq_reader_chunk must not overwrite
+    // them before it has run
+    HIP_TRY(hipEventSynchronize(s.t1));
+    return KBBQ_OK;
+}
+
+int kbbq_fastq_reader_kernel_ms(kbbq_fastq_reader *r, double *inflate_ms, double *index_ms) {
+    if (!r) return fail(KBBQ_EINVAL, "null argument");
+    if (inflate_ms) *inflate_ms = r->ms_inflate;
+    if (index_ms) *index_ms = r->ms_index;
     return KBBQ_OK;
 }
 

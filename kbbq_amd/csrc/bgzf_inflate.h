@@ -1,0 +1,570 @@
+// bgzf_inflate.h -- the input side of the BGZF codec on the device (gfx950): every BGZF block of a file inflated by one
+// wavefront, then the four-line FASTQ records of the inflated text indexed and packed into the engine's read layout.
+// Included once by bgzf_device.hip.
+//
+// What it replaces: the reference reads its input through htslib -- bgzf_read under kseq_read (htsiter.hh:101-126,
+// htsiter.cc:49-60) -- on the host, once per pass.  Here the compressed file goes to HBM as it is and stays there;
+// the host only finds the block boundaries (18-byte headers) and reads the file.
+//
+//   k_inflate            RFC 1951 decoder, one BGZF block per wavefront.  The decoder is a serial machine, so a wave runs
+//                        it in uniform control flow (everything it decides lives in scalar registers) and uses its lanes
+//                        as storage and for the copies: the canonical-code tables sit in vector registers (lane l holds
+//                        the bound of the codes of length l: one compare + ballot finds a code's length, v_readlane
+//                        fetches its symbol), 256 bytes of the compressed stream per vector register, and the
+//                        32 KB window in LDS, where a match is copied by up to 64 lanes at once and from where finished
+//                        4 KB pieces leave for HBM as coalesced 16-byte stores.  No per-symbol memory latency anywhere.
+//   k_count_newlines / k_newline_positions   where the lines of the inflated text start
+//   k_fastq_records      per record (four lines): name / comment / sequence / quality fields, kseq's rules
+//                        (htsiter.cc:52-59, kseq.h) and the read-name rules of readutils.cc:74-97 that need no dictionary
+//   k_fastq_gather       sequence text and qualities (- 33) of the records into the batch's contiguous arrays
+//   k_pack_text          2 bit per base, N mask, off-case bits from the sequence text (kbbq_pack_bases_case on the device)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "deflate_common.h"
+
+namespace kbbq {
+namespace dfl {
+
+constexpr int INF_WINDOW = 32768;            // DEFLATE's window: the LDS ring of one wavefront
+constexpr int INF_FLUSH = 4096;              // bytes that leave the ring for HBM at a time
+constexpr int INF_WAVES = 1;                 // one wavefront per workgroup
+
+// status codes of a block
+enum : uint32_t { INF_OK = 0, INF_BAD_BLOCK_TYPE = 1, INF_BAD_STORED = 2, INF_BAD_CODE = 3, INF_OVERRUN_IN = 4, INF_OVERRUN_OUT = 5,
+                  INF_BAD_DISTANCE = 6, INF_BAD_LENGTHS = 7, INF_SIZE_MISMATCH = 8 };
+
+struct InflateArgs {
+    const uint8_t *comp;        // the compressed bytes of the chunk (+ 1 KB readable behind them)
+    const uint64_t *c_off;      // per block: where its DEFLATE stream starts in comp
+    const uint32_t *c_len;      //            bytes of DEFLATE stream
+    const uint64_t *o_off;      //            where its bytes go in out
+    const uint32_t *o_len;      //            ISIZE
+    uint8_t *out;
+    uint32_t n_blocks;
+    uint32_t *status;           // per block
+};
+
+// the canonical decoder of one alphabet, in registers: lane l (1..15) of `lim` holds the exclusive upper bound of the
+// codes of length <= l, left-aligned to 15 bits; lane l of `offs` holds (index of the first symbol of length l) - (first code
+// of length l); sym[j] lane i = symbol number 64 j + i in (length, value) order.
+template <int NREG>
+struct CodeRegs {
+    uint32_t lim, offs;
+    uint32_t sym[NREG];
+};
+
+struct InflateLds {
+    alignas(16) uint8_t ring[INF_WINDOW];
+    uint8_t lens[320];           // code lengths of a dynamic block (literal/length then distance)
+    uint16_t sorted[320];        // scratch of the table builder
+};
+
+// Build the register tables of one alphabet from lens[0..n) (LDS).  Uniform control flow; returns false for an
+// over-subscribed set of lengths.  An incomplete code is accepted (RFC 1951 allows a single distance code); codes it
+// does not define decode as an error later.
+template <int NREG>
+__device__ __forceinline__ bool build_code(const uint8_t *lens, int n, uint16_t *scratch, CodeRegs<NREG> &C, int lane) {
+    // counts per length: ballots over chunks of 64 symbols
+    uint32_t my_len[NREG];
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) { const int s = 64 * j + lane; my_len[j] = s < n ? lens[s] : 0u; }
+    uint32_t lim = 0, offs = 0;
+    uint32_t code = 0, index = 0;
+    int left = 1;
+    bool ok = true;
+    for (int l = 1; l <= MAX_BITS; ++l) {
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < NREG; ++j) cnt += (uint32_t)__popcll(__ballot(my_len[j] == (uint32_t)l));
+        left = (left << 1) - (int)cnt;
+        if (left < 0) ok = false;
+        // lane l: bound of the codes of length <= l, and the offset that turns a code of length l into its symbol's index
+        const uint32_t bound = (code + cnt) << (MAX_BITS - l);
+        const uint32_t off = index - code;
+        if (lane == l) { lim = bound; offs = off; }
+        // where this lane's symbols of length l go
+#pragma unroll
+        for (int j = 0; j < NREG; ++j) {
+            const uint64_t b = __ballot(my_len[j] == (uint32_t)l);
+            if (my_len[j] == (uint32_t)l) scratch[index + (uint32_t)__popcll(b & ((1ull << lane) - 1))] = (uint16_t)(64 * j + lane);
+            index += (uint32_t)__popcll(b);
+        }
+        code = (code + cnt) << 1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    C.lim = lim;
+    C.offs = offs;
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) C.sym[j] = (64 * j + lane) < 320 ? scratch[64 * j + lane] : 0u;
+    __builtin_amdgcn_wave_barrier();
+    return ok;
+}
+
+// The bit reader: 256 bytes of the stream per vector register (lane i = dword i), two registers ahead; the bit buffer and
+// its counters are wave-uniform.
+struct BitReader {
+    const uint32_t *base;     // dword-aligned start
+    uint32_t w0, w1;          // current and next 64 dwords (per lane)
+    uint32_t idx;             // next dword of w0 to take (0..64)
+    uint32_t chunk;           // index of the 256-byte chunk in w0
+    uint64_t buf;             // bits not consumed yet, LSB first
+    int cnt;                  // how many
+    uint64_t taken;           // bits consumed so far (for the bound check)
+    __device__ __forceinline__ void init(const uint8_t *p, int lane) {
+        const uintptr_t a = (uintptr_t)p;
+        base = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+        w0 = base[lane];
+        w1 = base[64 + lane];
+        idx = 0;
+        chunk = 0;
+        buf = 0;
+        cnt = 0;
+        taken = 0;
+        const int skip = (int)(a & 3) * 8;
+        refill();
+        buf >>= skip;
+        cnt -= skip;
+    }
+    __device__ __forceinline__ void refill() {      // at least 32 valid bits afterwards
+        if (cnt <= 32) {
+            const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)w0, (int)idx);
+            buf |= (uint64_t)d << cnt;
+            cnt += 32;
+            if (++idx == 64) {
+                idx = 0;
+                ++chunk;
+                w0 = w1;
+                w1 = base[(size_t)(chunk + 1) * 64 + (threadIdx.x & 63)];
+            }
+        }
+    }
+    __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(buf & ((1ull << n) - 1)); }
+    __device__ __forceinline__ void drop(int n) { buf >>= n; cnt -= n; taken += (uint64_t)n; }
+    __device__ __forceinline__ uint32_t get(int n) {      // n <= 16
+        refill();
+        const uint32_t v = peek(n);
+        drop(n);
+        return v;
+    }
+};
+
+// one symbol of the alphabet C from the reader; -1: a bit pattern the code does not define
+template <int NREG>
+__device__ __forceinline__ int decode_symbol(BitReader &B, const CodeRegs<NREG> &C, int lane) {
+    B.refill();
+    // the next 15 bits, first bit of the code in the highest place (Huffman codes are packed starting with their MSB)
+    const uint32_t v = __brev(B.peek(MAX_BITS)) >> (32 - MAX_BITS);
+    const uint64_t fits = __ballot(lane >= 1 && lane <= MAX_BITS && v < C.lim);
+    if (!fits) return -1;
+    const int len = (int)__builtin_ctzll(fits);
+    const uint32_t index = (uint32_t)__builtin_amdgcn_readlane((int)C.offs, len) + (v >> (MAX_BITS - len));
+    B.drop(len);
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < NREG; ++j)
+        if ((index >> 6) == (uint32_t)j) s = (uint32_t)__builtin_amdgcn_readlane((int)C.sym[j], (int)(index & 63));
+    return (int)s;
+}
+
+__global__ void __launch_bounds__(64 * INF_WAVES) k_inflate(InflateArgs A) {
+    __shared__ InflateLds lds_all[INF_WAVES];
+    const int lane = threadIdx.x & 63;
+    InflateLds &S = lds_all[0];
+    const uint32_t wave = blockIdx.x, n_waves = gridDim.x;
+    for (uint32_t blk = wave; blk < A.n_blocks; blk += n_waves) {
+        const uint8_t *src = A.comp + A.c_off[blk];
+        const uint64_t src_bits = (uint64_t)A.c_len[blk] * 8;
+        uint8_t *dst = A.out + A.o_off[blk];
+        const uint32_t want = A.o_len[blk];
+        const bool dst_aligned = ((uintptr_t)dst & 15) == 0;
+        BitReader B;
+        B.init(src, lane);
+        uint32_t pos = 0, flushed = 0;      // bytes produced / bytes that have left the ring
+        uint32_t err = INF_OK;
+        // finished 4 KB pieces of the ring -> HBM
+        auto flush_to = [&](uint32_t upto) {
+            while (flushed + INF_FLUSH <= upto) {
+                const uint32_t r0 = flushed & (INF_WINDOW - 1);
+                if (dst_aligned) {
+#pragma unroll
+                    for (int it = 0; it < INF_FLUSH / 1024; ++it) {
+                        const uint32_t o = (uint32_t)it * 1024 + (uint32_t)lane * 16;
+                        *reinterpret_cast<uint4 *>(dst + flushed + o) = *reinterpret_cast<const uint4 *>(&S.ring[r0 + o]);
+                    }
+                } else {
+                    for (uint32_t o = lane; o < INF_FLUSH; o += 64) dst[flushed + o] = S.ring[r0 + o];
+                }
+                flushed += INF_FLUSH;
+            }
+        };
+        bool last = false;
+        while (!last && err == INF_OK) {
+            last = B.get(1) != 0;
+            const uint32_t type = B.get(2);
+            if (type == 0) {
+                // stored: to the next byte boundary, LEN, ~LEN, the bytes
+                B.refill();
+                B.drop(B.cnt & 7);
+                const uint32_t len = B.get(16), nlen = B.get(16);
+                if ((len ^ nlen) != 0xFFFFu) { err = INF_BAD_STORED; break; }
+                if (B.taken + (uint64_t)len * 8 > src_bits) { err = INF_OVERRUN_IN; break; }
+                if (pos + len > want) { err = INF_OVERRUN_OUT; break; }
+                // the reader is at a byte boundary: the bytes straight from the stream
+                const uint8_t *from = src + (B.taken >> 3);
+                for (uint32_t done = 0; done < len;) {
+                    const uint32_t n = min(len - done, (uint32_t)INF_FLUSH - ((pos + done) & (INF_FLUSH - 1)));
+                    for (uint32_t i = lane; i < n; i += 64) S.ring[(pos + done + i) & (INF_WINDOW - 1)] = from[done + i];
+                    done += n;
+                    __builtin_amdgcn_wave_barrier();
+                    flush_to(pos + done);
+                }
+                pos += len;
+                // re-aim the reader behind the stored bytes
+                const uint64_t at = B.taken + (uint64_t)len * 8;
+                B.init(src + (at >> 3), lane);
+                B.taken = at;
+                continue;
+            }
+            if (type == 3) { err = INF_BAD_BLOCK_TYPE; break; }
+            CodeRegs<5> LL;
+            CodeRegs<1> DD;
+            if (type == 1) {
+                // fixed codes (RFC 1951, 3.2.6)
+                for (int s = lane; s < 288; s += 64) S.lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
+                __builtin_amdgcn_wave_barrier();
+                build_code<5>(S.lens, 288, S.sorted, LL, lane);
+                if (lane < 32) S.lens[lane] = 5;
+                __builtin_amdgcn_wave_barrier();
+                build_code<1>(S.lens, 30, S.sorted, DD, lane);
+            } else {
+                const int hlit = (int)B.get(5) + 257, hdist = (int)B.get(5) + 1, hclen = (int)B.get(4) + 4;
+                if (hlit > 286 || hdist > 30) { err = INF_BAD_LENGTHS; break; }
+                if (lane < N_CL) S.lens[lane] = 0;
+                __builtin_amdgcn_wave_barrier();
+                for (int i = 0; i < hclen; ++i) {
+                    const uint32_t v = B.get(3);
+                    if (lane == 0) S.lens[cl_order(i)] = (uint8_t)v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                CodeRegs<1> CL;
+                if (!build_code<1>(S.lens, N_CL, S.sorted, CL, lane)) { err = INF_BAD_LENGTHS; break; }
+                // the code lengths of both alphabets, run-length coded
+                int i = 0, prev = 0;
+                const int total = hlit + hdist;
+                while (i < total && err == INF_OK) {
+                    const int sym = decode_symbol<1>(B, CL, lane);
+                    if (sym < 0 || sym > 18) { err = INF_BAD_CODE; break; }
+                    int rep = 1, val = sym;
+                    if (sym == 16) { if (i == 0) { err = INF_BAD_LENGTHS; break; } rep = 3 + (int)B.get(2); val = prev; }
+                    else if (sym == 17) { rep = 3 + (int)B.get(3); val = 0; }
+                    else if (sym == 18) { rep = 11 + (int)B.get(7); val = 0; }
+                    if (i + rep > total) { err = INF_BAD_LENGTHS; break; }
+                    if (lane < rep) S.lens[i + lane] = (uint8_t)val;
+                    if (rep > 64 && lane + 64 < rep) S.lens[i + 64 + lane] = (uint8_t)val;
+                    if (rep > 128 && lane + 128 < rep) S.lens[i + 128 + lane] = (uint8_t)val;
+                    i += rep;
+                    prev = val;
+                    if (B.taken > src_bits) err = INF_OVERRUN_IN;
+                }
+                if (err != INF_OK) break;
+                __builtin_amdgcn_wave_barrier();
+                // distance lengths follow the literal/length ones: move them to the front of a second array
+                uint8_t dl = 0;
+                if (lane < hdist) dl = S.lens[hlit + lane];
+                __builtin_amdgcn_wave_barrier();
+                for (int s = hlit + lane; s < 320; s += 64) S.lens[s] = 0;
+                __builtin_amdgcn_wave_barrier();
+                if (S.lens[256] == 0) { err = INF_BAD_LENGTHS; break; }      // no end-of-block code
+                if (!build_code<5>(S.lens, hlit, S.sorted, LL, lane)) { err = INF_BAD_LENGTHS; break; }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 32) S.lens[lane] = lane < hdist ? dl : 0;
+                __builtin_amdgcn_wave_barrier();
+                if (!build_code<1>(S.lens, hdist, S.sorted, DD, lane)) { err = INF_BAD_LENGTHS; break; }
+            }
+            // ---- the block's symbols
+            for (;;) {
+                const int sym = decode_symbol<5>(B, LL, lane);
+                if (sym < 0) { err = INF_BAD_CODE; break; }
+                if (B.taken > src_bits) { err = INF_OVERRUN_IN; break; }
+                if (sym < 256) {
+                    if (pos >= want) { err = INF_OVERRUN_OUT; break; }
+                    if (lane == 0) S.ring[pos & (INF_WINDOW - 1)] = (uint8_t)sym;
+                    ++pos;
+                    if ((pos & (INF_FLUSH - 1)) == 0) { __builtin_amdgcn_wave_barrier(); flush_to(pos); }
+                    continue;
+                }
+                if (sym == 256) break;
+                if (sym > 285) { err = INF_BAD_CODE; break; }
+                // length: base + extra bits (RFC 1951, 3.2.5)
+                const int li = sym - 257;
+                int len, eb;
+                if (li < 8) { len = 3 + li; eb = 0; }
+                else if (li == 28) { len = 258; eb = 0; }
+                else { eb = (li >> 2) - 1; len = 3 + ((4 + (li & 3)) << eb); }
+                if (eb) len += (int)B.get(eb);
+                const int ds = decode_symbol<1>(B, DD, lane);
+                if (ds < 0 || ds > 29) { err = INF_BAD_CODE; break; }
+                int dist;
+                if (ds < 4) dist = 1 + ds;
+                else { const int de = (ds >> 1) - 1; dist = 1 + ((2 + (ds & 1)) << de) + (int)B.get(de); }
+                if ((uint32_t)dist > pos) { err = INF_BAD_DISTANCE; break; }
+                if (pos + (uint32_t)len > want) { err = INF_OVERRUN_OUT; break; }
+                // the copy: byte i of the match is byte (i mod dist) of the dist bytes before it -- every lane reads from
+                // that finished region, so the chunks of a long match do not depend on each other
+                __builtin_amdgcn_wave_barrier();
+                for (int i0 = 0; i0 < len; i0 += 64) {
+                    const int i = i0 + lane;
+                    uint8_t v = 0;
+                    if (i < len) {
+                        const int k = dist >= len ? i : (dist == 1 ? 0 : i % dist);
+                        v = S.ring[(pos - (uint32_t)dist + (uint32_t)k) & (INF_WINDOW - 1)];
+                    }
+                    __builtin_amdgcn_wave_barrier();      // (dist = 32768: the source byte sits where the copy goes)
+                    if (i < len) S.ring[(pos + (uint32_t)i) & (INF_WINDOW - 1)] = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t before = pos;
+                pos += (uint32_t)len;
+                if ((before ^ pos) & ~(uint32_t)(INF_FLUSH - 1)) flush_to(pos);
+            }
+        }
+        if (err == INF_OK && pos != want) err = INF_SIZE_MISMATCH;
+        // what is left in the ring
+        __builtin_amdgcn_wave_barrier();
+        if (err == INF_OK)
+            for (uint32_t o = flushed + lane; o < pos; o += 64) dst[o] = S.ring[o & (INF_WINDOW - 1)];
+        if (lane == 0) A.status[blk] = err;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- exclusive scan of u64 values in place, three launches (tiles of 2048, their sums by one workgroup, the offsets back)
+constexpr int DSCAN_TILE = 2048;
+__global__ void __launch_bounds__(256) k_dscan_tiles(uint64_t *data, uint64_t n, uint64_t *tile_sums) {
+    __shared__ uint64_t wave_tot[4];
+    const uint64_t base = (uint64_t)blockIdx.x * DSCAN_TILE + (uint64_t)threadIdx.x * 8;
+    uint64_t v[8], run = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = base + j < n ? data[base + j] : 0; const uint64_t x = v[j]; v[j] = run; run += x; }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint64_t inc = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint64_t y = __shfl_up(inc, o); if (lane >= o) inc += y; }
+    if (lane == 63) wave_tot[w] = inc;
+    __syncthreads();
+    uint64_t before = inc - run;
+    for (int i = 0; i < w; ++i) before += wave_tot[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (base + j < n) data[base + j] = v[j] + before;
+    if (threadIdx.x == 255) tile_sums[blockIdx.x] = before + run;
+}
+__global__ void __launch_bounds__(1024) k_dscan_sums(uint64_t *tile_sums, uint64_t n_tiles, uint64_t *total) {
+    __shared__ uint64_t part[1024];
+    const int tid = threadIdx.x;
+    const uint64_t per = (n_tiles + 1023) / 1024;
+    const uint64_t b = min(n_tiles, per * tid), e = min(n_tiles, b + per);
+    uint64_t s = 0;
+    for (uint64_t i = b; i < e; ++i) s += tile_sums[i];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t run = 0;
+        for (int i = 0; i < 1024; ++i) { const uint64_t v = part[i]; part[i] = run; run += v; }
+        *total = run;
+    }
+    __syncthreads();
+    uint64_t run = part[tid];
+    for (uint64_t i = b; i < e; ++i) { const uint64_t v = tile_sums[i]; tile_sums[i] = run; run += v; }
+}
+__global__ void __launch_bounds__(256) k_dscan_add(uint64_t *data, uint64_t n, const uint64_t *tile_sums) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) data[i] += tile_sums[i / DSCAN_TILE];
+}
+
+// ---- where the lines start ------------------------------------------------------------------------------------------------
+// newlines per tile of 16 KB (256 lanes x 64 bytes), then -- behind the scan of the tile counts -- their positions
+constexpr int NL_TILE = 16384;
+__device__ __forceinline__ uint64_t newline_bits(const uint8_t *p, uint64_t avail) {      // bit i: p[i] == '\n', i < min(64, avail)
+    uint64_t m = 0;
+    if (avail >= 64) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(p + 16 * w);
+            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (((d[k] >> (8 * b)) & 0xFF) == 10u) m |= 1ull << (16 * w + 4 * k + b);
+        }
+    } else {
+        for (uint64_t i = 0; i < avail; ++i) if (p[i] == 10) m |= 1ull << i;
+    }
+    return m;
+}
+__global__ void __launch_bounds__(256) k_count_newlines(const uint8_t *text, uint64_t n, uint64_t *tile_counts) {
+    __shared__ uint32_t wave_cnt[4];
+    const uint64_t at = (uint64_t)blockIdx.x * NL_TILE + (uint64_t)threadIdx.x * 64;
+    const uint32_t c = at < n ? (uint32_t)__popcll(newline_bits(text + at, n - at)) : 0u;
+    uint32_t s = c;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = (uint64_t)wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+__global__ void __launch_bounds__(256) k_newline_positions(const uint8_t *text, uint64_t n, const uint64_t *tile_first, uint32_t *nl_pos,
+                                                            uint64_t nl_capacity) {
+    __shared__ uint32_t wave_cnt[4];
+    const uint64_t at = (uint64_t)blockIdx.x * NL_TILE + (uint64_t)threadIdx.x * 64;
+    uint64_t m = at < n ? newline_bits(text + at, n - at) : 0ull;
+    const uint32_t c = (uint32_t)__popcll(m);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = c;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o); if (lane >= o) inc += y; }
+    if (lane == 63) wave_cnt[w] = inc;
+    __syncthreads();
+    uint64_t idx = tile_first[blockIdx.x] + (inc - c);
+    for (int i = 0; i < w; ++i) idx += wave_cnt[i];
+    while (m) {
+        const int b = __builtin_ctzll(m);
+        m &= m - 1;
+        if (idx < nl_capacity) nl_pos[idx] = (uint32_t)(at + (uint64_t)b);
+        ++idx;
+    }
+}
+
+// ---- records ------------------------------------------------------------------------------------------------------------------
+// Record r is lines 4r .. 4r+3 of the text.  kseq's reading of a four-line record (htsiter.cc:52-59): the name is the
+// header line behind '@' up to the first white-space character, the comment what follows that character; the third line
+// only has to start with '+'; sequence and quality lines are equally long.  The read-name rules of the FASTQ constructor
+// (readutils.cc:74-97): the part before the first '_' names the read, "/2" at its end makes it second-in-pair; a later
+// field "RG:..." would name a read group -- that needs the dictionary of the host path, as do all shapes other than
+// this one (flagged, and the caller falls back to the serial reader, which stays the definition).
+struct FastqIndex {
+    uint32_t *name_off, *name_len, *com_off, *com_len, *seq_off, *seq_len, *qual_off;      // per record, offsets into the text
+    uint8_t *second;
+    uint64_t *base_sz;        // per record: seq_len (u64, scanned into base offsets)
+    uint64_t *text_sz;        // per record: bytes of its output text (scanned into text offsets)
+    uint32_t *flags;          // [0] bit 0: a shape the device path does not take; bit 1: a read name shorter than 2 characters
+                              // [1] longest read  [2] shortest read
+};
+__device__ __forceinline__ bool is_space(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }
+
+__global__ void __launch_bounds__(256) k_fastq_records(const uint8_t *text, const uint32_t *nl_pos, uint64_t n_records, FastqIndex X) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_records) return;
+    const uint32_t l0 = r ? nl_pos[4 * r - 1] + 1 : 0u;
+    const uint32_t e0 = nl_pos[4 * r], e1 = nl_pos[4 * r + 1], e2 = nl_pos[4 * r + 2], e3 = nl_pos[4 * r + 3];
+    const uint32_t l1 = e0 + 1, l2 = e1 + 1, l3 = e2 + 1;
+    uint32_t bad = 0;
+    if (e0 == l0 || text[l0] != '@') bad |= 1;
+    if (e2 == l2 || text[l2] != '+') bad |= 1;
+    const uint32_t sl = e1 - l1, ql = e3 - l3;
+    if (sl != ql || sl == 0) bad |= 1;
+    // a carriage return before any of the four newlines: kseq would strip it; not this path
+    if ((e0 > l0 && text[e0 - 1] == 13) || (e1 > l1 && text[e1 - 1] == 13) || (e2 > l2 && text[e2 - 1] == 13) || (e3 > l3 && text[e3 - 1] == 13)) bad |= 1;
+    // name and comment
+    uint32_t p = l0 + 1;
+    while (p < e0 && !is_space(text[p])) ++p;
+    const uint32_t nl = p > l0 ? p - (l0 + 1) : 0u;
+    const uint32_t c0 = p < e0 ? p + 1 : e0, cl = e0 - c0;
+    if (nl == 0) bad |= 1;
+    // the read-name rules
+    uint32_t first_len = nl;
+    for (uint32_t i = 0; i < nl; ++i)
+        if (text[l0 + 1 + i] == '_') {
+            if (first_len == nl) first_len = i;
+            if (i + 3 < nl && text[l0 + 2 + i] == 'R' && text[l0 + 3 + i] == 'G' && text[l0 + 4 + i] == ':') bad |= 1;      // a read-group field
+        }
+    if (first_len < 2) bad |= 2;
+    const bool second = first_len >= 2 && text[l0 + 1 + first_len - 2] == '/' && text[l0 + 1 + first_len - 1] == '2';
+    X.name_off[r] = l0 + 1; X.name_len[r] = nl; X.com_off[r] = c0; X.com_len[r] = cl;
+    X.seq_off[r] = l1; X.seq_len[r] = sl; X.qual_off[r] = l3;
+    X.second[r] = second ? 1 : 0;
+    X.base_sz[r] = sl;
+    X.text_sz[r] = (uint64_t)nl + cl + 2 * (uint64_t)sl + 6;
+    if (bad) atomicOr(&X.flags[0], bad);
+    atomicMax(&X.flags[1], sl);
+    atomicMin(&X.flags[2], sl);
+}
+
+// sequence text and qualities of every record into the batch's contiguous arrays (one wavefront per record)
+__global__ void __launch_bounds__(256) k_fastq_gather(const uint8_t *text, FastqIndex X, const uint64_t *base_off, uint64_t n_records,
+                                                       uint8_t *seq_text, uint8_t *qual) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * 4;
+    for (uint64_t r = wave; r < n_records; r += n_waves) {
+        const uint32_t sl = X.seq_len[r];
+        const uint8_t *s = text + X.seq_off[r], *q = text + X.qual_off[r];
+        const uint64_t at = base_off[r];
+        for (uint32_t i = lane; i < sl; i += 64) {
+            seq_text[at + i] = s[i];
+            qual[at + i] = (uint8_t)(q[i] - 33);      // readutils.cc:70-71
+        }
+    }
+}
+
+// 64 bases per lane: the 2-bit words, the non-ACGT mask and the off-case bits (kbbq_pack_bases_case, engine.hip: same table)
+__global__ void __launch_bounds__(256) k_pack_text(const uint8_t *seq_text, uint64_t n_bases, uint64_t *bases, uint64_t *nmask, uint64_t *offcase,
+                                                    unsigned long long *n_offcase) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t words = n_bases / 64 + 1;
+    if (w >= words) return;
+    const uint64_t first = w * 64;
+    const int n = (int)min((uint64_t)64, n_bases > first ? n_bases - first : 0);
+    uint64_t b0 = 0, b1 = 0, nm = 0, oc = 0;
+    for (int j = 0; j < n; ++j) {
+        const uint8_t ch = seq_text[first + j];
+        // seq_nt16_int[seq_nt16_table[ch]] (bloom.hh:351): A/a/0 = 0, C/c/1 = 1, G/g/2 = 2, T/t/3 = 3, everything else non-ACGT
+        uint32_t code = 4, odd = 0;
+        switch (ch) {
+            case 'A': code = 0; break; case 'C': code = 1; break; case 'G': code = 2; break; case 'T': code = 3; break;
+            case 'a': case '0': code = 0; odd = 1; break; case 'c': case '1': code = 1; odd = 1; break;
+            case 'g': case '2': code = 2; odd = 1; break; case 't': case '3': code = 3; odd = 1; break;
+            default: break;
+        }
+        const uint64_t c2 = code & 3 & (code < 4 ? 3u : 0u);
+        if (j < 32) b0 |= c2 << (2 * j); else b1 |= c2 << (2 * (j - 32));
+        nm |= (uint64_t)(code >> 2) << j;
+        oc |= (uint64_t)odd << j;
+    }
+    bases[2 * w] = b0;
+    bases[2 * w + 1] = b1;
+    nmask[w] = nm;
+    offcase[w] = oc;
+    if (oc) atomicAdd(n_offcase, (unsigned long long)__popcll(oc));
+}
+
+// the output text of a batch assembled from the DEVICE copy of the input text (pass 4 of the device path): the same
+// "@name\nseq\n+comment\nqual\n" as k_fastq_text, the pieces found by the record index
+__global__ void __launch_bounds__(256) k_fastq_text_indexed(const uint8_t *text, FastqIndex X, const uint64_t *text_off, const uint64_t *base_off,
+                                                             const uint8_t *new_qual, uint64_t n_records, uint8_t *out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * 4;
+    for (uint64_t r = wave; r < n_records; r += n_waves) {
+        const uint32_t nl = X.name_len[r], cl = X.com_len[r], sl = X.seq_len[r];
+        const uint8_t *name = text + X.name_off[r], *comment = text + X.com_off[r], *seq = text + X.seq_off[r];
+        const uint8_t *q = new_qual + base_off[r];
+        uint8_t *o = out + text_off[r];
+        const uint32_t a_seq = 1 + nl + 1, a_plus = a_seq + sl, a_com = a_plus + 2, a_q = a_com + cl + 1, total = a_q + sl + 1;
+        for (uint32_t i = lane; i < total; i += 64) {
+            uint8_t c;
+            if (i == 0) c = '@';
+            else if (i < 1 + nl) c = name[i - 1];
+            else if (i < a_seq) c = '\n';
+            else if (i < a_plus) c = seq[i - a_seq];
+            else if (i == a_plus) c = '\n';
+            else if (i == a_plus + 1) c = '+';
+            else if (i < a_com + cl) c = comment[i - a_com];
+            else if (i < a_q) c = '\n';
+            else if (i < a_q + sl) c = (uint8_t)(q[i - a_q] + 33);
+            else c = '\n';
+            o[i] = c;
+        }
+    }
+}
+
+}  // namespace dfl
+}  // namespace kbbq

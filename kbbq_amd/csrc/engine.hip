@@ -106,8 +106,8 @@ struct kbbq_engine {
     hipEvent_t ev_draw = nullptr, ev_ins[2] = {nullptr, nullptr};
     bool ins_pending[2] = {false, false};
     int draw_turn = 0;
-    bool side_busy[2] = {false, false};     // counters of that side not yet added to stats
-    uint64_t side_reads[2] = {0, 0};
+    bool side_busy[2] = {false, false};     // a batch of pass 3 used that side since the totals were last read
+    unsigned long long *d_totals = nullptr; // pass 3: [0] reads sent to the correction kernels, [1] Bloom queries there (k_add_counters)
     int side_turn = 0;
     uint32_t *d_qpresent = nullptr;     // quality values seen by pass 2 (256 bits), read at kbbq_trusted_finish
     uint32_t qpresent[8] = {};          // ... as read then; pass 3 on its own (--fixed mode) adds each batch's values (k_qpresence)
@@ -281,25 +281,28 @@ void drain_profile(kbbq_engine *e) {
     e->pending.clear();
 }
 
-// add the finished work-list and query counters of one side of pass 3 to the run's statistics
-int collect_side(kbbq_engine *e, int t) {
-    if (!e->side_busy[t]) return KBBQ_OK;
-    HIP_TRY(hipEventSynchronize(e->ev_side[t]));
-    // (the side's counters were copied into page-locked memory behind its kernels: no blocking copy here -- a blocking
-    // hipMemcpy waits for the whole device, which would serialise the copy of the next host batch behind this one's kernels)
-    const unsigned long long *c = e->bk.h_inserted + 2 + 3 * t;      // work-list length, Bloom queries, off-case work-list length
-    e->stats[0] += c[0] + c[2];
-    e->stats[1] += c[1];
-    e->stats[2] += e->side_reads[t];
-    e->side_busy[t] = false;
+// Pass 3 counts on the device: every batch's work-list length and Bloom-query count are added to running totals by a
+// one-lane kernel behind its walk (k_add_counters), so submitting a batch never waits for the batch that used its side's
+// scratch before (stream waits order that); the host reads the totals when it synchronises anyway.
+__global__ void k_add_counters(const unsigned long long *side, const unsigned long long *offcase, unsigned long long *totals) {
+    totals[0] += side[0] + offcase[0];      // reads sent to the correction kernels
+    totals[1] += side[1];                   // Bloom queries issued there
+}
+
+int collect_totals(kbbq_engine *e) {      // (both streams are idle)
+    unsigned long long t[2] = {0, 0};
+    HIP_TRY(hipMemcpy(t, e->d_totals, 16, hipMemcpyDeviceToHost));
+    e->stats[0] = t[0];
+    e->stats[1] = t[1];
+    e->side_busy[0] = e->side_busy[1] = false;
     return KBBQ_OK;
 }
 
 int sync_engine(kbbq_engine *e) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream2));
-    for (int t = 0; t < 2; ++t) {
-        int rc = collect_side(e, t);
+    if (e->side_busy[0] || e->side_busy[1]) {
+        int rc = collect_totals(e);
         if (rc) return rc;
     }
     drain_profile(e);
@@ -752,8 +755,8 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
         o.no_overlap = (fl & KBBQ_F_NO_OVERLAP) || env_set("KBBQ_NO_OVERLAP");
         o.no_fastpath = (fl & KBBQ_F_NO_FASTPATH) || env_set("KBBQ_NO_FASTPATH");
         o.lane_walk = (fl & KBBQ_F_LANE_WALK) || (getenv("KBBQ_CORRECT") && !strcmp(getenv("KBBQ_CORRECT"), "lane"));
-        o.no_pass4_pipeline = (fl & KBBQ_F_NO_PASS4_PIPELINE) || env_set("KBBQ_NO_PASS4_PIPELINE") || o.no_overlap;
-        o.pass2_side = !(fl & KBBQ_F_PASS2_INORDER) && env_int("KBBQ_PASS2_SIDE", 1) != 0 && !o.no_overlap;
+        o.no_pass4_pipeline = (fl & KBBQ_F_NO_PASS4_PIPELINE) || env_set("KBBQ_NO_PASS4_PIPELINE");      // (no_overlap implies it, where it is used)
+        o.pass2_side = !(fl & KBBQ_F_PASS2_INORDER) && env_int("KBBQ_PASS2_SIDE", 1) != 0;                // (no_overlap switches it off, where it is used)
         o.tally_general = env_set("KBBQ_TALLY_GENERAL");
         o.debug_bucket = env_set("KBBQ_DEBUG_BUCKET");
         o.bucket = (fl & KBBQ_F_BUCKET_ON) ? 1 : (fl & KBBQ_F_BUCKET_OFF) ? 0 : env_set("KBBQ_BUCKET") ? (env_int("KBBQ_BUCKET", 0) != 0 ? 1 : 0) : -1;
@@ -806,6 +809,8 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
     CREATE_TRY(hipMemset(e->d_counters, 0, 64));
     CREATE_TRY(hipMalloc(&e->d_tickets, 64));
     CREATE_TRY(hipMemset(e->d_tickets, 0, 64));
+    CREATE_TRY(hipMalloc(&e->d_totals, 16));
+    CREATE_TRY(hipMemset(e->d_totals, 0, 16));
     e->cur_cnt = e->d_counters;
     CREATE_TRY(hipMalloc(&e->d_dq_qslot, KBBQ_NQ));
     CREATE_TRY(hipMalloc(&e->d_qpresent, 32));
@@ -870,6 +875,7 @@ void kbbq_engine_destroy(kbbq_engine *e) {
     hipFree(e->d_dq_dinuc);
     hipFree(e->d_counters);
     hipFree(e->d_tickets);
+    hipFree(e->d_totals);
     hipFree(e->d_dq_qslot);
     hipFree(e->d_qpresent);
     hipFree(e->d_rg_present[0]);
@@ -898,6 +904,7 @@ int kbbq_engine_reset(kbbq_engine *e) {
     }
     HIP_TRY(hipMemsetAsync(e->d_hist, 0, (e->hist_cycle_words + e->hist_dinuc_words) * 8, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_counters, 0, 64, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_totals, 0, 16, e->stream));
     HIP_TRY(hipMemsetAsync(e->d_qpresent, 0, 32, e->stream));
     memset(e->qpresent, 0, sizeof e->qpresent);
     e->qpresent_known = false;
@@ -933,6 +940,14 @@ int kbbq_engine_tune(kbbq_engine *e, const char *name, uint64_t value) {
         e->opt.bucket_records = value;
     } else if (!strcmp(name, "pass4_piece")) {
         e->opt.pass4_piece = value;
+    } else if (!strcmp(name, "no_overlap")) {
+        // between two runs: every kernel in order on one stream (exclusive kernel durations for a profile) or back
+        ENGINE_DEVICE(e);
+        { int frc = bucket_flush_all(e); if (frc) return frc; }
+        int rc = sync_engine(e);
+        if (rc) return rc;
+        e->opt.no_overlap = value != 0;
+        e->bk.stream[0] = e->bk.stream[1] = nullptr;
     } else {
         return fail(KBBQ_EINVAL, "unknown knob '%s'", name);
     }
@@ -1497,7 +1512,7 @@ template <int NW> struct LaunchTrusted {
             // inserts of long reads are ordered against that stream by events, kbbq_trusted_batch.)
             // Measured +2.4 % on the 30x workload (profiles/r02_bench_full_i_{side,noside}.json); the exclusive duration
             // of k_infer -- the kernel the roofline is quoted for -- comes from the in-order run (KBBQ_F_NO_OVERLAP).
-            const bool side = e->opt.pass2_side;
+            const bool side = e->opt.pass2_side && !e->opt.no_overlap;
             e->bk.stream[1] = side ? e->stream2 : e->stream;
             if (side) {
                 HIP_TRY(hipEventRecord(e->ev_infer, e->stream));
@@ -1786,7 +1801,9 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
     if (overlap) {
         side = e->side_turn;
         e->side_turn ^= 1;
-        if ((rc = collect_side(e, side))) return rc;       // waits for the batch that last used this side
+        // the batch that last used this side's scratch may still be in its walk on the side stream: this batch's scan
+        // (engine's stream) overwrites that scratch, so the stream waits -- the host does not
+        if (e->side_busy[side]) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_side[side], 0));
     } else {
         if ((rc = sync_engine(e))) return rc;              // both sides' scratch is free
     }
@@ -1872,11 +1889,12 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
     }
     if ((rc = run_tally(e, R, d_err, patch, max_len, e->cur))) return rc;
     if (!(R.offcase && !long_reads)) HIP_TRY(hipMemsetAsync(e->d_counters + 6 + side, 0, 8, e->cur));
-    HIP_TRY(hipMemcpyAsync(e->bk.h_inserted + 2 + 3 * side, e->d_counters + 4 * side, 16, hipMemcpyDeviceToHost, e->cur));
-    HIP_TRY(hipMemcpyAsync(e->bk.h_inserted + 4 + 3 * side, e->d_counters + 6 + side, 8, hipMemcpyDeviceToHost, e->cur));
+    hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(1), 0, e->cur, (const unsigned long long *)(e->d_counters + 4 * side),
+                       (const unsigned long long *)(e->d_counters + 6 + side), e->d_totals);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->ev_side[side], e->cur));
     e->side_busy[side] = true;
-    e->side_reads[side] = R.n_reads;
+    e->stats[2] += R.n_reads;
     if (!overlap) {
         if ((rc = sync_engine(e))) return rc;
         if (errors_out && !reads->on_device)
@@ -2001,7 +2019,7 @@ static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qu
     ReadsDev R; int max_len;
     // a large host batch with its result in host memory goes through in pieces (below): 64 Ki-base multiples, at least 2^23
     // bases each, about four per batch
-    const bool no_pipe = e->opt.no_pass4_pipeline;
+    const bool no_pipe = e->opt.no_pass4_pipeline || e->opt.no_overlap;
     const uint64_t piece_env = e->opt.pass4_piece;      // tests: pieces of that many bases (rounded up to 64)
     const uint64_t piece = piece_env ? ((piece_env + 63) >> 6) << 6 : std::max<uint64_t>(1ull << 23, ((reads->n_bases / 4 + 65535) >> 16) << 16);
     const bool pipelined = !reads->on_device && out_on_host && !no_pipe && reads->n_bases >= 2 * piece;

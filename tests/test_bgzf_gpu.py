@@ -2,6 +2,7 @@
 BGZF stream that inflates to the payload -- block framing, CRC-32 and ISIZE checked per block with zlib -- for text,
 binary, incompressible and degenerate payloads, for two submissions in flight, and for FASTQ records whose text the
 device assembles around qualities that never leave HBM (FastqFile::write, htsiter.cc:75-86)."""
+import ctypes
 import zlib
 
 import numpy as np
@@ -88,3 +89,165 @@ def test_large_payload_and_kernel_times(writer):
     ms = writer.kernel_ms()
     assert ms["deflate"] > 0
     print("deflate %.1f ms for %.1f MB -> %.1f MB" % (ms["deflate"], len(data) / 1e6, len(comp) / 1e6))
+
+
+# ---- the input side: BGZF FASTQ read on the device -------------------------------------------------------------------------
+
+def bgzip(data, level=6, block=0xff00):
+    """BGZF as bgzip / htslib write it: zlib raw deflate per 0xff00 payload bytes + the EOF block."""
+    import struct
+    out = []
+    for at in range(0, len(data), block):
+        raw = data[at:at + block]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = co.compress(raw) + co.flush()
+        out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(body) + 25) + body +
+                   struct.pack("<II", zlib.crc32(raw), len(raw)))
+    out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0\x1b\0\x03\0\0\0\0\0\0\0\0\0")
+    return b"".join(out)
+
+
+def make_records(n, seed, uniform=True, comments=True, lower=False):
+    rng = np.random.RandomState(seed)
+    recs = []
+    alphabet = list("ACGTN") + (list("acgt") if lower else [])
+    for i in range(n):
+        l = 150 if uniform else int(rng.randint(1, 300))
+        name = "r%d/%d" % (i, 1 + i % 2) if i % 5 else "lane3_tile%d_x%d" % (i, i * 7)
+        comment = (" BX:Z:%d extra words" % i) if (comments and i % 3 == 0) else ("\tTAB" if comments and i % 7 == 0 else "")
+        seq = "".join(rng.choice(alphabet, l))
+        q = bytes(rng.randint(33, 33 + 60, l).astype(np.uint8)).decode()
+        plus = "+" + (name if i % 11 == 0 else "")
+        recs.append((name, comment, seq, q, plus))
+    text = "".join("@%s%s\n%s\n%s\n%s\n" % (nm, cm, sq, pl, q) for nm, cm, sq, q, pl in recs).encode()
+    return recs, text
+
+
+def download_batch(d):
+    import torch
+    from kbbq_amd.engine import device_tensor
+
+    def get(ptr, nbytes, dt):
+        return device_tensor(ptr, nbytes, torch.uint8, 0).cpu().numpy().view(dt).copy() if ptr else None
+    nb, nr = int(d.n_bases), int(d.n_reads)
+    return dict(bases=get(d.bases, (nb // 32 + 1) * 8, np.uint64), nmask=get(d.nmask, (nb // 64 + 1) * 8, np.uint64), qual=get(d.qual, nb, np.uint8),
+                offsets=get(d.offsets, (nr + 1) * 8, np.uint64), flags=get(d.flags, nr, np.uint8), offcase=get(d.offcase, (nb // 64 + 1) * 8, np.uint64),
+                read_len=int(d.read_len))
+
+
+@pytest.mark.parametrize("level", [1, 6, 9, 0])
+def test_inflate_on_the_device_every_block_type(level):
+    """zlib level 0 writes stored blocks, 1-9 dynamic ones, tiny payloads fixed ones: the reader's chunk() inflates them all
+    (the text is checked through the records it finds)."""
+    recs, text = make_records(3000, seed=level)
+    r = bgzf.FastqReader()
+    info = r.chunk(bgzip(text, level), True)
+    assert info["flags"] == 0 and info["n_records"] == len(recs) and info["text_bytes"] == len(text)
+    assert info["n_bases"] == sum(len(x[2]) for x in recs)
+    r.close()
+
+
+@pytest.mark.parametrize("uniform,lower", [(True, False), (False, False), (False, True)])
+def test_reader_batch_equals_the_host_packing(uniform, lower):
+    """The device batch of a chunk (2-bit bases, N mask, qualities - 33, offsets, second-in-pair flags, off-case bits) equals
+    what ReadBatch / kbbq_pack_bases_case make of the same records on the host; the file is fed in three chunks that cut
+    BGZF blocks and records anywhere."""
+    from kbbq_amd.reads import ReadBatch
+    recs, text = make_records(4000, seed=7 + uniform, uniform=uniform, lower=lower)
+    comp = bgzip(text, 6, block=20000)
+    cuts = [0, len(comp) // 3 + 5, 2 * len(comp) // 3 + 11, len(comp)]
+    r = bgzf.FastqReader()
+    got, pending = [], b""
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        data = pending + comp[a:b]
+        info = r.chunk(data, b == len(comp))
+        assert info["flags"] == 0
+        pending = data[info["consumed"]:]
+        if info["n_records"]:
+            d = r.batch()
+            got.append((info, download_batch(d)))
+            _lib.check(_lib.lib().kbbq_reads_free(None, ctypes.byref(d)))
+    assert not pending and sum(i["n_records"] for i, _ in got) == len(recs)
+    at = 0
+    for info, dev in got:
+        n = info["n_records"]
+        part = recs[at:at + n]
+        at += n
+        seq = np.frombuffer("".join(x[2] for x in part).encode(), dtype=np.uint8)
+        qual = np.frombuffer("".join(x[3] for x in part).encode(), dtype=np.uint8) - 33
+        off = np.concatenate([[0], np.cumsum([len(x[2]) for x in part])]).astype(np.uint64)
+        second = np.array([1 if x[0].split("_")[0].endswith("/2") else 0 for x in part], dtype=np.uint8)
+        hb = ReadBatch(seq, qual, off, np.zeros(n, np.uint16), second, uniform=False)
+        nbw, nmw = len(seq) // 32 + 1, len(seq) // 64 + 1
+        assert np.array_equal(dev["bases"][:nbw], hb.bases[:nbw]) and np.array_equal(dev["nmask"][:nmw], hb.nmask[:nmw])
+        assert np.array_equal(dev["qual"], qual) and np.array_equal(dev["flags"], second)
+        if dev["offsets"] is None:
+            assert dev["read_len"] == 150 and all(len(x[2]) == 150 for x in part)
+        else:
+            assert np.array_equal(dev["offsets"], off)
+        lower_bits = np.array([c in b"acgt0123" for c in seq.tobytes()], dtype=np.uint8)
+        if lower_bits.any():
+            assert np.array_equal(np.unpackbits(dev["offcase"].view(np.uint8), bitorder="little")[:len(seq)], lower_bits)
+        else:
+            assert dev["offcase"] is None
+    r.close()
+
+
+def test_reader_reports_the_shapes_it_does_not_take():
+    r = bgzf.FastqReader()
+    good = "@a1\nACGT\n+\nIIII\n"
+    for bad, flag in (("@a1\nACGT\n+\nIII\n", 1),                 # qualities shorter than the sequence
+                      ("@a1\nAC\nGT\n+\nIIII\n@b2\nAC\n+\nII\n@c\nA\n+\nI\n", 1),      # a two-line sequence shifts the lines
+                      (">a1\nACGT\n>b2\nACGT\n", 1),                # FASTA
+                      ("@a1\r\nACGT\r\n+\r\nIIII\r\n", 1),          # carriage returns
+                      ("@x_RG:grp1_more\nACGT\n+\nIIII\n", 1),      # a read group in the name: the host path's dictionary
+                      ("@a\nACGT\n+\nIIII\n", 2),                   # read name shorter than two characters (readutils.cc:90)
+                      ("@a1\n\n+\n\n", 1),                          # an empty read
+                      (good + "@b2\nACGT\n+\nIII", 4)):             # the file ends inside a record
+        r.rewind()
+        info = r.chunk(bgzip((good + bad).encode() if flag != 4 else bad.encode()), True)
+        assert info["flags"] & flag, (bad, info)
+    r.rewind()
+    assert r.chunk(b"@a1\nACGT\n+\nIIII\n" * 10, True)["flags"] & 1      # not BGZF at all
+    r.rewind()
+    assert r.chunk(bgzip((good * 50).encode()), True)["flags"] == 0
+    r.close()
+
+
+def test_reader_and_writer_round_trip_with_new_qualities(writer):
+    """Pass 4 of the device path: the chunk's records come back as "@name\\nseq\\n+comment\\nqual\\n" with the qualities
+    taken from a device array -- the comment moves to the '+' line and whatever stood there is dropped (htsiter.cc:75-86)."""
+    import torch
+    recs, text = make_records(6000, seed=33, uniform=False)
+    r = bgzf.FastqReader()
+    info = r.chunk(bgzip(text, 6), True)
+    assert info["flags"] == 0 and info["n_records"] == len(recs)
+    rng = np.random.RandomState(1)
+    newq = rng.randint(0, 94, info["n_bases"]).astype(np.uint8)
+    dq = torch.from_numpy(newq).cuda()
+    torch.cuda.synchronize()
+    r.write(writer, dq.data_ptr())
+    comp, n_text = writer.collect()
+    want, at = [], 0
+    for nm, cm, sq, q, pl in recs:
+        l = len(sq)
+        comment = cm[1:] if cm else ""
+        want.append(b"@" + nm.encode() + b"\n" + sq.encode() + b"\n+" + comment.encode() + b"\n" + bytes(newq[at:at + l] + 33) + b"\n")
+        at += l
+    want = b"".join(want)
+    assert n_text == len(want)
+    assert b"".join(bgzf_blocks(comp)) == want
+    r.close()
+
+
+def test_reader_large_file_rates(writer):
+    recs, text = make_records(20000, seed=5)
+    text = text * 40                     # 250 MB of text
+    comp = bgzip(text, 6)
+    r = bgzf.FastqReader()
+    info = r.chunk(comp, True)
+    assert info["flags"] == 0 and info["n_records"] == 20000 * 40
+    a, b = ctypes.c_double(), ctypes.c_double()
+    _lib.check(_lib.lib().kbbq_fastq_reader_kernel_ms(r.h, ctypes.byref(a), ctypes.byref(b)))
+    print("inflate %.1f ms, index %.1f ms for %.0f MB compressed -> %.0f MB" % (a.value, b.value, len(comp) / 1e6, len(text) / 1e6))
+    r.close()
