@@ -262,6 +262,8 @@ def pcie_inclusive(genome_len, coverage, local_rank):
     L = _lib.lib()
     up, dn = ctypes.c_double(), ctypes.c_double()
     _lib.check(L.kbbq_measure_host_link(local_rank, 1 << 30, ctypes.byref(up), ctypes.byref(dn)))
+    up2, dn2 = ctypes.c_double(), ctypes.c_double()
+    _lib.check(L.kbbq_measure_host_link_duplex(local_rank, 1 << 30, ctypes.byref(up2), ctypes.byref(dn2)))
     n_reads = genome_len * coverage // READ_LEN
     alpha_ld, cov, approx = plan_parameters(genome_len, coverage, None)
     e = Engine(K, alpha_ld, SEED_SAMPLER, approx, n_rg=1, max_read_len=READ_LEN, device=local_rank)
@@ -360,6 +362,7 @@ def pcie_inclusive(genome_len, coverage, local_rank):
     out = None
     out_pin.free()
     h2d, d2h = up.value * 1e9, dn.value * 1e9
+    h2d_dx, d2h_dx = up2.value * 1e9, dn2.value * 1e9      # with the other direction busy as well
     # per pass: bytes each way per base (bases 0.25 + N mask 0.125 + qualities 1)
     sub_bytes = [(0.375, 0.0), (1.375, 0.0), (1.375, 0.0), (1.375, 1.0)]
     once_bytes = [(1.375, 0.0), (0.0, 0.0), (0.0, 0.0), (0.0, 1.0)]
@@ -367,7 +370,8 @@ def pcie_inclusive(genome_len, coverage, local_rank):
     def bound(bytes_per_pass, duplex=False):
         # a pass cannot be faster than its transfers or than its resident time; `duplex`: the two directions of pass 4 fully
         # overlapped (the link carries both at once; the engine pipelines a host batch's pass 4 in pieces), otherwise summed
-        return sum(max(max(nb * u / h2d, nb * dwn / d2h) if duplex else nb * u / h2d + nb * dwn / d2h, c)
+        # (duplex: both directions at once, each at the rate measured WITH the other one running)
+        return sum(max(max(nb * u / (h2d_dx if dwn else h2d), nb * dwn / d2h_dx) if duplex else nb * u / h2d + nb * dwn / d2h, c)
                    for (u, dwn), c in zip(bytes_per_pass, t_res))
 
     def mode(t, bytes_per_pass, text):
@@ -376,7 +380,9 @@ def pcie_inclusive(genome_len, coverage, local_rank):
                     bound_Gbases_per_s=round(nb / b / 1e9, 4), fraction_of_bound=round(b / sum(t), 3),
                     duplex_bound_Gbases_per_s=round(nb / bd / 1e9, 4), fraction_of_duplex_bound=round(bd / sum(t), 3), traffic=text)
 
-    return dict(host_link=dict(h2d_GBps=round(up.value, 2), d2h_GBps=round(dn.value, 2), how="one 1 GiB copy each way, page-locked host memory"),
+    return dict(host_link=dict(h2d_GBps=round(up.value, 2), d2h_GBps=round(dn.value, 2), how="one 1 GiB copy each way, page-locked host memory",
+                               duplex_h2d_GBps=round(up2.value, 2), duplex_d2h_GBps=round(dn2.value, 2),
+                               duplex_how="three 1 GiB copies each way at the same time on two streams"),
                 sample="%d reads x %d bp = %.3g bases as page-locked host batches of %d reads (the command line's batch size)" % (n_reads, READ_LEN, nb, PB),
                 resident_pass_seconds=[round(x, 3) for x in t_res],
                 bound="per mode: sum over the four passes of max(bytes up / measured H2D rate + bytes down / measured D2H rate, the pass's resident time); duplex bound: the two directions of a pass overlapped",

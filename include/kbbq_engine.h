@@ -207,6 +207,9 @@ int kbbq_host_free(void *p);
 int kbbq_device_alloc(kbbq_engine *e, size_t bytes, void **out);
 int kbbq_device_free(kbbq_engine *e, void *p);
 int kbbq_measure_host_link(int32_t device, uint64_t bytes, double *h2d_gbps, double *d2h_gbps);
+/* The same with both directions running at once (three copies each way on two streams): the rates pass 4 of the
+ * host-batch mode, which copies in and out at the same time, can hope for. */
+int kbbq_measure_host_link_duplex(int32_t device, uint64_t bytes, double *h2d_gbps, double *d2h_gbps);
 /* For both, e may be NULL (current device): a driver can make its batches resident in HBM while it is
  * still counting the bases that size the engine (kbbq.cc:229-264), then run every pass from HBM.
  * kbbq_reads_alloc_hints gives a device batch zeroed hint arrays (see kbbq_reads.hint_*), owned by the

@@ -128,6 +128,7 @@ SYMBOLS = {
     "kbbq_device_alloc": (ctypes.c_int, [c_vp, ctypes.c_size_t, ctypes.POINTER(c_vp)]),
     "kbbq_device_free": (ctypes.c_int, [c_vp, c_vp]),
     "kbbq_measure_host_link": (ctypes.c_int, [ctypes.c_int32, c_u64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "kbbq_measure_host_link_duplex": (ctypes.c_int, [ctypes.c_int32, c_u64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "kbbq_synth_tables": (ctypes.c_int, [ctypes.POINTER(SynthParams), c_u32p, c_u32p]),
     "kbbq_synth_reads": (ctypes.c_int, [c_vp, ctypes.POINTER(SynthParams), c_u64, c_u64, ctypes.POINTER(Reads)]),
     "kbbq_profile_get": (ctypes.c_int, [c_vp, ctypes.POINTER(ProfileEntry), ctypes.c_int32, c_i32p]),

@@ -1253,6 +1253,60 @@ int kbbq_measure_host_link(int32_t device, uint64_t bytes, double *h2d_gbps, dou
     return KBBQ_OK;
 }
 
+// both directions at once (two streams): what pass 4 of the host-batch mode can hope for
+int kbbq_measure_host_link_duplex(int32_t device, uint64_t bytes, double *h2d_gbps, double *d2h_gbps) {
+    if (!bytes) return fail(KBBQ_EINVAL, "bad argument");
+    int cur_dev = 0;
+    HIP_TRY(hipGetDevice(&cur_dev));
+    DeviceGuard guard(device >= 0 ? device : cur_dev);
+    HIP_TRY(guard.err);
+    void *h_up = nullptr, *h_dn = nullptr, *d_up = nullptr, *d_dn = nullptr;
+    hipEvent_t a0 = nullptr, a1 = nullptr, b0 = nullptr, b1 = nullptr;
+    hipStream_t s_up = nullptr, s_dn = nullptr;
+    int rc = KBBQ_OK;
+    float ms_up = 0, ms_dn = 0;
+#define LINK_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess && rc == KBBQ_OK) rc = fail(KBBQ_EIO, "%s: %s", #x, hipGetErrorString(_e)); } while (0)
+    LINK_TRY(hipHostMalloc(&h_up, bytes, hipHostMallocDefault));
+    LINK_TRY(hipHostMalloc(&h_dn, bytes, hipHostMallocDefault));
+    LINK_TRY(hipMalloc(&d_up, bytes));
+    LINK_TRY(hipMalloc(&d_dn, bytes));
+    LINK_TRY(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking));
+    LINK_TRY(hipStreamCreateWithFlags(&s_dn, hipStreamNonBlocking));
+    LINK_TRY(hipEventCreate(&a0)); LINK_TRY(hipEventCreate(&a1)); LINK_TRY(hipEventCreate(&b0)); LINK_TRY(hipEventCreate(&b1));
+    if (rc == KBBQ_OK) {
+        memset(h_up, 1, bytes);
+        memset(h_dn, 0, bytes);
+        LINK_TRY(hipMemcpyAsync(d_up, h_up, bytes, hipMemcpyHostToDevice, s_up));      // warm-up, both ways
+        LINK_TRY(hipMemcpyAsync(h_dn, d_dn, bytes, hipMemcpyDeviceToHost, s_dn));
+        LINK_TRY(hipStreamSynchronize(s_up));
+        LINK_TRY(hipStreamSynchronize(s_dn));
+        LINK_TRY(hipEventRecord(a0, s_up));
+        LINK_TRY(hipEventRecord(b0, s_dn));
+        for (int i = 0; i < 3; ++i) {
+            LINK_TRY(hipMemcpyAsync(d_up, h_up, bytes, hipMemcpyHostToDevice, s_up));
+            LINK_TRY(hipMemcpyAsync(h_dn, d_dn, bytes, hipMemcpyDeviceToHost, s_dn));
+        }
+        LINK_TRY(hipEventRecord(a1, s_up));
+        LINK_TRY(hipEventRecord(b1, s_dn));
+        LINK_TRY(hipEventSynchronize(a1));
+        LINK_TRY(hipEventSynchronize(b1));
+        LINK_TRY(hipEventElapsedTime(&ms_up, a0, a1));
+        LINK_TRY(hipEventElapsedTime(&ms_dn, b0, b1));
+    }
+#undef LINK_TRY
+    hipEvent_t evs[] = {a0, a1, b0, b1};
+    for (hipEvent_t ev : evs) if (ev) hipEventDestroy(ev);
+    if (s_up) hipStreamDestroy(s_up);
+    if (s_dn) hipStreamDestroy(s_dn);
+    hipFree(d_up); hipFree(d_dn);
+    if (h_up) hipHostFree(h_up);
+    if (h_dn) hipHostFree(h_dn);
+    if (rc) return rc;
+    if (h2d_gbps) *h2d_gbps = ms_up > 0 ? 3.0 * (double)bytes / ms_up / 1e6 : 0;
+    if (d2h_gbps) *d2h_gbps = ms_dn > 0 ? 3.0 * (double)bytes / ms_dn / 1e6 : 0;
+    return KBBQ_OK;
+}
+
 int kbbq_reads_free(kbbq_engine *e, kbbq_reads *dev) {
     if (!dev) return fail(KBBQ_EINVAL, "null argument");
     if (!dev->on_device) return fail(KBBQ_EINVAL, "not a device batch");

@@ -19,7 +19,9 @@
 //     turns that off): same results, four decodes of the input fewer;
 //   * where the reference prints an error and then crashes or throws (missing --genomelen on FASTQ,
 //     kbbq.cc:218; missing RG / OQ tags, readutils.cc:20-30,42-53) this prints the same text and exits 1.
+#include <fcntl.h>
 #include <getopt.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -211,6 +213,15 @@ public:
         ++in_flight_;
         return true;
     }
+    // The current chunk of a device reader with new qualities (kbbq_fastq_reader_write): text assembled from the device's
+    // own copy of the input.
+    bool reader_chunk(kbbq_fastq_reader *reader, const uint8_t *d_qual, void *after_stream) {
+        if (!flush_host()) return false;
+        if (!make_room()) return false;
+        if (kbbq_fastq_reader_write(reader, z_, d_qual, after_stream) < 0) return fail_here();
+        ++in_flight_;
+        return true;
+    }
     // every submission so far has been written out (a caller may then reuse device memory the submissions read)
     bool drain() {
         while (in_flight_ > 0) if (!collect_one()) return false;
@@ -263,6 +274,87 @@ private:
     size_t fill_ = 0;
     int in_flight_ = 0;
     bool failed_ = false, closed_ = false;
+};
+
+// The input side on the GPU (include/kbbq_bgzf.h: kbbq_fastq_reader): a BGZF-compressed four-line FASTQ file goes to the
+// device as it is, chunk by chunk -- inflate, line index, record rules and packing are kernels -- and every chunk becomes one
+// resident batch.  Pass 4 feeds the same chunks again and the records' text is re-assembled there around the new qualities.
+// What the reference does with kseq_read over bgzf_read once per pass (htsiter.cc:49-60).  Any shape this path does not
+// take is reported by the reader and the caller starts over with the host parsers.
+class DeviceFastqInput {
+public:
+    struct Chunk { uint64_t start, given; int last; uint64_t n_records; };
+    ~DeviceFastqInput() { close(); }
+    bool active = false;
+    std::vector<Chunk> chunks;
+    kbbq_fastq_reader *reader = nullptr;
+    double read_s = 0, device_s = 0;
+
+    bool open(const std::string &path) {
+        fd_ = ::open(path.c_str(), O_RDONLY);
+        if (fd_ < 0) return false;
+        struct stat st;
+        if (fstat(fd_, &st) != 0 || !S_ISREG(st.st_mode)) return false;      // a pipe cannot be read twice
+        size_ = (uint64_t)st.st_size;
+        unsigned char magic[4] = {0, 0, 0, 0};
+        if (pread(fd_, magic, 4, 0) != 4 || magic[0] != 0x1f || magic[1] != 0x8b || magic[2] != 8 || !(magic[3] & 4)) return false;      // not BGZF
+        void *p = nullptr;
+        if (kbbq_host_alloc(kChunk, &p) < 0) return false;
+        buf_ = (uint8_t *)p;
+        return kbbq_fastq_reader_create(0, &reader) >= 0;
+    }
+    void close() {
+        if (reader) kbbq_fastq_reader_destroy(reader);
+        reader = nullptr;
+        if (buf_) kbbq_host_free(buf_);
+        buf_ = nullptr;
+        if (fd_ >= 0) ::close(fd_);
+        fd_ = -1;
+    }
+    // the bytes [start, start + n) of the file in the page-locked buffer
+    bool load(uint64_t start, uint64_t n) {
+        const auto t0 = std::chrono::steady_clock::now();
+        uint64_t got = 0;
+        while (got < n) {
+            const ssize_t k = pread(fd_, buf_ + got, n - got, (off_t)(start + got));
+            if (k <= 0) return false;
+            got += (uint64_t)k;
+        }
+        read_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return true;
+    }
+    // first scan: 1 = the next chunk is in `info` (and its records, if any, are the reader's current chunk), 0 = end of file,
+    // -1 = I/O or device error, -2 = a shape for the host parsers
+    int next_chunk(kbbq_fastq_chunk &info) {
+        if (at_ >= size_) return 0;
+        const uint64_t n = std::min<uint64_t>(kChunk, size_ - at_);
+        const int last = at_ + n == size_;
+        if (!load(at_, n)) return -1;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (kbbq_fastq_reader_chunk(reader, buf_, n, last, &info) < 0) return -1;
+        device_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (info.flags & 7) return -2;      // (a read name that is too short included: the host path reports it)
+        if (info.consumed == 0 && !last) return -2;      // a BGZF block larger than the chunk: not a file this path reads
+        chunks.push_back(Chunk{at_, n, last, info.n_records});
+        at_ += last ? n : info.consumed;
+        return 1;
+    }
+    // pass 4: chunk i again (same bytes, same records)
+    bool replay(size_t i, kbbq_fastq_chunk &info) {
+        const Chunk &c = chunks[i];
+        if (i == 0 && kbbq_fastq_reader_rewind(reader) < 0) return false;
+        if (!load(c.start, c.given)) return false;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (kbbq_fastq_reader_chunk(reader, buf_, c.given, c.last, &info) < 0) return false;
+        device_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return info.n_records == c.n_records && !(info.flags & 7);
+    }
+
+private:
+    static constexpr uint64_t kChunk = 256ull << 20;
+    int fd_ = -1;
+    uint64_t size_ = 0, at_ = 0;
+    uint8_t *buf_ = nullptr;
 };
 
 // What the output pass needs of one batch besides the new qualities, kept from the first scan when it fits in
@@ -651,7 +743,43 @@ int main(int argc, char *argv[]) {
     // The first scan parses its input with a pool: BAM always (bam_io.h: BamChunkParser), FASTQ when it is strictly
     // four-line (fastq_io.h: FastqChunkParser) -- anything else, found out while parsing, starts the scan over with the
     // serial reader.  KBBQ_SERIAL_PARSE=1: the serial readers at once.
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    // A BGZF-compressed FASTQ file is read on the GPU (DeviceFastqInput): the compressed bytes go to the device, which
+    // inflates, finds the records and packs them; every chunk of the file is one resident batch.  Anything that path does
+    // not take -- another container, records that are not four lines, read groups in the names, reads that do not fit in HBM
+    // -- starts over with the host parsers below.  KBBQ_DEVICE_READER=0: the host parsers at once.
+    DeviceFastqInput dev_in;
+    if (!is_bam && !fixed_mode && resident.on && filename != "-" && !(getenv("KBBQ_DEVICE_READER") && atoi(getenv("KBBQ_DEVICE_READER")) == 0) &&
+        !(getenv("KBBQ_SERIAL_PARSE") && atoi(getenv("KBBQ_SERIAL_PARSE"))) && dev_in.open(filename)) {
+        bool ok = true;
+        for (;;) {
+            kbbq_fastq_chunk info;
+            const int rc = dev_in.next_chunk(info);
+            if (rc == 0) break;
+            if (rc < 0) { ok = false; break; }
+            if (!info.n_records) continue;
+            const uint64_t need = info.n_bases * 13 / 8 + info.n_records * 16 + (1 << 16);
+            kbbq_reads d;
+            if (info.longest > KBBQ_MAX_READ_LEN || resident.bytes + need > resident.budget || kbbq_fastq_reader_batch(dev_in.reader, &d) < 0) { ok = false; break; }
+            if (kbbq_reads_alloc_hints(&d) < 0) { kbbq_reads_free(nullptr, &d); ok = false; break; }
+            resident.dev.push_back(d);
+            resident.bytes += need;
+            seqlen += info.n_bases;
+            n_reads += info.n_records;
+            longest = std::max<size_t>(longest, info.longest);
+        }
+        if (ok && n_reads) {
+            dev_in.active = true;
+            resident.keep_recs = false;      // the record text comes from the device's own copy of the input in pass 4
+            groups.index_of(std::string());  // FASTQ without read-group fields: the one read group "" (readutils.cc:98-103)
+        } else {
+            seqlen = n_reads = 0;
+            longest = 0;
+            resident.drop();
+            init_resident();
+            dev_in.close();
+        }
+    }
+    for (int attempt = 0; attempt < 2 && !dev_in.active; ++attempt) {
         const bool fast = attempt == 0 && g_io_threads > 1 && !(getenv("KBBQ_SERIAL_PARSE") && atoi(getenv("KBBQ_SERIAL_PARSE")));
         if (attempt == 1) {
             groups = ReadGroups();
@@ -958,7 +1086,36 @@ int main(int argc, char *argv[]) {
             else std::copy(q, q + len, b.qual());
             return bam_out.write(b) ? 0 : -1;
         };
-        if (resident.on && resident.keep_recs && !is_bam && dev_out) {
+        if (dev_in.active && dev_out) {
+            // The device path: the file's chunks again (inflate + record index, as in the first scan), pass 4 into a device
+            // array, the text assembled from the device's own copy of the input, deflated, written.  Nothing but compressed
+            // bytes crosses the host link in either direction.
+            void *d_q[2] = {nullptr, nullptr};
+            size_t d_q_bytes[2] = {0, 0};
+            struct FreeQ { kbbq_engine *e; void **p; ~FreeQ() { for (int i = 0; i < 2; ++i) if (p[i]) kbbq_device_free(e, p[i]); } } free_q{e, d_q};
+            size_t bi = 0;
+            for (size_t ci = 0; ci < dev_in.chunks.size(); ++ci) {
+                kbbq_fastq_chunk info;
+                if (!dev_in.replay(ci, info)) {
+                    std::cerr << put_now << " Error: the input changed between the passes." << std::endl;
+                    return 1;
+                }
+                if (!info.n_records) continue;
+                const kbbq_reads &d = resident.dev[bi];
+                const int t = (int)(bi & 1);
+                ++bi;
+                while (dev_out->in_flight() >= 2) if (!dev_out->drain()) return 1;
+                if (d_q_bytes[t] < d.n_bases + 16) {
+                    if (d_q[t] && kbbq_device_free(e, d_q[t]) < 0) return fail_engine("recalibrating");
+                    d_q[t] = nullptr;
+                    d_q_bytes[t] = d.n_bases + d.n_bases / 8 + 4096;
+                    if (kbbq_device_alloc(e, d_q_bytes[t], &d_q[t]) < 0) return fail_engine("recalibrating");
+                }
+                if (kbbq_recalibrate_batch(e, &d, (uint8_t *)d_q[t]) < 0) return fail_engine("recalibrating");
+                if (!dev_out->reader_chunk(dev_in.reader, (const uint8_t *)d_q[t], kbbq_engine_stream(e))) return 1;
+            }
+            if (!dev_out->drain()) return 1;
+        } else if (resident.on && resident.keep_recs && !is_bam && dev_out) {
             // FASTQ, every batch in HBM, its record text in host memory: the new qualities never leave the GPU.  Pass 4
             // writes them to a device array, the writer assembles "@name\nseq\n+comment\nqual\n" there (FastqFile::write,
             // htsiter.cc:75-86), deflates and hands back finished blocks; two batches are in flight, so the kernels of
@@ -1044,6 +1201,12 @@ int main(int argc, char *argv[]) {
         }
     }
     clock.mark("pass4+format+deflate+write");
+    if (clock.on && dev_in.active) {
+        double inf = 0, idx = 0;
+        kbbq_fastq_reader_kernel_ms(dev_in.reader, &inf, &idx);
+        std::cerr << "[timing] FASTQ reader on the GPU (both scans): file reads " << dev_in.read_s << " s, device calls " << dev_in.device_s
+                  << " s; kernels: inflate " << inf << " ms, index + pack " << idx << " ms" << std::endl;
+    }
     if (clock.on && out_payload)
         std::cerr << "[timing] BGZF writer on the GPU: " << out_payload << " bytes -> " << out_compressed << " (ratio "
                   << (double)out_payload / (double)std::max<uint64_t>(1, out_compressed) << "); kernels: format " << ms_format
