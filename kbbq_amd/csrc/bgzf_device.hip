@@ -468,7 +468,7 @@ int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uin
         A.status = (uint32_t *)r->status.p;
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, r->device));
-        const unsigned grid = std::min<unsigned>(nb, (unsigned)std::max(1, prop.multiProcessorCount) * 4);      // 33 KB of LDS each: four per CU
+        const unsigned grid = std::min<unsigned>(nb, (unsigned)std::max(1, prop.multiProcessorCount) * 16);      // 9 KB of LDS each, five waves per SIMD by registers
         hipLaunchKernelGGL(k_inflate, dim3(grid), dim3(64 * INF_WAVES), 0, r->st, A);
         HIP_TRY(hipGetLastError());
     }
@@ -563,7 +563,7 @@ int kbbq_fastq_reader_batch(kbbq_fastq_reader *r, kbbq_reads *dev) {
     dev->n_bases = nbases;
     dev->on_device = 1;
     void *b = nullptr, *m = nullptr, *q = nullptr, *oc = nullptr, *off = nullptr, *fl = nullptr, *seq_text = nullptr, *cnt = nullptr;
-    auto release = [&]() { hipFree(b); hipFree(m); hipFree(q); hipFree(oc); hipFree(off); hipFree(fl); hipFree(seq_text); hipFree(cnt); };
+    auto release = [&]() { void *all[] = {b, m, q, oc, off, fl, seq_text, cnt}; for (void *x : all) (void)hipFree(x); };
 #define RB_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { release(); return fail(_e == hipErrorOutOfMemory ? KBBQ_ENOMEM : KBBQ_EIO, "%s: %s", #expr, hipGetErrorString(_e)); } } while (0)
     const uint64_t words = nbases / 64 + 1;
     RB_TRY(hipMalloc(&b, (2 * words + 2) * 8));
@@ -591,9 +591,9 @@ int kbbq_fastq_reader_batch(kbbq_fastq_reader *r, kbbq_reads *dev) {
     RB_TRY(hipMemcpyAsync(&n_off, cnt, 8, hipMemcpyDeviceToHost, r->st));
     RB_TRY(hipStreamSynchronize(r->st));
 #undef RB_TRY
-    hipFree(seq_text);
-    hipFree(cnt);
-    if (!n_off) { hipFree(oc); oc = nullptr; }
+    (void)hipFree(seq_text);
+    (void)hipFree(cnt);
+    if (!n_off) { (void)hipFree(oc); oc = nullptr; }
     dev->bases = (const uint64_t *)b;
     dev->nmask = (const uint64_t *)m;
     dev->qual = (const uint8_t *)q;

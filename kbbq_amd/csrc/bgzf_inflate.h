@@ -27,8 +27,10 @@
 namespace kbbq {
 namespace dfl {
 
-constexpr int INF_WINDOW = 32768;            // DEFLATE's window: the LDS ring of one wavefront
-constexpr int INF_FLUSH = 4096;              // bytes that leave the ring for HBM at a time
+constexpr int INF_RING = 8192;               // the recent output of one wavefront in LDS: matches that reach no further back are
+                                             // LDS-to-LDS copies; the rest of DEFLATE's 32 KB window is read back from HBM
+constexpr int INF_FLUSH = 256;               // bytes that leave the ring for HBM at a time: one aligned 256-byte line of the output
+constexpr int INF_NEAR = INF_RING - 512;     // a match at most this far back (plus its length) still lies in the ring
 constexpr int INF_WAVES = 1;                 // one wavefront per workgroup
 
 // status codes of a block
@@ -56,7 +58,7 @@ struct CodeRegs {
 };
 
 struct InflateLds {
-    alignas(16) uint8_t ring[INF_WINDOW];
+    alignas(16) uint8_t ring[INF_RING];
     uint8_t lens[320];           // code lengths of a dynamic block (literal/length then distance)
     uint16_t sorted[320];        // scratch of the table builder
 };
@@ -178,25 +180,29 @@ __global__ void __launch_bounds__(64 * INF_WAVES) k_inflate(InflateArgs A) {
         const uint64_t src_bits = (uint64_t)A.c_len[blk] * 8;
         uint8_t *dst = A.out + A.o_off[blk];
         const uint32_t want = A.o_len[blk];
-        const bool dst_aligned = ((uintptr_t)dst & 15) == 0;
+        // The ring holds the block's latest INF_RING bytes at the index (address in HBM) mod INF_RING, so that an aligned
+        // 256-byte line of the output is an aligned 256-byte piece of the ring: it leaves as 64 coalesced dword stores as
+        // soon as it is complete (the block's first and last lines, which it shares with its neighbours, byte by byte).
+        const uint32_t skew = (uint32_t)((uintptr_t)dst & (INF_RING - 1));
         BitReader B;
         B.init(src, lane);
         uint32_t pos = 0, flushed = 0;      // bytes produced / bytes that have left the ring
         uint32_t err = INF_OK;
-        // finished 4 KB pieces of the ring -> HBM
-        auto flush_to = [&](uint32_t upto) {
-            while (flushed + INF_FLUSH <= upto) {
-                const uint32_t r0 = flushed & (INF_WINDOW - 1);
-                if (dst_aligned) {
-#pragma unroll
-                    for (int it = 0; it < INF_FLUSH / 1024; ++it) {
-                        const uint32_t o = (uint32_t)it * 1024 + (uint32_t)lane * 16;
-                        *reinterpret_cast<uint4 *>(dst + flushed + o) = *reinterpret_cast<const uint4 *>(&S.ring[r0 + o]);
-                    }
+        auto ring_at = [&](uint32_t p) -> uint32_t { return (skew + p) & (INF_RING - 1); };
+        auto flush_to = [&](uint32_t upto, bool all) {
+            // whole lines [flushed, line end) while they are complete; `all`: also what is left at the block's end
+            for (;;) {
+                const uint32_t line_end = ((skew + flushed) | (INF_FLUSH - 1)) + 1 - skew;      // position behind the line that holds `flushed`
+                if (line_end > upto && !all) break;
+                const uint32_t end = line_end < upto ? line_end : upto;
+                if (end <= flushed) break;
+                const uint32_t r0 = ring_at(flushed);
+                if ((r0 & (INF_FLUSH - 1)) == 0 && end - flushed == INF_FLUSH) {
+                    *reinterpret_cast<uint32_t *>(dst + flushed + 4 * lane) = *reinterpret_cast<const uint32_t *>(&S.ring[r0 + 4 * lane]);
                 } else {
-                    for (uint32_t o = lane; o < INF_FLUSH; o += 64) dst[flushed + o] = S.ring[r0 + o];
+                    for (uint32_t o = flushed + lane; o < end; o += 64) dst[o] = S.ring[ring_at(o)];
                 }
-                flushed += INF_FLUSH;
+                flushed = end;
             }
         };
         bool last = false;
@@ -211,14 +217,15 @@ __global__ void __launch_bounds__(64 * INF_WAVES) k_inflate(InflateArgs A) {
                 if ((len ^ nlen) != 0xFFFFu) { err = INF_BAD_STORED; break; }
                 if (B.taken + (uint64_t)len * 8 > src_bits) { err = INF_OVERRUN_IN; break; }
                 if (pos + len > want) { err = INF_OVERRUN_OUT; break; }
-                // the reader is at a byte boundary: the bytes straight from the stream
+                // the reader is at a byte boundary: the bytes straight from the stream, through the ring (later matches may
+                // want them there)
                 const uint8_t *from = src + (B.taken >> 3);
                 for (uint32_t done = 0; done < len;) {
-                    const uint32_t n = min(len - done, (uint32_t)INF_FLUSH - ((pos + done) & (INF_FLUSH - 1)));
-                    for (uint32_t i = lane; i < n; i += 64) S.ring[(pos + done + i) & (INF_WINDOW - 1)] = from[done + i];
+                    const uint32_t n = min(len - done, (uint32_t)1024);
+                    for (uint32_t i = lane; i < n; i += 64) S.ring[ring_at(pos + done + i)] = from[done + i];
                     done += n;
                     __builtin_amdgcn_wave_barrier();
-                    flush_to(pos + done);
+                    flush_to(pos + done, false);
                 }
                 pos += len;
                 // re-aim the reader behind the stored bytes
@@ -243,9 +250,13 @@ __global__ void __launch_bounds__(64 * INF_WAVES) k_inflate(InflateArgs A) {
                 if (hlit > 286 || hdist > 30) { err = INF_BAD_LENGTHS; break; }
                 if (lane < N_CL) S.lens[lane] = 0;
                 __builtin_amdgcn_wave_barrier();
+                // the code-length code's own lengths arrive in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 (RFC 1951,
+                // 3.2.7), four bits of a constant per place
+                const uint64_t order_tail = 0xF1E2D3C4B5A69780ull;      // places 3..18: 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
                 for (int i = 0; i < hclen; ++i) {
                     const uint32_t v = B.get(3);
-                    if (lane == 0) S.lens[cl_order(i)] = (uint8_t)v;
+                    const uint32_t where = i < 3 ? 16u + (uint32_t)i : (uint32_t)((order_tail >> (4 * (i - 3))) & 15);
+                    if (lane == 0) S.lens[where] = (uint8_t)v;
                 }
                 __builtin_amdgcn_wave_barrier();
                 CodeRegs<1> CL;
@@ -290,9 +301,9 @@ __global__ void __launch_bounds__(64 * INF_WAVES) k_inflate(InflateArgs A) {
                 if (B.taken > src_bits) { err = INF_OVERRUN_IN; break; }
                 if (sym < 256) {
                     if (pos >= want) { err = INF_OVERRUN_OUT; break; }
-                    if (lane == 0) S.ring[pos & (INF_WINDOW - 1)] = (uint8_t)sym;
+                    if (lane == 0) S.ring[ring_at(pos)] = (uint8_t)sym;
                     ++pos;
-                    if ((pos & (INF_FLUSH - 1)) == 0) { __builtin_amdgcn_wave_barrier(); flush_to(pos); }
+                    if (((skew + pos) & (INF_FLUSH - 1)) == 0) { __builtin_amdgcn_wave_barrier(); flush_to(pos, false); }
                     continue;
                 }
                 if (sym == 256) break;
@@ -311,30 +322,34 @@ __global__ void __launch_bounds__(64 * INF_WAVES) k_inflate(InflateArgs A) {
                 else { const int de = (ds >> 1) - 1; dist = 1 + ((2 + (ds & 1)) << de) + (int)B.get(de); }
                 if ((uint32_t)dist > pos) { err = INF_BAD_DISTANCE; break; }
                 if (pos + (uint32_t)len > want) { err = INF_OVERRUN_OUT; break; }
-                // the copy: byte i of the match is byte (i mod dist) of the dist bytes before it -- every lane reads from
-                // that finished region, so the chunks of a long match do not depend on each other
+                // The copy: byte i of the match is byte (i mod dist) of the dist bytes before it -- every lane reads from
+                // that finished region, so the chunks of a long match do not depend on each other.  A source inside the ring
+                // is an LDS-to-LDS copy; a source further back has left the ring long ago (at least 7 KB of output lie between
+                // it and the flush frontier) and is read back from HBM, behind a wait for this wave's own stores.
                 __builtin_amdgcn_wave_barrier();
+                const bool far = dist > INF_NEAR;
+                if (far) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 for (int i0 = 0; i0 < len; i0 += 64) {
                     const int i = i0 + lane;
                     uint8_t v = 0;
                     if (i < len) {
                         const int k = dist >= len ? i : (dist == 1 ? 0 : i % dist);
-                        v = S.ring[(pos - (uint32_t)dist + (uint32_t)k) & (INF_WINDOW - 1)];
+                        const uint32_t from = pos - (uint32_t)dist + (uint32_t)k;
+                        v = far ? dst[from] : S.ring[ring_at(from)];
                     }
-                    __builtin_amdgcn_wave_barrier();      // (dist = 32768: the source byte sits where the copy goes)
-                    if (i < len) S.ring[(pos + (uint32_t)i) & (INF_WINDOW - 1)] = v;
+                    __builtin_amdgcn_wave_barrier();
+                    if (i < len) S.ring[ring_at(pos + (uint32_t)i)] = v;
                 }
                 __builtin_amdgcn_wave_barrier();
-                const uint32_t before = pos;
+                const uint32_t before = skew + pos;
                 pos += (uint32_t)len;
-                if ((before ^ pos) & ~(uint32_t)(INF_FLUSH - 1)) flush_to(pos);
+                if ((before ^ (skew + pos)) & ~(uint32_t)(INF_FLUSH - 1)) flush_to(pos, false);
             }
         }
         if (err == INF_OK && pos != want) err = INF_SIZE_MISMATCH;
         // what is left in the ring
         __builtin_amdgcn_wave_barrier();
-        if (err == INF_OK)
-            for (uint32_t o = flushed + lane; o < pos; o += 64) dst[o] = S.ring[o & (INF_WINDOW - 1)];
+        if (err == INF_OK) flush_to(pos, true);
         if (lane == 0) A.status[blk] = err;
         __builtin_amdgcn_wave_barrier();
     }

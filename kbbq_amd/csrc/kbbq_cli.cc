@@ -748,7 +748,9 @@ int main(int argc, char *argv[]) {
     // not take -- another container, records that are not four lines, read groups in the names, reads that do not fit in HBM
     // -- starts over with the host parsers below.  KBBQ_DEVICE_READER=0: the host parsers at once.
     DeviceFastqInput dev_in;
-    if (!is_bam && !fixed_mode && resident.on && filename != "-" && !(getenv("KBBQ_DEVICE_READER") && atoi(getenv("KBBQ_DEVICE_READER")) == 0) &&
+    // (KBBQ_HOST_DEFLATE=1, the zlib writer of rounds 1-2, goes with the host readers: the A/B of the whole host I/O path)
+    const bool host_io = getenv("KBBQ_HOST_DEFLATE") && atoi(getenv("KBBQ_HOST_DEFLATE")) != 0;
+    if (!is_bam && !fixed_mode && !host_io && resident.on && filename != "-" && !(getenv("KBBQ_DEVICE_READER") && atoi(getenv("KBBQ_DEVICE_READER")) == 0) &&
         !(getenv("KBBQ_SERIAL_PARSE") && atoi(getenv("KBBQ_SERIAL_PARSE"))) && dev_in.open(filename)) {
         bool ok = true;
         for (;;) {
