@@ -336,6 +336,38 @@ __global__ void k_fastq_sizes(const uint32_t *lens, uint64_t n, uint64_t *blob_s
     text_sz[r] = nl + cl + 2 * sl + 6;      // '@' '\n' '\n' '+' '\n' '\n'
 }
 
+// "@" name "\n" seq "\n+" comment "\n" qual "\n" of one record, written by one wavefront: lane l takes the bytes l, l + 64, ...;
+// four of them per round, their source bytes loaded before any is stored (the record's pieces are a few hundred bytes
+// spread over four places: what bounds this is the latency of those loads, so they travel together)
+__device__ __forceinline__ void emit_fastq_record(int lane, const uint8_t *name, uint32_t nl, const uint8_t *comment, uint32_t cl, const uint8_t *seq,
+                                                  uint32_t sl, const uint8_t *q, uint8_t *out) {
+    const uint32_t a_seq = 1 + nl + 1, a_plus = a_seq + sl, a_com = a_plus + 2, a_q = a_com + cl + 1, total = a_q + sl + 1;
+    for (uint32_t i0 = 0; i0 < total; i0 += 256) {
+        uint8_t c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + 64 * (uint32_t)u + (uint32_t)lane;
+            const uint8_t *sp = nullptr;
+            uint8_t k = '\n', add = 0;
+            if (i == 0) k = '@';
+            else if (i < 1 + nl) sp = name + (i - 1);
+            else if (i < a_seq) k = '\n';
+            else if (i < a_plus) sp = seq + (i - a_seq);
+            else if (i == a_plus) k = '\n';
+            else if (i == a_plus + 1) k = '+';
+            else if (i < a_com + cl) sp = comment + (i - a_com);
+            else if (i < a_q) k = '\n';
+            else if (i < a_q + sl) { sp = q + (i - a_q); add = 33; }
+            c[u] = (sp && i < total) ? (uint8_t)(*sp + add) : k;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + 64 * (uint32_t)u + (uint32_t)lane;
+            if (i < total) out[i] = c[u];
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_fastq_text(FastqArgs F) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * 4;
@@ -343,23 +375,7 @@ __global__ void __launch_bounds__(256) k_fastq_text(FastqArgs F) {
         const uint32_t nl = F.lens[3 * r], cl = F.lens[3 * r + 1], sl = F.lens[3 * r + 2];
         const uint8_t *name = F.blob + F.blob_off[r], *comment = name + nl, *seq = comment + cl;
         const uint8_t *q = F.qual + (F.qual_off ? F.qual_off[r] : r * (uint64_t)F.uniform_len);
-        uint8_t *out = F.text + F.text_off[r];
-        // "@" name "\n" seq "\n+" comment "\n" qual "\n"
-        const uint32_t a_seq = 1 + nl + 1, a_plus = a_seq + sl, a_com = a_plus + 2, a_q = a_com + cl + 1, total = a_q + sl + 1;
-        for (uint32_t i = lane; i < total; i += 64) {
-            uint8_t c;
-            if (i == 0) c = '@';
-            else if (i < 1 + nl) c = name[i - 1];
-            else if (i < a_seq) c = '\n';
-            else if (i < a_plus) c = seq[i - a_seq];
-            else if (i == a_plus) c = '\n';
-            else if (i == a_plus + 1) c = '+';
-            else if (i < a_com + cl) c = comment[i - a_com];
-            else if (i < a_q) c = '\n';
-            else if (i < a_q + sl) c = (uint8_t)(q[i - a_q] + 33);
-            else c = '\n';
-            out[i] = c;
-        }
+        emit_fastq_record(lane, name, nl, comment, cl, seq, sl, q, F.text + F.text_off[r]);
     }
 }
 

@@ -561,23 +561,7 @@ __global__ void __launch_bounds__(256) k_fastq_text_indexed(const uint8_t *text,
     for (uint64_t r = wave; r < n_records; r += n_waves) {
         const uint32_t nl = X.name_len[r], cl = X.com_len[r], sl = X.seq_len[r];
         const uint8_t *name = text + X.name_off[r], *comment = text + X.com_off[r], *seq = text + X.seq_off[r];
-        const uint8_t *q = new_qual + base_off[r];
-        uint8_t *o = out + text_off[r];
-        const uint32_t a_seq = 1 + nl + 1, a_plus = a_seq + sl, a_com = a_plus + 2, a_q = a_com + cl + 1, total = a_q + sl + 1;
-        for (uint32_t i = lane; i < total; i += 64) {
-            uint8_t c;
-            if (i == 0) c = '@';
-            else if (i < 1 + nl) c = name[i - 1];
-            else if (i < a_seq) c = '\n';
-            else if (i < a_plus) c = seq[i - a_seq];
-            else if (i == a_plus) c = '\n';
-            else if (i == a_plus + 1) c = '+';
-            else if (i < a_com + cl) c = comment[i - a_com];
-            else if (i < a_q) c = '\n';
-            else if (i < a_q + sl) c = (uint8_t)(q[i - a_q] + 33);
-            else c = '\n';
-            o[i] = c;
-        }
+        emit_fastq_record(lane, name, nl, comment, cl, seq, sl, new_qual + base_off[r], out + text_off[r]);
     }
 }
 

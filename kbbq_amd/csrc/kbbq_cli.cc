@@ -21,11 +21,13 @@
 //     kbbq.cc:218; missing RG / OQ tags, readutils.cc:20-30,42-53) this prints the same text and exits 1.
 #include <fcntl.h>
 #include <getopt.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -33,6 +35,7 @@
 #include <iomanip>
 #include <iostream>
 #include <memory>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -166,6 +169,8 @@ struct PhaseClock {
         if (!on) return;
         std::cerr << "[timing]";
         for (auto &p : phases) std::cerr << " " << p.first << " " << p.second << " s";
+        struct rusage ru;
+        if (getrusage(RUSAGE_SELF, &ru) == 0) std::cerr << " peak_host_rss_MB " << ru.ru_maxrss / 1024;
         std::cerr << std::endl;
     }
 };
@@ -283,12 +288,11 @@ private:
 // take is reported by the reader and the caller starts over with the host parsers.
 class DeviceFastqInput {
 public:
-    struct Chunk { uint64_t start, given; int last; uint64_t n_records; };
     ~DeviceFastqInput() { close(); }
     bool active = false;
-    std::vector<Chunk> chunks;
+    std::vector<uint64_t> chunk_records;      // records of every chunk of the first scan (pass 4 must meet the same)
     kbbq_fastq_reader *reader = nullptr;
-    double read_s = 0, device_s = 0;
+    double wait_s = 0, device_s = 0;
 
     bool open(const std::string &path) {
         fd_ = ::open(path.c_str(), O_RDONLY);
@@ -298,63 +302,115 @@ public:
         size_ = (uint64_t)st.st_size;
         unsigned char magic[4] = {0, 0, 0, 0};
         if (pread(fd_, magic, 4, 0) != 4 || magic[0] != 0x1f || magic[1] != 0x8b || magic[2] != 8 || !(magic[3] & 4)) return false;      // not BGZF
-        void *p = nullptr;
-        if (kbbq_host_alloc(kChunk, &p) < 0) return false;
-        buf_ = (uint8_t *)p;
-        return kbbq_fastq_reader_create(0, &reader) >= 0;
+        for (int i = 0; i < 2; ++i) {
+            void *p = nullptr;
+            if (kbbq_host_alloc(kFront + kPiece, &p) < 0) return false;
+            buf_[i] = (uint8_t *)p;
+        }
+        if (kbbq_fastq_reader_create(0, &reader) < 0) return false;
+        start_pass();
+        return true;
     }
     void close() {
+        stop_io();
         if (reader) kbbq_fastq_reader_destroy(reader);
         reader = nullptr;
-        if (buf_) kbbq_host_free(buf_);
-        buf_ = nullptr;
+        for (int i = 0; i < 2; ++i) { if (buf_[i]) kbbq_host_free(buf_[i]); buf_[i] = nullptr; }
         if (fd_ >= 0) ::close(fd_);
         fd_ = -1;
     }
-    // the bytes [start, start + n) of the file in the page-locked buffer
-    bool load(uint64_t start, uint64_t n) {
-        const auto t0 = std::chrono::steady_clock::now();
-        uint64_t got = 0;
-        while (got < n) {
-            const ssize_t k = pread(fd_, buf_ + got, n - got, (off_t)(start + got));
-            if (k <= 0) return false;
-            got += (uint64_t)k;
-        }
-        read_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        return true;
+    // The file is read front to back in pieces of 256 MB by a thread of its own, into two page-locked buffers in turn; the
+    // bytes the device did not take from one piece (the last, incomplete BGZF block: less than 64 KB) go in front of the
+    // next one.  The same sequence of chunks comes out of every pass.
+    void start_pass() {
+        stop_io();
+        next_piece_ = 0;
+        taken_piece_ = 0;
+        left_ = 0;
+        io_error_ = false;
+        quit_ = false;
+        filled_[0] = filled_[1] = false;
+        io_ = std::thread([this] {
+            for (uint64_t k = 0;; ++k) {
+                const uint64_t at = k * kPiece;
+                if (at >= size_) break;
+                const int b = (int)(k & 1);
+                {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_.wait(lk, [&] { return quit_ || !filled_[b]; });
+                    if (quit_) return;
+                }
+                const uint64_t n = std::min<uint64_t>(kPiece, size_ - at);
+                uint64_t got = 0;
+                bool ok = true;
+                while (got < n) {
+                    const ssize_t r = pread(fd_, buf_[b] + kFront + got, n - got, (off_t)(at + got));
+                    if (r <= 0) { ok = false; break; }
+                    got += (uint64_t)r;
+                }
+                {
+                    std::lock_guard<std::mutex> lk(mu_);
+                    if (!ok) io_error_ = true;
+                    filled_[b] = true;
+                    piece_bytes_[b] = n;
+                }
+                cv_.notify_all();
+                if (!ok) return;
+            }
+        });
     }
-    // first scan: 1 = the next chunk is in `info` (and its records, if any, are the reader's current chunk), 0 = end of file,
-    // -1 = I/O or device error, -2 = a shape for the host parsers
+    // 1 = the next chunk is in `info` (its records, if any, are the reader's current chunk), 0 = end of file, -1 = I/O or device
+    // error, -2 = a shape for the host parsers
     int next_chunk(kbbq_fastq_chunk &info) {
-        if (at_ >= size_) return 0;
-        const uint64_t n = std::min<uint64_t>(kChunk, size_ - at_);
-        const int last = at_ + n == size_;
-        if (!load(at_, n)) return -1;
+        const uint64_t at = taken_piece_ * kPiece;
+        if (at >= size_) return 0;
+        const int b = (int)(taken_piece_ & 1);
         const auto t0 = std::chrono::steady_clock::now();
-        if (kbbq_fastq_reader_chunk(reader, buf_, n, last, &info) < 0) return -1;
-        device_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return filled_[b] || io_error_; });
+            if (io_error_) return -1;
+        }
+        wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const uint64_t n = piece_bytes_[b];
+        const int last = at + n >= size_;
+        uint8_t *data = buf_[b] + kFront - left_;
+        if (left_) memcpy(data, carry_, left_);
+        const auto t1 = std::chrono::steady_clock::now();
+        if (kbbq_fastq_reader_chunk(reader, data, left_ + n, last, &info) < 0) return -1;
+        device_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
         if (info.flags & 7) return -2;      // (a read name that is too short included: the host path reports it)
-        if (info.consumed == 0 && !last) return -2;      // a BGZF block larger than the chunk: not a file this path reads
-        chunks.push_back(Chunk{at_, n, last, info.n_records});
-        at_ += last ? n : info.consumed;
+        const uint64_t rest = left_ + n - info.consumed;
+        if (rest > kFront || (rest && last)) return -2;      // a block that does not end: not a file this path reads
+        if (rest) memcpy(carry_, data + info.consumed, rest);
+        left_ = rest;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            filled_[b] = false;
+        }
+        cv_.notify_all();
+        ++taken_piece_;
         return 1;
-    }
-    // pass 4: chunk i again (same bytes, same records)
-    bool replay(size_t i, kbbq_fastq_chunk &info) {
-        const Chunk &c = chunks[i];
-        if (i == 0 && kbbq_fastq_reader_rewind(reader) < 0) return false;
-        if (!load(c.start, c.given)) return false;
-        const auto t0 = std::chrono::steady_clock::now();
-        if (kbbq_fastq_reader_chunk(reader, buf_, c.given, c.last, &info) < 0) return false;
-        device_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        return info.n_records == c.n_records && !(info.flags & 7);
     }
 
 private:
-    static constexpr uint64_t kChunk = 256ull << 20;
+    void stop_io() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        if (io_.joinable()) io_.join();
+    }
+    static constexpr uint64_t kPiece = 256ull << 20, kFront = 1ull << 16;
     int fd_ = -1;
-    uint64_t size_ = 0, at_ = 0;
-    uint8_t *buf_ = nullptr;
+    uint64_t size_ = 0, next_piece_ = 0, taken_piece_ = 0, left_ = 0, piece_bytes_[2] = {0, 0};
+    uint8_t *buf_[2] = {nullptr, nullptr};
+    uint8_t carry_[1 << 16];
+    std::thread io_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool filled_[2] = {false, false}, io_error_ = false, quit_ = false;
 };
 
 // What the output pass needs of one batch besides the new qualities, kept from the first scan when it fits in
@@ -758,6 +814,7 @@ int main(int argc, char *argv[]) {
             const int rc = dev_in.next_chunk(info);
             if (rc == 0) break;
             if (rc < 0) { ok = false; break; }
+            dev_in.chunk_records.push_back(info.n_records);
             if (!info.n_records) continue;
             const uint64_t need = info.n_bases * 13 / 8 + info.n_records * 16 + (1 << 16);
             kbbq_reads d;
@@ -1096,9 +1153,11 @@ int main(int argc, char *argv[]) {
             size_t d_q_bytes[2] = {0, 0};
             struct FreeQ { kbbq_engine *e; void **p; ~FreeQ() { for (int i = 0; i < 2; ++i) if (p[i]) kbbq_device_free(e, p[i]); } } free_q{e, d_q};
             size_t bi = 0;
-            for (size_t ci = 0; ci < dev_in.chunks.size(); ++ci) {
+            dev_in.start_pass();
+            if (kbbq_fastq_reader_rewind(dev_in.reader) < 0) return fail_engine("recalibrating");
+            for (size_t ci = 0; ci < dev_in.chunk_records.size(); ++ci) {
                 kbbq_fastq_chunk info;
-                if (!dev_in.replay(ci, info)) {
+                if (dev_in.next_chunk(info) != 1 || info.n_records != dev_in.chunk_records[ci]) {
                     std::cerr << put_now << " Error: the input changed between the passes." << std::endl;
                     return 1;
                 }
@@ -1206,7 +1265,7 @@ int main(int argc, char *argv[]) {
     if (clock.on && dev_in.active) {
         double inf = 0, idx = 0;
         kbbq_fastq_reader_kernel_ms(dev_in.reader, &inf, &idx);
-        std::cerr << "[timing] FASTQ reader on the GPU (both scans): file reads " << dev_in.read_s << " s, device calls " << dev_in.device_s
+        std::cerr << "[timing] FASTQ reader on the GPU (both scans): waiting for file reads " << dev_in.wait_s << " s, device calls " << dev_in.device_s
                   << " s; kernels: inflate " << inf << " ms, index + pack " << idx << " ms" << std::endl;
     }
     if (clock.on && out_payload)

@@ -1,0 +1,25 @@
+#!/bin/bash
+# tools/r03_e2e_big.sh [TAG] -- the command line at 3e10 bases (BASELINE configs[1] at one third): the 3e9-base BGZF FASTQ of
+# tools/r03_e2e.sh ten times over (BGZF files concatenate), -g 1000000000; per-phase split, peak host RSS, device budgets.
+set -o pipefail
+tag=${1:-a}
+D=${TMPDIR:-/tmp}/kbbq_e2e_big
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+L=$R/gpurun_out/r03_e2e_big_$tag.log
+mkdir -p $D $R/gpurun_out
+: > $L
+df -h $D | tail -1 >> $L
+python tools/make_fastq.py $D/part.fq 100000000 30 >> $L 2>&1 || exit 1
+$R/kbbq_amd/kbbq --io-test bgzf 16 < $D/part.fq > $D/part.fq.gz || exit 1
+rm -f $D/part.fq
+for i in 0 1 2 3 4 5 6 7 8 9; do cat $D/part.fq.gz; done > $D/big.fq.gz
+ls -l $D/part.fq.gz $D/big.fq.gz >> $L
+echo "files ready"
+for name in first second; do
+    s=$(date +%s%N)
+    KBBQ_TIMING=1 KBBQ_SEED=777 $R/kbbq_amd/kbbq -g 1000000000 $D/big.fq.gz 2> $D/err_$name.txt | wc -c > $D/out_$name.bytes || { echo "$name failed"; tail -3 $D/err_$name.txt; exit 1; }
+    e=$(date +%s%N)
+    echo "$name wall_ms $(( (e - s) / 1000000 )) $(grep timing $D/err_$name.txt | tr '\n' ' ') out_bytes $(cat $D/out_$name.bytes)" | tee -a $L
+    grep -i "resident\|batches" $D/err_$name.txt | head -3 >> $L
+done
+rm -rf $D
