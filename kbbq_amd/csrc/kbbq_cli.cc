@@ -218,6 +218,16 @@ public:
         ++in_flight_;
         return true;
     }
+    // Bytes the caller has formatted itself in page-locked memory (a whole batch of BAM records): submitted as they are
+    // (the caller's buffer is free again on return); what write() gathered before them goes first.
+    bool submit_buffer(const char *pinned, size_t n) {
+        if (!flush_host()) return false;
+        if (!n) return true;
+        if (!make_room()) return false;
+        if (kbbq_bgzf_submit(z_, pinned, n, 0, nullptr) < 0) return fail_here();
+        ++in_flight_;
+        return true;
+    }
     // The current chunk of a device reader with new qualities (kbbq_fastq_reader_write): text assembled from the device's
     // own copy of the input.
     bool reader_chunk(kbbq_fastq_reader *reader, const uint8_t *d_qual, void *after_stream) {
@@ -1200,6 +1210,91 @@ int main(int argc, char *argv[]) {
                 if (!dev_out->fastq_batch(st.blob.data(), st.lens.data(), d.n_reads, (const uint8_t *)d_q[t], d.offsets, d.read_len,
                                           kbbq_engine_stream(e)))
                     return 1;
+            }
+            if (!dev_out->drain()) return 1;
+        } else if (resident.on && resident.keep_recs && is_bam && dev_out) {
+            // BAM, every batch in HBM, its alignment blocks in host memory: BamFile::recalibrate + write (htsiter.cc:11-45) for a
+            // whole batch by a pool -- every thread rewrites a run of records (OQ tag, qualities, reversed for reverse-strand
+            // reads) into a buffer of its own, the runs are copied side by side into one page-locked buffer, and the
+            // encoder on the GPU takes it from there.
+            const unsigned T = (unsigned)std::max(1, out_threads);
+            std::vector<std::string> part(T);
+            std::vector<int> part_rc(T, 0);
+            char *pin = nullptr;
+            size_t pin_bytes = 0;
+            struct FreePin { char **p; ~FreePin() { if (*p) kbbq_host_free(*p); } } free_pin{&pin};
+            for (size_t bi = 0; bi < resident.dev.size(); ++bi) {
+                const kbbq_reads &d = resident.dev[bi];
+                const RecordStore &st = resident.recs[bi];
+                newq.assign(d.n_bases + 16, 0);
+                if (kbbq_recalibrate_batch_host(e, &d, newq.data()) < 0) return fail_engine("recalibrating");
+                // where every record's block and qualities start
+                std::vector<uint64_t> rec_at(d.n_reads + 1), q_at(d.n_reads + 1);
+                {
+                    uint64_t at = 0, qa = 0;
+                    for (size_t r = 0; r < d.n_reads; ++r) {
+                        rec_at[r] = at; q_at[r] = qa;
+                        at += st.lens[r];
+                        const uint8_t *rec = (const uint8_t *)st.blob.data() + rec_at[r];
+                        qa += (uint64_t)rec[16] | ((uint64_t)rec[17] << 8) | ((uint64_t)rec[18] << 16) | ((uint64_t)rec[19] << 24);      // l_seq
+                    }
+                    rec_at[d.n_reads] = at; q_at[d.n_reads] = qa;
+                }
+                std::vector<std::thread> pool;
+                for (unsigned t = 0; t < T; ++t) {
+                    pool.emplace_back([&, t] {
+                        const size_t r0 = d.n_reads * t / T, r1 = d.n_reads * (t + 1) / T;
+                        std::string &out_s = part[t];
+                        out_s.clear();
+                        out_s.reserve((size_t)(rec_at[r1] - rec_at[r0]) + (r1 - r0) * (set_oq ? 8 : 4) + (set_oq ? (size_t)(q_at[r1] - q_at[r0]) : 0));
+                        BamRecord b;
+                        std::string qtext_t;
+                        for (size_t r = r0; r < r1; ++r) {
+                            b.data.assign((const uint8_t *)st.blob.data() + rec_at[r], (const uint8_t *)st.blob.data() + rec_at[r + 1]);
+                            const size_t len = b.l_seq();
+                            const uint8_t *q = newq.data() + q_at[r];
+                            if (set_oq) {
+                                qtext_t.resize(len);
+                                for (size_t i = 0; i < len; ++i) qtext_t[i] = (char)(b.qual()[i] + 33);
+                                int status = 0;
+                                if (!b.aux_update_string("OQ", qtext_t, status)) { part_rc[t] = -1; return; }
+                            }
+                            if (b.reverse()) std::reverse_copy(q, q + len, b.qual());
+                            else std::copy(q, q + len, b.qual());
+                            const uint32_t n = (uint32_t)b.data.size();
+                            const char len4[4] = {(char)(n & 0xFF), (char)((n >> 8) & 0xFF), (char)((n >> 16) & 0xFF), (char)((n >> 24) & 0xFF)};
+                            out_s.append(len4, 4);
+                            out_s.append((const char *)b.data.data(), b.data.size());
+                        }
+                    });
+                }
+                for (auto &th : pool) th.join();
+                size_t total = 0;
+                for (unsigned t = 0; t < T; ++t) {
+                    if (part_rc[t] < 0) {
+                        std::cerr << "Tag data is corrupt. Repair the tags and try again." << std::endl;
+                        return 1;      // std::invalid_argument("Unable to update OQ tag.") in the reference
+                    }
+                    total += part[t].size();
+                }
+                if (pin_bytes < total) {
+                    if (pin) kbbq_host_free(pin);
+                    pin = nullptr;
+                    pin_bytes = total + total / 8 + 4096;
+                    void *p = nullptr;
+                    if (kbbq_host_alloc(pin_bytes, &p) < 0) return fail_engine("recalibrating");
+                    pin = (char *)p;
+                }
+                {
+                    std::vector<std::thread> copiers;
+                    size_t at = 0;
+                    for (unsigned t = 0; t < T; ++t) {
+                        copiers.emplace_back([&, t, at] { memcpy(pin + at, part[t].data(), part[t].size()); });
+                        at += part[t].size();
+                    }
+                    for (auto &th : copiers) th.join();
+                }
+                if (!dev_out->submit_buffer(pin, total)) return 1;
             }
             if (!dev_out->drain()) return 1;
         } else if (resident.on && resident.keep_recs) {

@@ -125,6 +125,21 @@ def make_wide_quality_dataset(seed=40, **kw):
     return d
 
 
+def make_high_quality_dataset(seed=94, share=0.4, **kw):
+    """Qualities above KBBQ_MAXQ = 93 (a BAM can hold up to 255; 0xFF is what "missing" looks like): a share of the best
+    bases gets 94, 95, 120, 200, 254 or 255.  The reference's tables grow with the largest quality seen
+    (covariateutils.cc:65-76,102-116,147-164): those bases are tallied, modelled in rows of their own and only clamped on
+    output (readutils.cc:592-594)."""
+    d = make_dataset(seed=seed, **kw)
+    rng = np.random.RandomState(seed)
+    q = d["qual"].copy()
+    best = np.nonzero(q == q.max())[0]
+    at = rng.choice(best, size=int(len(best) * share), replace=False)
+    q[at] = rng.choice([94, 95, 120, 200, 254, 255], size=len(at)).astype(np.uint8)
+    d["qual"] = np.ascontiguousarray(q)
+    return d
+
+
 def make_softmasked_dataset(seed=707, frac=0.04, stretches=120, digits=30, **kw):
     """Soft-masked FASTQ text: scattered lower-case bases, whole lower-case stretches (masked repeats), and a few of
     the digits '0'..'3' that seq_nt16_table also folds to bases.  K-mers and covariates fold case, but the reference
@@ -193,6 +208,9 @@ PARITY_CASES = {
                                                                       extra_errors=80, clusters=40), dict(k=25), dict(uniform=True, n_batches=3)),
     "reads_400": (make_dataset, dict(seed=400, genome_len=20000, coverage=20, read_len=400, n_per_million=500,
                                      extra_errors=60), dict(), dict(uniform=True)),
+    # qualities above 93 (BAM-only values): 256 quality rows in every table, as the reference's growing tables
+    "high_qualities_2rg": (make_high_quality_dataset, dict(genome_len=20000, coverage=24, n_rg=2, paired=True, extra_errors=60), dict(n_rg=2),
+                           dict(uniform=False, n_batches=2)),
 }
 
 
