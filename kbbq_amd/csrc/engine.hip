@@ -1747,10 +1747,12 @@ static int launch_correct(kbbq_engine *e, ReadsDev R, const uint32_t *list, cons
 template <int NB, int NN>
 static int launch_correct_wave(kbbq_engine *e, ReadsDev R, const uint32_t *list, const uint64_t *tmask, int tw,
                                uint32_t *err_bits, uint32_t *patch) {
+    unsigned int *ticket = e->d_tickets + 3 + (e->cur_cnt != e->d_counters ? 1 : 0);      // per side of pass 3
+    HIP_TRY(hipMemsetAsync(ticket, 0, 4, e->cur));
     Timed t(e, "k_correct_wave", e->cur);
     const int blocks = (int)std::min<uint64_t>((R.n_reads + 3) / 4, 256 * 16);
     hipLaunchKernelGGL((k_correct_wave<NB, NN>), dim3(blocks), dim3(256), 0, e->cur, R, e->K, e->filt[1].dev(), list,
-                       (const unsigned long long *)e->cur_cnt, tmask, tw, err_bits, patch, e->cur_cnt);
+                       (const unsigned long long *)e->cur_cnt, tmask, tw, err_bits, patch, e->cur_cnt, ticket);
     HIP_TRY(hipGetLastError());
     return KBBQ_OK;
 }

@@ -691,16 +691,16 @@ template <int NB, int NN>
 __global__ void __launch_bounds__(256, 5) k_correct_wave(ReadsDev R, KParams K, FiltDev T, const uint32_t *list,
                                                        const unsigned long long *n_list, const uint64_t *tmask,
                                                        int tmask_words, uint32_t *err_bits, uint32_t *patch,
-                                                       unsigned long long *stats) {
+                                                       unsigned long long *stats, unsigned int *ticket) {
     typedef WaveCorrector<NB, NN> C;
     __shared__ uint64_t lds_words[4 * C::WORDS];
     const int lane = threadIdx.x & 63;
-    // wave-uniform by construction: lets the compiler keep the read's words and the walk in SGPRs
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t n = *n_list;
     unsigned long long q_total = 0;
-    for (uint64_t slot = wave; slot < n; slot += n_waves) {
+    // the work list goes out in chunks of four entries from a global counter (device_common.h: ReadChunks): a walk costs
+    // anything from a dozen to a few thousand lookups, and an even split leaves the last round of workgroups half empty
+    ReadChunks<4> Q;
+    for (uint64_t slot = Q.begin(ticket, n, lane); slot < n; Q.advance(lane), slot = Q.cur) {
         const uint64_t r = C::uni((uint64_t)list[slot]);
         uint64_t off; uint32_t len32;
         read_span(R, r, off, len32);
