@@ -29,7 +29,10 @@ def test_bench_prints_one_contract_line():
     assert abs(d["value"] - bases / (d["ms_per_step"] / 1e3) / 1e9) < 1e-3 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert not d["kernels"][r["kernel"]].get("overlapped")          # an exclusive duration
+    # an exclusive duration: the kernel's own launches of the untimed in-order step, not the time it shared the chip
+    dom = d["kernels"][r["kernel"]]
+    assert r["duration_measured_in"].startswith("exclusive") and r["avg_launch_ms"] == dom["exclusive_avg_ms"]
+    assert r["timed_region_avg_launch_ms"] == dom["avg_ms"]
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] / 1e3) / 1e9) < 0.01 * r["achieved"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Gbases/s" and c["value"] > 0 and "sample" in c
