@@ -605,9 +605,12 @@ def main():
         from kbbq_amd import _lib as _l
         _l.check(e.L.kbbq_engine_tune(e.h, b"no_overlap", 1))
         e.profile_reset()
+        xch_ms_timed = dict(xch.ms)
         run_step(e, xch, batches, ordinals, out_buf, hints)
         barrier()
         prof_excl = e.profile()
+        xch.ms.clear()
+        xch.ms.update(xch_ms_timed)      # the exchange times quoted are the timed region's alone
         _l.check(e.L.kbbq_engine_tune(e.h, b"no_overlap", 0))
     # untimed: digest of the recalibrated qualities (rank-count invariant)
     digest = 0
