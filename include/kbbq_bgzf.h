@@ -85,6 +85,17 @@ int kbbq_fastq_reader_create(int32_t device, kbbq_fastq_reader **out);
 void kbbq_fastq_reader_destroy(kbbq_fastq_reader *r);
 /* Restart at the beginning of a file (pass 4 feeds the same chunks again). */
 int kbbq_fastq_reader_rewind(kbbq_fastq_reader *r);
+/* Keep what the first scan inflates: with on != 0 (before the scan's first chunk) the text and record index of every chunk
+ * with records stay in device memory, so that pass 4 selects them (kbbq_fastq_reader_select) instead of reading and
+ * inflating the file a second time -- the reference reads its input once per pass (htsiter.cc:49-60); here the second
+ * reading costs nothing while the text fits in HBM (about 2.3 bytes per base).  A chunk whose buffers can no longer be
+ * allocated releases everything kept (kbbq_fastq_reader_kept then reports 0 chunks) and the scan goes on; on == 0 does
+ * the same on the caller's word (its own budget is used up).  kept: chunks and bytes held now. */
+int kbbq_fastq_reader_keep(kbbq_fastq_reader *r, int32_t on);
+int kbbq_fastq_reader_kept(kbbq_fastq_reader *r, uint64_t *n_chunks, uint64_t *n_bytes);
+/* Kept chunk i (in the order of the first scan, chunks without records not counted) becomes the current chunk for
+ * kbbq_fastq_reader_write; info (may be NULL) gets its counts. */
+int kbbq_fastq_reader_select(kbbq_fastq_reader *r, uint64_t i, kbbq_fastq_chunk *info);
 /* The next bytes of the file (host memory; page-locked memory is copied by DMA).  last != 0: nothing follows. */
 int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uint64_t n_bytes, int32_t last, kbbq_fastq_chunk *info);
 /* The current chunk's records as a device batch (arrays owned by the library: kbbq_reads_free): bases, N mask, qualities,

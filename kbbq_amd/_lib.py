@@ -159,6 +159,9 @@ SYMBOLS = {
     "kbbq_fastq_reader_chunk": (ctypes.c_int, [c_vp, c_vp, c_u64, ctypes.c_int32, ctypes.POINTER(FastqChunk)]),
     "kbbq_fastq_reader_batch": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads)]),
     "kbbq_fastq_reader_write": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "kbbq_fastq_reader_keep": (ctypes.c_int, [c_vp, ctypes.c_int32]),
+    "kbbq_fastq_reader_kept": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    "kbbq_fastq_reader_select": (ctypes.c_int, [c_vp, ctypes.c_uint64, ctypes.c_void_p]),
     "kbbq_fastq_reader_kernel_ms": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }
 

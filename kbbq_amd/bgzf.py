@@ -99,3 +99,21 @@ class FastqReader:
 
     def write(self, writer, d_qual, after_stream=None):
         _lib.check(self.L.kbbq_fastq_reader_write(self.h, writer.h, d_qual, after_stream))
+
+    def kernel_ms(self):
+        a, b = ctypes.c_double(), ctypes.c_double()
+        _lib.check(self.L.kbbq_fastq_reader_kernel_ms(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return dict(inflate=a.value, index=b.value)
+
+    def keep(self, on=True):
+        _lib.check(self.L.kbbq_fastq_reader_keep(self.h, 1 if on else 0))
+
+    def kept(self):
+        n, b = ctypes.c_uint64(), ctypes.c_uint64()
+        _lib.check(self.L.kbbq_fastq_reader_kept(self.h, ctypes.byref(n), ctypes.byref(b)))
+        return n.value, b.value
+
+    def select(self, i):
+        info = _lib.FastqChunk()
+        _lib.check(self.L.kbbq_fastq_reader_select(self.h, i, ctypes.byref(info)))
+        return {k: getattr(info, k) for k, _ in _lib.FastqChunk._fields_}

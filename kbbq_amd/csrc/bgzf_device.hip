@@ -31,10 +31,11 @@ struct Buf {
     void *p = nullptr;
     size_t bytes = 0;
     bool host = false;
+    bool exact = false;      // no room to grow into: the buffer is filled once and kept
     int reserve(size_t need) {
         if (bytes >= need) return KBBQ_OK;
         if (p) { if (host) (void)hipHostFree(p); else (void)hipFree(p); p = nullptr; bytes = 0; }
-        const size_t want = need + need / 8 + 4096;
+        const size_t want = exact ? need : need + need / 8 + 4096;
         HIP_TRY(host ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want));
         bytes = want;
         return KBBQ_OK;
@@ -315,9 +316,20 @@ struct kbbq_fastq_reader {
     uint64_t carry_bytes = 0;
     // the current chunk
     uint64_t text_bytes = 0, n_records = 0, n_bases = 0;
+    uint64_t out_text_bytes = 0;            // bytes of the chunk's records written out as FASTQ text
     uint32_t longest = 0, shortest = 0;
     bool have_chunk = false;
     double ms_inflate = 0, ms_index = 0;
+    // chunks of the first scan that stay in device memory (kbbq_fastq_reader_keep): their text and record index
+    struct Kept {
+        Buf text, idx_u32, base_sz, text_sz;
+        uint64_t text_bytes = 0, n_records = 0, n_bases = 0, out_text_bytes = 0;
+        uint32_t longest = 0, shortest = 0;
+    };
+    std::vector<Kept> kept;
+    bool keeping = false;
+    int64_t selected = -1;      // the kept chunk that is the current one (pass 4), or -1: the live buffers
+    uint64_t kept_bytes = 0;
 };
 
 namespace {
@@ -334,16 +346,41 @@ int device_scan(kbbq_fastq_reader *r, uint64_t *d, uint64_t n, uint64_t *d_total
     return KBBQ_OK;
 }
 
-FastqIndex index_of(kbbq_fastq_reader *r, uint64_t cap) {
+FastqIndex index_from(void *idx_u32, void *second, void *base_sz, void *text_sz, void *flags, uint64_t cap) {
     FastqIndex X;
-    uint32_t *u = (uint32_t *)r->idx_u32.p;
+    uint32_t *u = (uint32_t *)idx_u32;
     X.name_off = u; X.name_len = u + cap; X.com_off = u + 2 * cap; X.com_len = u + 3 * cap;
     X.seq_off = u + 4 * cap; X.seq_len = u + 5 * cap; X.qual_off = u + 6 * cap;
-    X.second = (uint8_t *)r->idx_second.p;
-    X.base_sz = (uint64_t *)r->base_sz.p;
-    X.text_sz = (uint64_t *)r->text_sz.p;
-    X.flags = (uint32_t *)r->flags.p;
+    X.second = (uint8_t *)second;
+    X.base_sz = (uint64_t *)base_sz;
+    X.text_sz = (uint64_t *)text_sz;
+    X.flags = (uint32_t *)flags;
     return X;
+}
+FastqIndex index_of(kbbq_fastq_reader *r, uint64_t cap) {
+    return index_from(r->idx_u32.p, r->idx_second.p, r->base_sz.p, r->text_sz.p, r->flags.p, cap);
+}
+
+void release_kept(kbbq_fastq_reader *r) {
+    for (auto &k : r->kept) { k.text.release(); k.idx_u32.release(); k.base_sz.release(); k.text_sz.release(); }
+    r->kept.clear();
+    r->kept_bytes = 0;
+    r->selected = -1;
+}
+
+// The live chunk moves into the kept list (its buffers with it: the next chunk allocates its own).
+void stash_current(kbbq_fastq_reader *r) {
+    if (!r->keeping || r->selected >= 0 || !r->have_chunk || !r->n_records) return;
+    kbbq_fastq_reader::Kept k;
+    k.text = r->text; k.idx_u32 = r->idx_u32; k.base_sz = r->base_sz; k.text_sz = r->text_sz;
+    r->text = Buf(); r->idx_u32 = Buf(); r->base_sz = Buf(); r->text_sz = Buf();
+    r->text.exact = r->idx_u32.exact = r->base_sz.exact = r->text_sz.exact = true;
+    k.text_bytes = r->text_bytes; k.n_records = r->n_records; k.n_bases = r->n_bases;
+    k.longest = r->longest; k.shortest = r->shortest;
+    k.out_text_bytes = r->out_text_bytes;
+    r->kept_bytes += k.text.bytes + k.idx_u32.bytes + k.base_sz.bytes + k.text_sz.bytes;
+    r->kept.push_back(k);
+    r->have_chunk = false;
 }
 
 }  // namespace
@@ -379,6 +416,7 @@ void kbbq_fastq_reader_destroy(kbbq_fastq_reader *r) {
     Buf *all[] = {&r->comp, &r->text, &r->status, &r->blk_meta, &r->h_meta, &r->tile_counts, &r->tile_sums, &r->nl_pos, &r->idx_u32,
                   &r->idx_second, &r->base_sz, &r->text_sz, &r->flags, &r->carry, &r->h_small};
     for (Buf *b : all) b->release();
+    release_kept(r);
     hipEvent_t evs[] = {r->t0, r->t1, r->t2};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     if (r->st) (void)hipStreamDestroy(r->st);
@@ -387,8 +425,54 @@ void kbbq_fastq_reader_destroy(kbbq_fastq_reader *r) {
 
 int kbbq_fastq_reader_rewind(kbbq_fastq_reader *r) {
     if (!r) return fail(KBBQ_EINVAL, "null argument");
+    stash_current(r);
+    r->keeping = false;      // what was kept stays; a second scan keeps nothing more
+    r->selected = -1;
     r->carry_bytes = 0;
     r->have_chunk = false;
+    return KBBQ_OK;
+}
+
+int kbbq_fastq_reader_keep(kbbq_fastq_reader *r, int32_t on) {
+    if (!r) return fail(KBBQ_EINVAL, "null argument");
+    KbbqDeviceGuard guard(r->device);
+    HIP_TRY(guard.err);
+    if (on) {
+        if (r->have_chunk || !r->kept.empty()) return fail(KBBQ_ESTATE, "keeping starts before the first chunk of a scan");
+        r->keeping = true;
+        r->text.exact = r->idx_u32.exact = r->base_sz.exact = r->text_sz.exact = true;
+    } else {
+        HIP_TRY(hipStreamSynchronize(r->st));
+        release_kept(r);
+        r->keeping = false;
+        r->text.exact = r->idx_u32.exact = r->base_sz.exact = r->text_sz.exact = false;
+    }
+    return KBBQ_OK;
+}
+
+int kbbq_fastq_reader_kept(kbbq_fastq_reader *r, uint64_t *n_chunks, uint64_t *n_bytes) {
+    if (!r) return fail(KBBQ_EINVAL, "null argument");
+    if (n_chunks) *n_chunks = r->kept.size() + ((r->keeping && r->selected < 0 && r->have_chunk && r->n_records) ? 1 : 0);
+    if (n_bytes) *n_bytes = r->kept_bytes + ((r->keeping && r->selected < 0 && r->have_chunk && r->n_records)
+                                                 ? r->text.bytes + r->idx_u32.bytes + r->base_sz.bytes + r->text_sz.bytes : 0);
+    return KBBQ_OK;
+}
+
+int kbbq_fastq_reader_select(kbbq_fastq_reader *r, uint64_t i, kbbq_fastq_chunk *info) {
+    if (!r) return fail(KBBQ_EINVAL, "null argument");
+    stash_current(r);
+    if (i >= r->kept.size()) return fail(KBBQ_EINVAL, "kept chunk %llu of %llu", (unsigned long long)i, (unsigned long long)r->kept.size());
+    const kbbq_fastq_reader::Kept &k = r->kept[i];
+    r->selected = (int64_t)i;
+    r->have_chunk = true;
+    r->text_bytes = k.text_bytes; r->n_records = k.n_records; r->n_bases = k.n_bases;
+    r->longest = k.longest; r->shortest = k.shortest;
+    r->out_text_bytes = k.out_text_bytes;
+    if (info) {
+        memset(info, 0, sizeof *info);
+        info->n_records = k.n_records; info->n_bases = k.n_bases; info->longest = k.longest; info->shortest = k.shortest;
+        info->text_bytes = k.text_bytes;
+    }
     return KBBQ_OK;
 }
 
@@ -397,6 +481,8 @@ int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uin
     KbbqDeviceGuard guard(r->device);
     HIP_TRY(guard.err);
     memset(info, 0, sizeof *info);
+    stash_current(r);
+    r->selected = -1;
     r->have_chunk = false;
     // ---- the block boundaries: hop from header to header (RFC 1952 member with the 'BC' extra subfield, SAM spec 4.1)
     std::vector<uint64_t> c_off, o_off;
@@ -436,9 +522,20 @@ int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uin
     if (at == 0 && n_bytes && !last && c_off.empty()) return fail(KBBQ_EINVAL, "the chunk holds no complete BGZF block");
     const uint32_t nb = (uint32_t)c_off.size();
     int rc;
+    // (while chunks are kept, a buffer that no longer fits gives up the kept ones: pass 4 then inflates the file again)
+    auto reserve_or_drop = [&](Buf &b, size_t need) -> int {
+        int rc2 = b.reserve(need);
+        if (rc2 == KBBQ_ENOMEM && (r->keeping || !r->kept.empty())) {
+            (void)hipGetLastError();
+            release_kept(r);
+            r->keeping = false;
+            rc2 = b.reserve(need);
+        }
+        return rc2;
+    };
     // ---- compressed bytes and block table to the device, inflate
     if ((rc = r->comp.reserve(at + 4096))) return rc;
-    if ((rc = r->text.reserve(text + 4096))) return rc;
+    if ((rc = reserve_or_drop(r->text, text + 4096))) return rc;
     if ((rc = r->status.reserve((size_t)nb * 4 + 64))) return rc;
     const size_t meta_bytes = (size_t)nb * 24 + 64;
     if ((rc = r->blk_meta.reserve(meta_bytes))) return rc;
@@ -451,12 +548,14 @@ int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uin
         memcpy((uint32_t *)(hm + 2 * (size_t)nb), c_len.data(), (size_t)nb * 4);
         memcpy((uint32_t *)(hm + 2 * (size_t)nb) + nb, o_len.data(), (size_t)nb * 4);
     }
-    HIP_TRY(hipEventRecord(r->t0, r->st));
     if (r->carry_bytes) HIP_TRY(hipMemcpyAsync(r->text.p, r->carry.p, r->carry_bytes, hipMemcpyDeviceToDevice, r->st));
     if (nb) {
         HIP_TRY(hipMemcpyAsync(r->comp.p, file_bytes, at, hipMemcpyHostToDevice, r->st));
         HIP_TRY(hipMemsetAsync((char *)r->comp.p + at, 0, 4096, r->st));
         HIP_TRY(hipMemcpyAsync(r->blk_meta.p, hm, (size_t)nb * 24, hipMemcpyHostToDevice, r->st));
+    }
+    HIP_TRY(hipEventRecord(r->t0, r->st));      // (the kernel alone: the upload of the compressed bytes is not in its time)
+    if (nb) {
         InflateArgs A;
         A.comp = (const uint8_t *)r->comp.p;
         A.c_off = (const uint64_t *)r->blk_meta.p;
@@ -468,7 +567,11 @@ int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uin
         A.status = (uint32_t *)r->status.p;
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, r->device));
-        const unsigned grid = std::min<unsigned>(nb, (unsigned)std::max(1, prop.multiProcessorCount) * 16);      // 9 KB of LDS each, five waves per SIMD by registers
+        // as many wavefronts as stay resident (13 KB of LDS each): blocks are handed out round-robin, a second round of
+        // workgroups would only queue behind the first
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate, 64 * INF_WAVES, 0));
+        const unsigned grid = std::min<unsigned>(nb, (unsigned)std::max(1, prop.multiProcessorCount) * (unsigned)std::max(1, per_cu));
         hipLaunchKernelGGL(k_inflate, dim3(grid), dim3(64 * INF_WAVES), 0, r->st, A);
         HIP_TRY(hipGetLastError());
     }
@@ -503,10 +606,10 @@ int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uin
                            (const uint64_t *)r->tile_counts.p, (uint32_t *)r->nl_pos.p, n_lines);
         HIP_TRY(hipGetLastError());
         // ---- records
-        if ((rc = r->idx_u32.reserve(n_rec * 7 * 4))) return rc;
+        if ((rc = reserve_or_drop(r->idx_u32, n_rec * 7 * 4))) return rc;
         if ((rc = r->idx_second.reserve(n_rec))) return rc;
-        if ((rc = r->base_sz.reserve((n_rec + 2) * 8))) return rc;
-        if ((rc = r->text_sz.reserve((n_rec + 2) * 8))) return rc;
+        if ((rc = reserve_or_drop(r->base_sz, (n_rec + 2) * 8))) return rc;
+        if ((rc = reserve_or_drop(r->text_sz, (n_rec + 2) * 8))) return rc;
         if ((rc = r->flags.reserve(64))) return rc;
         const uint32_t init_flags[4] = {0, 0, 0xFFFFFFFFu, 0};
         HIP_TRY(hipMemcpyAsync(r->flags.p, init_flags, 16, hipMemcpyHostToDevice, r->st));
@@ -520,8 +623,10 @@ int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uin
         HIP_TRY(hipMemcpyAsync(hs, X.base_sz + n_rec, 8, hipMemcpyDeviceToHost, r->st));
         HIP_TRY(hipMemcpyAsync(hs + 1, X.flags, 16, hipMemcpyDeviceToHost, r->st));
         HIP_TRY(hipMemcpyAsync(hs + 4, (const uint32_t *)r->nl_pos.p + (4 * n_rec - 1), 4, hipMemcpyDeviceToHost, r->st));
+        HIP_TRY(hipMemcpyAsync(hs + 5, X.text_sz + n_rec, 8, hipMemcpyDeviceToHost, r->st));
         HIP_TRY(hipStreamSynchronize(r->st));
         r->n_bases = hs[0];
+        r->out_text_bytes = hs[5];
         const uint32_t *fl = (const uint32_t *)(hs + 1);
         info->flags |= fl[0];
         r->longest = fl[1];
@@ -553,7 +658,7 @@ int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uin
 
 int kbbq_fastq_reader_batch(kbbq_fastq_reader *r, kbbq_reads *dev) {
     if (!r || !dev) return fail(KBBQ_EINVAL, "null argument");
-    if (!r->have_chunk || !r->n_records) return fail(KBBQ_ESTATE, "no records in the current chunk");
+    if (!r->have_chunk || !r->n_records || r->selected >= 0) return fail(KBBQ_ESTATE, "no records in the current chunk");
     KbbqDeviceGuard guard(r->device);
     HIP_TRY(guard.err);
     const uint64_t n = r->n_records, nbases = r->n_bases;
@@ -616,22 +721,23 @@ int kbbq_fastq_reader_write(kbbq_fastq_reader *r, kbbq_bgzf *z, const uint8_t *d
     if (rc) return rc;
     Submission &s = *sp;
     const uint64_t n = r->n_records;
-    const FastqIndex X = index_of(r, n);
-    // the size of the text: the scanned sizes' total sits behind the offsets
-    uint64_t t = 0;
-    HIP_TRY(hipMemcpy(&t, X.text_sz + n, 8, hipMemcpyDeviceToHost));
+    const bool from_kept = r->selected >= 0;
+    const kbbq_fastq_reader::Kept *k = from_kept ? &r->kept[(size_t)r->selected] : nullptr;
+    const FastqIndex X = from_kept ? index_from(k->idx_u32.p, nullptr, k->base_sz.p, k->text_sz.p, nullptr, n) : index_of(r, n);
+    const uint8_t *text = (const uint8_t *)(from_kept ? k->text.p : r->text.p);
+    const uint64_t t = r->out_text_bytes;      // (the scanned sizes' total, read back with the chunk's other counts)
     s.n = t;
     s.formatted = true;
     if ((rc = s.payload.reserve(t + 16))) return rc;
     HIP_TRY(hipMemsetAsync((char *)s.payload.p + t, 0, 16, z->st));
     HIP_TRY(hipEventRecord(s.t0, z->st));
-    hipLaunchKernelGGL(k_fastq_text_indexed, dim3((unsigned)std::min<uint64_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, z->st, (const uint8_t *)r->text.p, X,
+    hipLaunchKernelGGL(k_fastq_text_indexed, dim3((unsigned)std::min<uint64_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, z->st, text, X,
                        (const uint64_t *)X.text_sz, (const uint64_t *)X.base_sz, d_qual, n, (uint8_t *)s.payload.p);
     HIP_TRY(hipGetLastError());
     if ((rc = launch_deflate(z, s))) return rc;
-    // the reader's text and index are read by the kernel just queued: the next kbbq_fastq_reader_chunk must not overwrite
-    // them before it has run
-    HIP_TRY(hipEventSynchronize(s.t1));
+    // the reader's live text and index are read by the kernel just queued: the next kbbq_fastq_reader_chunk must not
+    // overwrite them before it has run (a kept chunk's buffers stay as they are)
+    if (!from_kept) HIP_TRY(hipEventSynchronize(s.t1));
     return KBBQ_OK;
 }
 

@@ -30,45 +30,56 @@ namespace dfl {
 constexpr int INF_RING = 8192;               // the recent output of one wavefront in LDS: matches that reach no further back are
                                              // LDS-to-LDS copies; the rest of DEFLATE's 32 KB window is read back from HBM
 constexpr int INF_FLUSH = 256;               // bytes that leave the ring for HBM at a time: one aligned 256-byte line of the output
-constexpr int INF_NEAR = INF_RING - 512;     // a match at most this far back (plus its length) still lies in the ring
+constexpr int INF_NEAR = INF_RING - 512;     // a match at most this far back still lies in the ring (the 512: lanes write up to 63
+                                             // bytes ahead of the output position, see the literal and match copies)
+constexpr int INF_TBITS = 10;                // the literal/length table is indexed by the next 10 bits of the stream
 constexpr int INF_WAVES = 1;                 // one wavefront per workgroup
+constexpr int INF_LDS_PER_WAVE = INF_RING + (4 << INF_TBITS) + 1280;
 
 // status codes of a block
 enum : uint32_t { INF_OK = 0, INF_BAD_BLOCK_TYPE = 1, INF_BAD_STORED = 2, INF_BAD_CODE = 3, INF_OVERRUN_IN = 4, INF_OVERRUN_OUT = 5,
                   INF_BAD_DISTANCE = 6, INF_BAD_LENGTHS = 7, INF_SIZE_MISMATCH = 8 };
 
 struct InflateArgs {
-    const uint8_t *comp;        // the compressed bytes of the chunk (+ 1 KB readable behind them)
+    const uint8_t *comp;        // the compressed bytes of the chunk (+ 4 KB readable behind them)
     const uint64_t *c_off;      // per block: where its DEFLATE stream starts in comp
     const uint32_t *c_len;      //            bytes of DEFLATE stream
     const uint64_t *o_off;      //            where its bytes go in out
     const uint32_t *o_len;      //            ISIZE
-    uint8_t *out;
+    uint8_t *out;               // (+ 4 KB writable behind the last block: a block that overruns its size is caught a line late)
     uint32_t n_blocks;
     uint32_t *status;           // per block
 };
 
-// the canonical decoder of one alphabet, in registers: lane l (1..15) of `lim` holds the exclusive upper bound of the
-// codes of length <= l, left-aligned to 15 bits; lane l of `offs` holds (index of the first symbol of length l) - (first code
-// of length l); sym[j] lane i = symbol number 64 j + i in (length, value) order.
-template <int NREG>
-struct CodeRegs {
+// The canonical decoder of one alphabet: lane l (1..15) of `lim` holds the exclusive upper bound of the codes of length
+// <= l, left-aligned to 15 bits (0 in every other lane); lane l of `offs` holds (index of the first symbol of length l) -
+// (first code of length l).  The symbols in (length, value) order lie in LDS (literal/length alphabet) or, for the two small
+// alphabets, in the lanes of one more register.
+struct CodeBounds {
     uint32_t lim, offs;
-    uint32_t sym[NREG];
 };
+
+// Entries of the literal/length table (u32), found by the next INF_TBITS bits of the stream as they lie in it (LSB first):
+//   literals   [3:0] bits of the codes together  [5:4] how many literals (1..3)  [15:8] [23:16] [31:24] the bytes
+//   otherwise  [5:4] = 0 and [7:6]: 0 a length code: [3:0] code bits, [12:8] extra bits, [24:16] base length
+//                                   1 end of block:  [3:0] code bits
+//                                   2 a code longer than INF_TBITS bits (or no code at all): decoded by the bounds
+//                                   3 a symbol the alphabet does not have (286, 287)
+enum : uint32_t { INF_E_LENGTH = 0u << 6, INF_E_EOB = 1u << 6, INF_E_LONG = 2u << 6, INF_E_BAD = 3u << 6 };
 
 struct InflateLds {
     alignas(16) uint8_t ring[INF_RING];
+    uint32_t ll[1 << INF_TBITS];
+    uint16_t sorted_ll[320];     // literal/length symbols in (length, value) order
+    uint16_t sorted_small[64];   // the same of the code-length alphabet, then of the distance alphabet
     uint8_t lens[320];           // code lengths of a dynamic block (literal/length then distance)
-    uint16_t sorted[320];        // scratch of the table builder
 };
 
-// Build the register tables of one alphabet from lens[0..n) (LDS).  Uniform control flow; returns false for an
-// over-subscribed set of lengths.  An incomplete code is accepted (RFC 1951 allows a single distance code); codes it
-// does not define decode as an error later.
+// Bounds and sorted symbols of one alphabet from lens[0..n) (LDS).  Uniform control flow; returns false for an
+// over-subscribed set of lengths.  An incomplete code is accepted (RFC 1951 allows a single distance code); bit patterns
+// it does not define decode as an error later.  *n_coded: how many symbols have a code.
 template <int NREG>
-__device__ __forceinline__ bool build_code(const uint8_t *lens, int n, uint16_t *scratch, CodeRegs<NREG> &C, int lane) {
-    // counts per length: ballots over chunks of 64 symbols
+__device__ __forceinline__ bool build_code(const uint8_t *lens, int n, uint16_t *sorted, CodeBounds &C, uint32_t *n_coded, int lane) {
     uint32_t my_len[NREG];
 #pragma unroll
     for (int j = 0; j < NREG; ++j) { const int s = 64 * j + lane; my_len[j] = s < n ? lens[s] : 0u; }
@@ -77,59 +88,60 @@ __device__ __forceinline__ bool build_code(const uint8_t *lens, int n, uint16_t 
     int left = 1;
     bool ok = true;
     for (int l = 1; l <= MAX_BITS; ++l) {
+        uint64_t b[NREG];
         uint32_t cnt = 0;
 #pragma unroll
-        for (int j = 0; j < NREG; ++j) cnt += (uint32_t)__popcll(__ballot(my_len[j] == (uint32_t)l));
+        for (int j = 0; j < NREG; ++j) { b[j] = __ballot(my_len[j] == (uint32_t)l); cnt += (uint32_t)__popcll(b[j]); }
         left = (left << 1) - (int)cnt;
         if (left < 0) ok = false;
         // lane l: bound of the codes of length <= l, and the offset that turns a code of length l into its symbol's index
         const uint32_t bound = (code + cnt) << (MAX_BITS - l);
         const uint32_t off = index - code;
         if (lane == l) { lim = bound; offs = off; }
-        // where this lane's symbols of length l go
+        if (cnt) {
 #pragma unroll
-        for (int j = 0; j < NREG; ++j) {
-            const uint64_t b = __ballot(my_len[j] == (uint32_t)l);
-            if (my_len[j] == (uint32_t)l) scratch[index + (uint32_t)__popcll(b & ((1ull << lane) - 1))] = (uint16_t)(64 * j + lane);
-            index += (uint32_t)__popcll(b);
+            for (int j = 0; j < NREG; ++j) {
+                if (my_len[j] == (uint32_t)l) sorted[index + (uint32_t)__popcll(b[j] & ((1ull << lane) - 1))] = (uint16_t)(64 * j + lane);
+                index += (uint32_t)__popcll(b[j]);
+            }
         }
         code = (code + cnt) << 1;
     }
     __builtin_amdgcn_wave_barrier();
     C.lim = lim;
     C.offs = offs;
-#pragma unroll
-    for (int j = 0; j < NREG; ++j) C.sym[j] = (64 * j + lane) < 320 ? scratch[64 * j + lane] : 0u;
-    __builtin_amdgcn_wave_barrier();
+    *n_coded = index;
     return ok;
 }
 
 // The bit reader: 256 bytes of the stream per vector register (lane i = dword i), two registers ahead; the bit buffer and
-// its counters are wave-uniform.
+// its counters are wave-uniform.  It never reads further than two 256-byte pieces behind the end of the stream it was
+// given (a damaged stream cannot walk out of the buffer); consumed() against the stream's length tells an overrun.
 struct BitReader {
     const uint32_t *base;     // dword-aligned start
     uint32_t w0, w1;          // current and next 64 dwords (per lane)
     uint32_t idx;             // next dword of w0 to take (0..64)
     uint32_t chunk;           // index of the 256-byte chunk in w0
+    uint32_t last_chunk;      // the last chunk that may be loaded
     uint64_t buf;             // bits not consumed yet, LSB first
     int cnt;                  // how many
-    uint64_t taken;           // bits consumed so far (for the bound check)
-    __device__ __forceinline__ void init(const uint8_t *p, int lane) {
+    uint32_t skip;            // bits of the first dword that lie before the stream
+    __device__ __forceinline__ void init(const uint8_t *p, uint32_t n_bytes, int lane) {
         const uintptr_t a = (uintptr_t)p;
-        base = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+        base = reinterpret_cast<const uint32_t *>(p - (a & 3));      // (pointer arithmetic: the loads stay global ones)
+        last_chunk = (n_bytes + 3 + 255) / 256 + 1;
         w0 = base[lane];
         w1 = base[64 + lane];
         idx = 0;
         chunk = 0;
         buf = 0;
         cnt = 0;
-        taken = 0;
-        const int skip = (int)(a & 3) * 8;
+        skip = (uint32_t)(a & 3) * 8;
         refill();
         buf >>= skip;
-        cnt -= skip;
+        cnt -= (int)skip;
     }
-    __device__ __forceinline__ void refill() {      // at least 32 valid bits afterwards
+    __device__ __forceinline__ void refill() {      // at least 33 valid bits afterwards (25 right behind init)
         if (cnt <= 32) {
             const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)w0, (int)idx);
             buf |= (uint64_t)d << cnt;
@@ -138,12 +150,15 @@ struct BitReader {
                 idx = 0;
                 ++chunk;
                 w0 = w1;
-                w1 = base[(size_t)(chunk + 1) * 64 + (threadIdx.x & 63)];
+                const uint32_t next = chunk + 1 < last_chunk ? chunk + 1 : last_chunk;
+                w1 = base[(size_t)next * 64 + (threadIdx.x & 63)];
             }
         }
     }
+    __device__ __forceinline__ uint64_t consumed() const { return ((uint64_t)chunk * 64 + idx) * 32 - (uint64_t)cnt - skip; }
+    __device__ __forceinline__ uint32_t bits() const { return (uint32_t)buf; }
     __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(buf & ((1ull << n) - 1)); }
-    __device__ __forceinline__ void drop(int n) { buf >>= n; cnt -= n; taken += (uint64_t)n; }
+    __device__ __forceinline__ void drop(int n) { buf >>= n; cnt -= n; }
     __device__ __forceinline__ uint32_t get(int n) {      // n <= 16
         refill();
         const uint32_t v = peek(n);
@@ -152,22 +167,92 @@ struct BitReader {
     }
 };
 
-// one symbol of the alphabet C from the reader; -1: a bit pattern the code does not define
-template <int NREG>
-__device__ __forceinline__ int decode_symbol(BitReader &B, const CodeRegs<NREG> &C, int lane) {
-    B.refill();
+// index (in (length, value) order) of the symbol whose code starts the reader's bits, by the bounds; -1: a bit pattern the
+// code does not define.  *len: bits of the code.  The reader holds at least 15 bits.
+__device__ __forceinline__ int decode_index(uint32_t bits, const CodeBounds &C, int *len) {
     // the next 15 bits, first bit of the code in the highest place (Huffman codes are packed starting with their MSB)
-    const uint32_t v = __brev(B.peek(MAX_BITS)) >> (32 - MAX_BITS);
-    const uint64_t fits = __ballot(lane >= 1 && lane <= MAX_BITS && v < C.lim);
+    const uint32_t v = __brev(bits) >> (32 - MAX_BITS);
+    const uint64_t fits = __ballot(v < C.lim);
     if (!fits) return -1;
-    const int len = (int)__builtin_ctzll(fits);
-    const uint32_t index = (uint32_t)__builtin_amdgcn_readlane((int)C.offs, len) + (v >> (MAX_BITS - len));
-    B.drop(len);
-    uint32_t s = 0;
+    const int l = (int)__builtin_ctzll(fits);
+    *len = l;
+    return (int)((uint32_t)__builtin_amdgcn_readlane((int)C.offs, l) + (v >> (MAX_BITS - l)));
+}
+
+// length symbol 257..285 -> base length and extra bits (RFC 1951, 3.2.5)
+__device__ __forceinline__ void length_base(int li, int *base, int *eb) {
+    if (li < 8) { *base = 3 + li; *eb = 0; }
+    else if (li == 28) { *base = 258; *eb = 0; }
+    else { *eb = (li >> 2) - 1; *base = 3 + ((4 + (li & 3)) << *eb); }
+}
+
+// The literal/length table of a block from its bounds and sorted symbols: every lane decodes 16 of the 1024 bit patterns
+// the slow way, then looks whether one or two more literals fit behind a literal in the same ten bits.
+__device__ __forceinline__ void build_ll_table(InflateLds &S, const CodeBounds &LL, uint32_t n_coded, int lane) {
+    constexpr int PER = (1 << INF_TBITS) / 64;
+    uint32_t e[PER];
 #pragma unroll
-    for (int j = 0; j < NREG; ++j)
-        if ((index >> 6) == (uint32_t)j) s = (uint32_t)__builtin_amdgcn_readlane((int)C.sym[j], (int)(index & 63));
-    return (int)s;
+    for (int j = 0; j < PER; ++j) {
+        const uint32_t x = (uint32_t)(64 * j + lane);
+        const uint32_t v = (__brev(x) >> (32 - INF_TBITS)) << (MAX_BITS - INF_TBITS);      // the pattern's bits, first in the highest place
+        uint32_t len = 0, off = 0;
+        for (int l = INF_TBITS; l >= 1; --l) {
+            const uint32_t lim_l = (uint32_t)__builtin_amdgcn_readlane((int)LL.lim, l);
+            const uint32_t off_l = (uint32_t)__builtin_amdgcn_readlane((int)LL.offs, l);
+            if (v < lim_l) { len = (uint32_t)l; off = off_l; }      // the bounds grow with l: the smallest l that fits is written last
+        }
+        uint32_t ent = INF_E_LONG;
+        if (len) {
+            const uint32_t index = off + (v >> (MAX_BITS - len));
+            const uint32_t sym = index < n_coded ? S.sorted_ll[index] : 287u;
+            if (sym < 256) ent = len | (1u << 4) | (sym << 8);
+            else if (sym == 256) ent = len | INF_E_EOB;
+            else if (sym <= 285) {
+                int base, eb;
+                length_base((int)sym - 257, &base, &eb);
+                ent = len | INF_E_LENGTH | ((uint32_t)eb << 8) | ((uint32_t)base << 16);
+            } else ent = len | INF_E_BAD;
+        }
+        e[j] = ent;
+        S.ll[x] = ent;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // more literals behind a literal: the pattern's remaining bits (zeros above them) find the next code's entry; it counts
+    // when that code is a literal and no longer than the bits that are left
+    uint32_t packed[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const uint32_t x = (uint32_t)(64 * j + lane);
+        uint32_t ent = e[j];
+        if ((ent & 0x30u) == 0x10u) {
+            const uint32_t l1 = ent & 15u;
+            if (l1 < (uint32_t)INF_TBITS) {
+                const uint32_t e2 = S.ll[x >> l1];
+                const uint32_t l2 = e2 & 15u;
+                if ((e2 & 0x30u) == 0x10u && l1 + l2 <= (uint32_t)INF_TBITS) {
+                    ent = (l1 + l2) | (2u << 4) | (ent & 0xFF00u) | ((e2 & 0xFF00u) << 8);
+                    if (l1 + l2 < (uint32_t)INF_TBITS) {
+                        const uint32_t e3 = S.ll[x >> (l1 + l2)];
+                        const uint32_t l3 = e3 & 15u;
+                        if ((e3 & 0x30u) == 0x10u && l1 + l2 + l3 <= (uint32_t)INF_TBITS)
+                            ent = (l1 + l2 + l3) | (3u << 4) | (ent & 0xFFFF00u) | ((e3 & 0xFF00u) << 16);
+                    }
+                }
+            }
+        }
+        packed[j] = ent;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) S.ll[64 * j + lane] = packed[j];
+    __builtin_amdgcn_wave_barrier();
+}
+
+// distance symbol -> base distance | extra bits << 16 (RFC 1951, 3.2.5)
+__device__ __forceinline__ uint32_t distance_info(uint32_t ds) {
+    if (ds < 4) return 1u + ds;
+    const uint32_t de = (ds >> 1) - 1;
+    return (1u + ((2u + (ds & 1u)) << de)) | (de << 16);
 }
 
 __global__ void __launch_bounds__(64 * INF_WAVES) k_inflate(InflateArgs A) {
@@ -175,34 +260,39 @@ __global__ void __launch_bounds__(64 * INF_WAVES) k_inflate(InflateArgs A) {
     const int lane = threadIdx.x & 63;
     InflateLds &S = lds_all[0];
     const uint32_t wave = blockIdx.x, n_waves = gridDim.x;
+    constexpr uint32_t MASK = INF_RING - 1;
+    const uint32_t lit_shift = (8u + 8u * (uint32_t)lane) & 31u;      // lane i < 3 takes byte i of a literal entry
     for (uint32_t blk = wave; blk < A.n_blocks; blk += n_waves) {
         const uint8_t *src = A.comp + A.c_off[blk];
-        const uint64_t src_bits = (uint64_t)A.c_len[blk] * 8;
+        const uint32_t src_bytes = A.c_len[blk];
+        const uint64_t src_bits = (uint64_t)src_bytes * 8;
         uint8_t *dst = A.out + A.o_off[blk];
         const uint32_t want = A.o_len[blk];
         // The ring holds the block's latest INF_RING bytes at the index (address in HBM) mod INF_RING, so that an aligned
         // 256-byte line of the output is an aligned 256-byte piece of the ring: it leaves as 64 coalesced dword stores as
         // soon as it is complete (the block's first and last lines, which it shares with its neighbours, byte by byte).
-        const uint32_t skew = (uint32_t)((uintptr_t)dst & (INF_RING - 1));
-        BitReader B;
-        B.init(src, lane);
-        uint32_t pos = 0, flushed = 0;      // bytes produced / bytes that have left the ring
+        // Positions below are `sp` = skew + (bytes produced): the ring index is sp & MASK, the address dst_base + sp.
+        const uint32_t skew = (uint32_t)((uintptr_t)dst & MASK);
+        uint8_t *dst_base = dst - skew;
+        const uint32_t sp_end = skew + want;
+        uint32_t sp = skew, fl = skew;                   // produced / flushed
+        uint32_t next_line = (skew | (INF_FLUSH - 1)) + 1;      // where the line that holds `fl` ends
         uint32_t err = INF_OK;
-        auto ring_at = [&](uint32_t p) -> uint32_t { return (skew + p) & (INF_RING - 1); };
-        auto flush_to = [&](uint32_t upto, bool all) {
-            // whole lines [flushed, line end) while they are complete; `all`: also what is left at the block's end
-            for (;;) {
-                const uint32_t line_end = ((skew + flushed) | (INF_FLUSH - 1)) + 1 - skew;      // position behind the line that holds `flushed`
-                if (line_end > upto && !all) break;
-                const uint32_t end = line_end < upto ? line_end : upto;
-                if (end <= flushed) break;
-                const uint32_t r0 = ring_at(flushed);
-                if ((r0 & (INF_FLUSH - 1)) == 0 && end - flushed == INF_FLUSH) {
-                    *reinterpret_cast<uint32_t *>(dst + flushed + 4 * lane) = *reinterpret_cast<const uint32_t *>(&S.ring[r0 + 4 * lane]);
+        uint64_t bits_before = 0;                        // bits consumed before the reader was last aimed
+        BitReader B;
+        B.init(src, src_bytes, lane);
+        // whole lines up to sp leave the ring
+        auto flush_lines = [&]() {
+            while (sp >= next_line && err == INF_OK) {
+                if (next_line > sp_end + INF_FLUSH) { err = INF_OVERRUN_OUT; break; }
+                if ((fl & (INF_FLUSH - 1)) == 0) {
+                    *reinterpret_cast<uint32_t *>(dst_base + fl + 4 * lane) = *reinterpret_cast<const uint32_t *>(&S.ring[(fl & MASK) + 4 * lane]);
                 } else {
-                    for (uint32_t o = flushed + lane; o < end; o += 64) dst[o] = S.ring[ring_at(o)];
+#pragma clang loop vectorize(disable) unroll(disable)
+                    for (uint32_t o = fl + lane; o < next_line; o += 64) dst_base[o] = S.ring[o & MASK];
                 }
-                flushed = end;
+                fl = next_line;
+                next_line += INF_FLUSH;
             }
         };
         bool last = false;
@@ -214,37 +304,38 @@ __global__ void __launch_bounds__(64 * INF_WAVES) k_inflate(InflateArgs A) {
                 B.refill();
                 B.drop(B.cnt & 7);
                 const uint32_t len = B.get(16), nlen = B.get(16);
+                const uint64_t at = bits_before + B.consumed();
                 if ((len ^ nlen) != 0xFFFFu) { err = INF_BAD_STORED; break; }
-                if (B.taken + (uint64_t)len * 8 > src_bits) { err = INF_OVERRUN_IN; break; }
-                if (pos + len > want) { err = INF_OVERRUN_OUT; break; }
+                if (at + (uint64_t)len * 8 > src_bits) { err = INF_OVERRUN_IN; break; }
+                if (sp + len > sp_end) { err = INF_OVERRUN_OUT; break; }
                 // the reader is at a byte boundary: the bytes straight from the stream, through the ring (later matches may
                 // want them there)
-                const uint8_t *from = src + (B.taken >> 3);
+                const uint8_t *from = src + (at >> 3);
                 for (uint32_t done = 0; done < len;) {
                     const uint32_t n = min(len - done, (uint32_t)1024);
-                    for (uint32_t i = lane; i < n; i += 64) S.ring[ring_at(pos + done + i)] = from[done + i];
+#pragma clang loop vectorize(disable) unroll(disable)
+                    for (uint32_t i = lane; i < n; i += 64) S.ring[(sp + i) & MASK] = from[done + i];
                     done += n;
+                    sp += n;
                     __builtin_amdgcn_wave_barrier();
-                    flush_to(pos + done, false);
+                    flush_lines();
                 }
-                pos += len;
                 // re-aim the reader behind the stored bytes
-                const uint64_t at = B.taken + (uint64_t)len * 8;
-                B.init(src + (at >> 3), lane);
-                B.taken = at;
+                bits_before = at + (uint64_t)len * 8;
+                B.init(src + (bits_before >> 3), src_bytes - (uint32_t)(bits_before >> 3), lane);
                 continue;
             }
             if (type == 3) { err = INF_BAD_BLOCK_TYPE; break; }
-            CodeRegs<5> LL;
-            CodeRegs<1> DD;
+            CodeBounds LL, DD;
+            uint32_t n_ll = 0, n_dd = 0;
             if (type == 1) {
                 // fixed codes (RFC 1951, 3.2.6)
                 for (int s = lane; s < 288; s += 64) S.lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
                 __builtin_amdgcn_wave_barrier();
-                build_code<5>(S.lens, 288, S.sorted, LL, lane);
+                build_code<5>(S.lens, 288, S.sorted_ll, LL, &n_ll, lane);
                 if (lane < 32) S.lens[lane] = 5;
                 __builtin_amdgcn_wave_barrier();
-                build_code<1>(S.lens, 30, S.sorted, DD, lane);
+                build_code<1>(S.lens, 30, S.sorted_small, DD, &n_dd, lane);
             } else {
                 const int hlit = (int)B.get(5) + 257, hdist = (int)B.get(5) + 1, hclen = (int)B.get(4) + 4;
                 if (hlit > 286 || hdist > 30) { err = INF_BAD_LENGTHS; break; }
@@ -259,14 +350,21 @@ __global__ void __launch_bounds__(64 * INF_WAVES) k_inflate(InflateArgs A) {
                     if (lane == 0) S.lens[where] = (uint8_t)v;
                 }
                 __builtin_amdgcn_wave_barrier();
-                CodeRegs<1> CL;
-                if (!build_code<1>(S.lens, N_CL, S.sorted, CL, lane)) { err = INF_BAD_LENGTHS; break; }
+                CodeBounds CL;
+                uint32_t n_cl = 0;
+                if (!build_code<1>(S.lens, N_CL, S.sorted_small, CL, &n_cl, lane)) { err = INF_BAD_LENGTHS; break; }
+                const uint32_t cl_sym = S.sorted_small[lane];      // lane i: the i-th symbol of the code-length alphabet
+                __builtin_amdgcn_wave_barrier();
                 // the code lengths of both alphabets, run-length coded
                 int i = 0, prev = 0;
                 const int total = hlit + hdist;
-                while (i < total && err == INF_OK) {
-                    const int sym = decode_symbol<1>(B, CL, lane);
-                    if (sym < 0 || sym > 18) { err = INF_BAD_CODE; break; }
+                while (i < total) {
+                    B.refill();
+                    int cl = 0;
+                    const int ci = decode_index(B.bits(), CL, &cl);
+                    if (ci < 0 || (uint32_t)ci >= n_cl) { err = INF_BAD_CODE; break; }
+                    B.drop(cl);
+                    const int sym = __builtin_amdgcn_readlane((int)cl_sym, ci);
                     int rep = 1, val = sym;
                     if (sym == 16) { if (i == 0) { err = INF_BAD_LENGTHS; break; } rep = 3 + (int)B.get(2); val = prev; }
                     else if (sym == 17) { rep = 3 + (int)B.get(3); val = 0; }
@@ -277,9 +375,9 @@ __global__ void __launch_bounds__(64 * INF_WAVES) k_inflate(InflateArgs A) {
                     if (rep > 128 && lane + 128 < rep) S.lens[i + 128 + lane] = (uint8_t)val;
                     i += rep;
                     prev = val;
-                    if (B.taken > src_bits) err = INF_OVERRUN_IN;
                 }
                 if (err != INF_OK) break;
+                if (bits_before + B.consumed() > src_bits) { err = INF_OVERRUN_IN; break; }
                 __builtin_amdgcn_wave_barrier();
                 // distance lengths follow the literal/length ones: move them to the front of a second array
                 uint8_t dl = 0;
@@ -288,68 +386,124 @@ __global__ void __launch_bounds__(64 * INF_WAVES) k_inflate(InflateArgs A) {
                 for (int s = hlit + lane; s < 320; s += 64) S.lens[s] = 0;
                 __builtin_amdgcn_wave_barrier();
                 if (S.lens[256] == 0) { err = INF_BAD_LENGTHS; break; }      // no end-of-block code
-                if (!build_code<5>(S.lens, hlit, S.sorted, LL, lane)) { err = INF_BAD_LENGTHS; break; }
+                if (!build_code<5>(S.lens, hlit, S.sorted_ll, LL, &n_ll, lane)) { err = INF_BAD_LENGTHS; break; }
                 __builtin_amdgcn_wave_barrier();
                 if (lane < 32) S.lens[lane] = lane < hdist ? dl : 0;
                 __builtin_amdgcn_wave_barrier();
-                if (!build_code<1>(S.lens, hdist, S.sorted, DD, lane)) { err = INF_BAD_LENGTHS; break; }
+                if (!build_code<1>(S.lens, hdist, S.sorted_small, DD, &n_dd, lane)) { err = INF_BAD_LENGTHS; break; }
             }
+            build_ll_table(S, LL, n_ll, lane);
+            // lane i: base distance and extra bits of the i-th distance symbol in (length, value) order
+            const uint32_t dd_info = (uint32_t)lane < n_dd ? distance_info(S.sorted_small[lane]) : 0u;
             // ---- the block's symbols
             for (;;) {
-                const int sym = decode_symbol<5>(B, LL, lane);
-                if (sym < 0) { err = INF_BAD_CODE; break; }
-                if (B.taken > src_bits) { err = INF_OVERRUN_IN; break; }
-                if (sym < 256) {
-                    if (pos >= want) { err = INF_OVERRUN_OUT; break; }
-                    if (lane == 0) S.ring[ring_at(pos)] = (uint8_t)sym;
-                    ++pos;
-                    if (((skew + pos) & (INF_FLUSH - 1)) == 0) { __builtin_amdgcn_wave_barrier(); flush_to(pos, false); }
+                B.refill();
+                uint32_t bits = B.bits();
+                uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.ll[bits & ((1u << INF_TBITS) - 1)]);
+                if (ent & 0x30u) {
+                    // one to three literals: lane i writes byte i (the lanes behind them write bytes that the following symbols
+                    // overwrite: what lies up to 63 bytes ahead of the output position is nobody's yet)
+                    S.ring[(sp + (uint32_t)lane) & MASK] = (uint8_t)(ent >> lit_shift);
+                    B.drop((int)(ent & 15u));
+                    sp += (ent >> 4) & 3u;
+                    if (sp >= next_line) { __builtin_amdgcn_wave_barrier(); flush_lines(); if (err != INF_OK) break; }
                     continue;
                 }
-                if (sym == 256) break;
-                if (sym > 285) { err = INF_BAD_CODE; break; }
-                // length: base + extra bits (RFC 1951, 3.2.5)
-                const int li = sym - 257;
-                int len, eb;
-                if (li < 8) { len = 3 + li; eb = 0; }
-                else if (li == 28) { len = 258; eb = 0; }
-                else { eb = (li >> 2) - 1; len = 3 + ((4 + (li & 3)) << eb); }
-                if (eb) len += (int)B.get(eb);
-                const int ds = decode_symbol<1>(B, DD, lane);
-                if (ds < 0 || ds > 29) { err = INF_BAD_CODE; break; }
-                int dist;
-                if (ds < 4) dist = 1 + ds;
-                else { const int de = (ds >> 1) - 1; dist = 1 + ((2 + (ds & 1)) << de) + (int)B.get(de); }
-                if ((uint32_t)dist > pos) { err = INF_BAD_DISTANCE; break; }
-                if (pos + (uint32_t)len > want) { err = INF_OVERRUN_OUT; break; }
-                // The copy: byte i of the match is byte (i mod dist) of the dist bytes before it -- every lane reads from
-                // that finished region, so the chunks of a long match do not depend on each other.  A source inside the ring
-                // is an LDS-to-LDS copy; a source further back has left the ring long ago (at least 7 KB of output lie between
-                // it and the flush frontier) and is read back from HBM, behind a wait for this wave's own stores.
-                __builtin_amdgcn_wave_barrier();
-                const bool far = dist > INF_NEAR;
-                if (far) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                for (int i0 = 0; i0 < len; i0 += 64) {
-                    const int i = i0 + lane;
-                    uint8_t v = 0;
-                    if (i < len) {
-                        const int k = dist >= len ? i : (dist == 1 ? 0 : i % dist);
-                        const uint32_t from = pos - (uint32_t)dist + (uint32_t)k;
-                        v = far ? dst[from] : S.ring[ring_at(from)];
+                int len;
+                if ((ent & 0xC0u) == INF_E_LENGTH) {
+                    const int nb = (int)(ent & 15u), eb = (int)((ent >> 8) & 31u);
+                    len = (int)((ent >> 16) & 511u) + (int)((bits >> nb) & ((1u << eb) - 1u));
+                    B.drop(nb + eb);
+                } else if ((ent & 0xC0u) == INF_E_EOB) {
+                    B.drop((int)(ent & 15u));
+                    break;
+                } else if ((ent & 0xC0u) == INF_E_BAD) {
+                    err = INF_BAD_CODE;
+                    break;
+                } else {
+                    // a code longer than the table's index
+                    int cl = 0;
+                    const int ci = decode_index(bits, LL, &cl);
+                    if (ci < 0 || (uint32_t)ci >= n_ll) { err = INF_BAD_CODE; break; }
+                    B.drop(cl);
+                    const int sym = __builtin_amdgcn_readfirstlane((int)S.sorted_ll[ci]);
+                    if (sym < 256) {
+                        if (lane == 0) S.ring[sp & MASK] = (uint8_t)sym;
+                        ++sp;
+                        if (sp >= next_line) { __builtin_amdgcn_wave_barrier(); flush_lines(); if (err != INF_OK) break; }
+                        continue;
                     }
-                    __builtin_amdgcn_wave_barrier();
-                    if (i < len) S.ring[ring_at(pos + (uint32_t)i)] = v;
+                    if (sym == 256) break;
+                    if (sym > 285) { err = INF_BAD_CODE; break; }
+                    int base, eb;
+                    length_base(sym - 257, &base, &eb);
+                    len = base + (int)((bits >> cl) & ((1u << eb) - 1u));
+                    B.drop(eb);
+                }
+                // the distance
+                B.refill();
+                bits = B.bits();
+                int dl = 0;
+                const int di = decode_index(bits, DD, &dl);
+                if (di < 0 || (uint32_t)di >= n_dd) { err = INF_BAD_CODE; break; }
+                const uint32_t dinfo = (uint32_t)__builtin_amdgcn_readlane((int)dd_info, di);
+                const int de = (int)(dinfo >> 16);
+                const uint32_t dist = (dinfo & 0xFFFFu) + ((bits >> dl) & ((1u << de) - 1u));
+                B.drop(dl + de);
+                if (dist > sp - skew) { err = INF_BAD_DISTANCE; break; }
+                // The copy: byte i of the match is byte (i mod dist) of the dist bytes before it.  A source inside the ring is an
+                // LDS-to-LDS copy; a source further back has left the ring long ago (at least 7 KB of output lie between it and
+                // the flush frontier) and is read back from HBM, behind a wait for this wave's own stores.  Like the literals,
+                // the lanes behind the match's length copy bytes nobody owns yet.
+                __builtin_amdgcn_wave_barrier();
+                if (dist <= (uint32_t)INF_NEAR) {
+                    if (dist >= (uint32_t)len) {
+                        // source and destination apart: all reads, then all writes
+                        const uint32_t from = sp - dist + (uint32_t)lane, to = sp + (uint32_t)lane;
+                        if (len <= 64) {
+                            const uint8_t v = S.ring[from & MASK];
+                            S.ring[to & MASK] = v;
+                        } else {
+                            uint8_t v[5];
+#pragma unroll
+                            for (int r = 0; r < 5; ++r) v[r] = S.ring[(from + 64u * r) & MASK];
+#pragma unroll
+                            for (int r = 0; r < 5; ++r) if (64 * r < len) S.ring[(to + 64u * r) & MASK] = v[r];
+                        }
+                    } else {
+                        // the match runs into itself: the first `dist` bytes, then twice as many, ... (every round's source is
+                        // finished, its stride a multiple of dist)
+                        uint32_t c = dist;
+                        for (uint32_t done = 0; done < (uint32_t)len;) {
+                            const uint32_t n = min(c, 64u);
+                            const uint8_t v = S.ring[(sp + done - c + (uint32_t)lane) & MASK];
+                            __builtin_amdgcn_wave_barrier();
+                            if ((uint32_t)lane < n) S.ring[(sp + done + (uint32_t)lane) & MASK] = v;
+                            __builtin_amdgcn_wave_barrier();
+                            done += n;
+                            if (c < 64u) c *= 2;
+                        }
+                    }
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    for (int i0 = 0; i0 < len; i0 += 64) {
+                        const int i = i0 + lane;
+                        if (i < len) S.ring[(sp + (uint32_t)i) & MASK] = dst_base[sp - dist + (uint32_t)i];
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
-                const uint32_t before = skew + pos;
-                pos += (uint32_t)len;
-                if ((before ^ (skew + pos)) & ~(uint32_t)(INF_FLUSH - 1)) flush_to(pos, false);
+                sp += (uint32_t)len;
+                if (sp >= next_line) { flush_lines(); if (err != INF_OK) break; }
             }
+            if (err == INF_OK && bits_before + B.consumed() > src_bits) err = INF_OVERRUN_IN;
         }
-        if (err == INF_OK && pos != want) err = INF_SIZE_MISMATCH;
+        if (err == INF_OK && sp != sp_end) err = sp > sp_end ? INF_OVERRUN_OUT : INF_SIZE_MISMATCH;
         // what is left in the ring
         __builtin_amdgcn_wave_barrier();
-        if (err == INF_OK) flush_to(pos, true);
+        if (err == INF_OK) {
+#pragma clang loop vectorize(disable) unroll(disable)
+            for (uint32_t o = fl + lane; o < sp; o += 64) dst_base[o] = S.ring[o & MASK];
+        }
         if (lane == 0) A.status[blk] = err;
         __builtin_amdgcn_wave_barrier();
     }

@@ -300,6 +300,8 @@ class DeviceFastqInput {
 public:
     ~DeviceFastqInput() { close(); }
     bool active = false;
+    bool text_kept = false;                   // every chunk's text and index stayed in HBM: pass 4 reads nothing
+    uint64_t kept_bytes = 0;
     std::vector<uint64_t> chunk_records;      // records of every chunk of the first scan (pass 4 must meet the same)
     kbbq_fastq_reader *reader = nullptr;
     double wait_s = 0, device_s = 0;
@@ -819,6 +821,11 @@ int main(int argc, char *argv[]) {
     if (!is_bam && !fixed_mode && !host_io && resident.on && filename != "-" && !(getenv("KBBQ_DEVICE_READER") && atoi(getenv("KBBQ_DEVICE_READER")) == 0) &&
         !(getenv("KBBQ_SERIAL_PARSE") && atoi(getenv("KBBQ_SERIAL_PARSE"))) && dev_in.open(filename)) {
         bool ok = true;
+        // The inflated text stays in HBM beside the packed reads while both fit in three quarters of the free memory
+        // (resident.budget is 60 %): pass 4 then takes the record text from there and the file is read and inflated once.
+        // KBBQ_KEEP_TEXT=0: pass 4 reads the file again.
+        bool keeping = !(getenv("KBBQ_KEEP_TEXT") && atoi(getenv("KBBQ_KEEP_TEXT")) == 0) && kbbq_fastq_reader_keep(dev_in.reader, 1) == 0;
+        const uint64_t text_budget = resident.budget / 4 * 5;
         for (;;) {
             kbbq_fastq_chunk info;
             const int rc = dev_in.next_chunk(info);
@@ -827,6 +834,13 @@ int main(int argc, char *argv[]) {
             dev_in.chunk_records.push_back(info.n_records);
             if (!info.n_records) continue;
             const uint64_t need = info.n_bases * 13 / 8 + info.n_records * 16 + (1 << 16);
+            if (keeping) {
+                uint64_t kept_chunks = 0, kept_bytes = 0;
+                if (kbbq_fastq_reader_kept(dev_in.reader, &kept_chunks, &kept_bytes) < 0 || resident.bytes + need + kept_bytes > text_budget) {
+                    kbbq_fastq_reader_keep(dev_in.reader, 0);
+                    keeping = false;
+                }
+            }
             kbbq_reads d;
             if (info.longest > KBBQ_MAX_READ_LEN || resident.bytes + need > resident.budget || kbbq_fastq_reader_batch(dev_in.reader, &d) < 0) { ok = false; break; }
             if (kbbq_reads_alloc_hints(&d) < 0) { kbbq_reads_free(nullptr, &d); ok = false; break; }
@@ -838,6 +852,10 @@ int main(int argc, char *argv[]) {
         }
         if (ok && n_reads) {
             dev_in.active = true;
+            uint64_t kept_chunks = 0;
+            if (kbbq_fastq_reader_rewind(dev_in.reader) == 0 && kbbq_fastq_reader_kept(dev_in.reader, &kept_chunks, &dev_in.kept_bytes) == 0)
+                dev_in.text_kept = kept_chunks == resident.dev.size();
+            if (!dev_in.text_kept) { kbbq_fastq_reader_keep(dev_in.reader, 0); dev_in.kept_bytes = 0; }
             resident.keep_recs = false;      // the record text comes from the device's own copy of the input in pass 4
             groups.index_of(std::string());  // FASTQ without read-group fields: the one read group "" (readutils.cc:98-103)
         } else {
@@ -1163,11 +1181,17 @@ int main(int argc, char *argv[]) {
             size_t d_q_bytes[2] = {0, 0};
             struct FreeQ { kbbq_engine *e; void **p; ~FreeQ() { for (int i = 0; i < 2; ++i) if (p[i]) kbbq_device_free(e, p[i]); } } free_q{e, d_q};
             size_t bi = 0;
-            dev_in.start_pass();
-            if (kbbq_fastq_reader_rewind(dev_in.reader) < 0) return fail_engine("recalibrating");
+            if (!dev_in.text_kept) {
+                dev_in.start_pass();
+                if (kbbq_fastq_reader_rewind(dev_in.reader) < 0) return fail_engine("recalibrating");
+            }
             for (size_t ci = 0; ci < dev_in.chunk_records.size(); ++ci) {
                 kbbq_fastq_chunk info;
-                if (dev_in.next_chunk(info) != 1 || info.n_records != dev_in.chunk_records[ci]) {
+                if (dev_in.text_kept) {
+                    // the chunk's text and index are still on the device
+                    if (!dev_in.chunk_records[ci]) continue;
+                    if (kbbq_fastq_reader_select(dev_in.reader, bi, &info) < 0 || info.n_records != dev_in.chunk_records[ci]) return fail_engine("recalibrating");
+                } else if (dev_in.next_chunk(info) != 1 || info.n_records != dev_in.chunk_records[ci]) {
                     std::cerr << put_now << " Error: the input changed between the passes." << std::endl;
                     return 1;
                 }
@@ -1360,8 +1384,9 @@ int main(int argc, char *argv[]) {
     if (clock.on && dev_in.active) {
         double inf = 0, idx = 0;
         kbbq_fastq_reader_kernel_ms(dev_in.reader, &inf, &idx);
-        std::cerr << "[timing] FASTQ reader on the GPU (both scans): waiting for file reads " << dev_in.wait_s << " s, device calls " << dev_in.device_s
-                  << " s; kernels: inflate " << inf << " ms, index + pack " << idx << " ms" << std::endl;
+        std::cerr << "[timing] FASTQ reader on the GPU (" << (dev_in.text_kept ? "one scan, the text kept in HBM: " : "both scans: ")
+                  << (dev_in.text_kept ? std::to_string(dev_in.kept_bytes) + " bytes; " : std::string()) << "waiting for file reads " << dev_in.wait_s
+                  << " s, device calls " << dev_in.device_s << " s; kernels: inflate " << inf << " ms, index + pack " << idx << " ms" << std::endl;
     }
     if (clock.on && out_payload)
         std::cerr << "[timing] BGZF writer on the GPU: " << out_payload << " bytes -> " << out_compressed << " (ratio "

@@ -240,6 +240,56 @@ def test_reader_and_writer_round_trip_with_new_qualities(writer):
     r.close()
 
 
+def test_kept_chunks_are_written_without_a_second_scan(writer):
+    """kbbq_fastq_reader_keep: the chunks of the first scan stay on the device; pass 4 selects them one by one and gets the
+    same text as a second inflation would give.  A file in three pieces, the cuts inside records."""
+    import torch
+    recs, text = make_records(9000, seed=41, uniform=False)
+    comp = bgzip(text, 6, block=20000)
+    # cut at BGZF block boundaries (the reader takes whole blocks and reports what it consumed)
+    r = bgzf.FastqReader()
+    r.keep(True)
+    pieces, at, counts = [len(comp) // 3, 2 * len(comp) // 3, len(comp)], 0, []
+    for end in pieces:
+        info = r.chunk(comp[at:end], end == len(comp))
+        assert info["flags"] == 0
+        at += info["consumed"]
+        counts.append((info["n_records"], info["n_bases"]))
+    assert sum(c[0] for c in counts) == len(recs)
+    n_kept, n_bytes = r.kept()
+    assert n_kept == sum(1 for c in counts if c[0]) and n_bytes > len(text)
+    r.rewind()
+    assert r.kept()[0] == n_kept
+    rng = np.random.RandomState(2)
+    got, want, rec_at = [], [], 0
+    k = 0
+    for n_rec, n_bases in counts:
+        if not n_rec:
+            continue
+        info = r.select(k)
+        k += 1
+        assert info["n_records"] == n_rec and info["n_bases"] == n_bases
+        newq = rng.randint(0, 94, n_bases).astype(np.uint8)
+        dq = torch.from_numpy(newq).cuda()
+        torch.cuda.synchronize()
+        r.write(writer, dq.data_ptr())
+        comp_out, n_text = writer.collect()
+        got.append(b"".join(bgzf_blocks(comp_out)))
+        qa = 0
+        for nm, cm, sq, q, pl in recs[rec_at:rec_at + n_rec]:
+            l = len(sq)
+            want.append(b"@" + nm.encode() + b"\n" + sq.encode() + b"\n+" + (cm[1:] if cm else "").encode() + b"\n" + bytes(newq[qa:qa + l] + 33) + b"\n")
+            qa += l
+        rec_at += n_rec
+    assert b"".join(got) == b"".join(want)
+    # giving the kept chunks up: nothing left to select
+    r.keep(False)
+    assert r.kept() == (0, 0)
+    with pytest.raises(Exception):
+        r.select(0)
+    r.close()
+
+
 def test_reader_large_file_rates(writer):
     recs, text = make_records(20000, seed=5)
     text = text * 40                     # 250 MB of text

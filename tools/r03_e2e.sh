@@ -23,9 +23,10 @@ run() {   # name, env..., -- args
 }
 run device
 run device_again
+run device_rescan KBBQ_KEEP_TEXT=0
 run hostzlib_level1 KBBQ_HOST_DEFLATE=1 KBBQ_BGZF_LEVEL=1
 run streaming KBBQ_RESIDENT=0
-a=$(gzip -dc $D/out_device.gz | md5sum); b=$(gzip -dc $D/out_hostzlib_level1.gz | md5sum); c=$(gzip -dc $D/out_streaming.gz | md5sum)
-echo "decompressed md5 device=$a hostzlib=$b streaming=$c" | tee -a $L
-[ "$a" = "$b" ] && [ "$a" = "$c" ] || { echo "OUTPUTS DIFFER" | tee -a $L; exit 1; }
+a=$(gzip -dc $D/out_device.gz | md5sum); b=$(gzip -dc $D/out_hostzlib_level1.gz | md5sum); c=$(gzip -dc $D/out_streaming.gz | md5sum); d=$(gzip -dc $D/out_device_rescan.gz | md5sum)
+echo "decompressed md5 device=$a hostzlib=$b streaming=$c device_rescan=$d" | tee -a $L
+[ "$a" = "$b" ] && [ "$a" = "$c" ] && [ "$a" = "$d" ] || { echo "OUTPUTS DIFFER" | tee -a $L; exit 1; }
 rm -rf $D
