@@ -34,7 +34,7 @@ constexpr int INF_NEAR = INF_RING - 512;     // a match at most this far back st
                                              // bytes ahead of the output position, see the literal and match copies)
 constexpr int INF_TBITS = 10;                // the literal/length table is indexed by the next 10 bits of the stream
 constexpr int INF_WAVES = 1;                 // one wavefront per workgroup
-constexpr int INF_LDS_PER_WAVE = INF_RING + (4 << INF_TBITS) + 1280;
+constexpr int INF_LDS_PER_WAVE = INF_RING + (4 << INF_TBITS) + 1536;
 
 // status codes of a block
 enum : uint32_t { INF_OK = 0, INF_BAD_BLOCK_TYPE = 1, INF_BAD_STORED = 2, INF_BAD_CODE = 3, INF_OVERRUN_IN = 4, INF_OVERRUN_OUT = 5,
@@ -73,6 +73,7 @@ struct InflateLds {
     uint16_t sorted_ll[320];     // literal/length symbols in (length, value) order
     uint16_t sorted_small[64];   // the same of the code-length alphabet, then of the distance alphabet
     uint8_t lens[320];           // code lengths of a dynamic block (literal/length then distance)
+    alignas(16) uint8_t head[INF_FLUSH];      // the block's first line while it is incomplete in HBM (it starts inside it)
 };
 
 // Bounds and sorted symbols of one alphabet from lens[0..n) (LDS).  Uniform control flow; returns false for an
@@ -281,16 +282,20 @@ __global__ void __launch_bounds__(64 * INF_WAVES) k_inflate(InflateArgs A) {
         uint64_t bits_before = 0;                        // bits consumed before the reader was last aimed
         BitReader B;
         B.init(src, src_bytes, lane);
-        // whole lines up to sp leave the ring
+        // Whole lines up to sp leave the ring.  Everything inside the symbol loop is wave-uniform control flow (no lane
+        // ever branches on its own: the compiler then keeps the loop's branches as the plain scalar jumps they are), so
+        // the block's first line -- which starts inside the line, the bytes before belong to the block in front -- is not
+        // written byte by byte here: all 256 bytes of the ring's line are parked in `head` and the block's own part of
+        // them goes out at the block's end.
+        const uint32_t head_end = next_line;             // the first line is [skew, head_end)
+        const bool head_whole = (skew & (INF_FLUSH - 1)) == 0;
         auto flush_lines = [&]() {
             while (sp >= next_line && err == INF_OK) {
                 if (next_line > sp_end + INF_FLUSH) { err = INF_OVERRUN_OUT; break; }
-                if ((fl & (INF_FLUSH - 1)) == 0) {
-                    *reinterpret_cast<uint32_t *>(dst_base + fl + 4 * lane) = *reinterpret_cast<const uint32_t *>(&S.ring[(fl & MASK) + 4 * lane]);
-                } else {
-#pragma clang loop vectorize(disable) unroll(disable)
-                    for (uint32_t o = fl + lane; o < next_line; o += 64) dst_base[o] = S.ring[o & MASK];
-                }
+                const uint32_t line = next_line - INF_FLUSH;      // aligned start of the line that holds fl
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(&S.ring[(line & MASK) + 4 * lane]);
+                if (fl == line) *reinterpret_cast<uint32_t *>(dst_base + line + 4 * lane) = v;
+                else *reinterpret_cast<uint32_t *>(&S.head[4 * lane]) = v;
                 fl = next_line;
                 next_line += INF_FLUSH;
             }
@@ -428,7 +433,7 @@ __global__ void __launch_bounds__(64 * INF_WAVES) k_inflate(InflateArgs A) {
                     B.drop(cl);
                     const int sym = __builtin_amdgcn_readfirstlane((int)S.sorted_ll[ci]);
                     if (sym < 256) {
-                        if (lane == 0) S.ring[sp & MASK] = (uint8_t)sym;
+                        S.ring[sp & MASK] = (uint8_t)sym;      // (every lane the same byte to the same place)
                         ++sp;
                         if (sp >= next_line) { __builtin_amdgcn_wave_barrier(); flush_lines(); if (err != INF_OK) break; }
                         continue;
@@ -478,7 +483,7 @@ __global__ void __launch_bounds__(64 * INF_WAVES) k_inflate(InflateArgs A) {
                             const uint32_t n = min(c, 64u);
                             const uint8_t v = S.ring[(sp + done - c + (uint32_t)lane) & MASK];
                             __builtin_amdgcn_wave_barrier();
-                            if ((uint32_t)lane < n) S.ring[(sp + done + (uint32_t)lane) & MASK] = v;
+                            S.ring[(sp + done + (uint32_t)lane) & MASK] = v;      // (lanes from n on: bytes nobody owns yet)
                             __builtin_amdgcn_wave_barrier();
                             done += n;
                             if (c < 64u) c *= 2;
@@ -486,9 +491,14 @@ __global__ void __launch_bounds__(64 * INF_WAVES) k_inflate(InflateArgs A) {
                     }
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    // (lanes behind the match's length read bytes of this block's own output that may not have arrived yet:
+                    // they land ahead of the output position like every other such byte)
+                    // The block's first line is not in HBM before the block's end: its bytes come from `head`.
+                    const uint32_t head_stop = head_whole ? 0u : head_end;
                     for (int i0 = 0; i0 < len; i0 += 64) {
-                        const int i = i0 + lane;
-                        if (i < len) S.ring[(sp + (uint32_t)i) & MASK] = dst_base[sp - dist + (uint32_t)i];
+                        const uint32_t from = sp - dist + (uint32_t)(i0 + lane);
+                        const uint8_t g = dst_base[from], h = S.head[from & (INF_FLUSH - 1)];
+                        S.ring[(sp + (uint32_t)(i0 + lane)) & MASK] = from < head_stop ? h : g;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -501,8 +511,15 @@ __global__ void __launch_bounds__(64 * INF_WAVES) k_inflate(InflateArgs A) {
         // what is left in the ring
         __builtin_amdgcn_wave_barrier();
         if (err == INF_OK) {
+            // the first line's own bytes: parked in `head` if the line was completed, otherwise still in the ring
+            if (!head_whole) {
+                const uint32_t stop = min(head_end, sp);
+                const bool parked = fl >= head_end;
 #pragma clang loop vectorize(disable) unroll(disable)
-            for (uint32_t o = fl + lane; o < sp; o += 64) dst_base[o] = S.ring[o & MASK];
+                for (uint32_t o = skew + lane; o < stop; o += 64) dst_base[o] = parked ? S.head[o & (INF_FLUSH - 1)] : S.ring[o & MASK];
+            }
+#pragma clang loop vectorize(disable) unroll(disable)
+            for (uint32_t o = max(fl, head_whole ? skew : head_end) + lane; o < sp; o += 64) dst_base[o] = S.ring[o & MASK];
         }
         if (lane == 0) A.status[blk] = err;
         __builtin_amdgcn_wave_barrier();
