@@ -22,13 +22,14 @@
 namespace kbbq {
 namespace dfl {
 
-constexpr int HASH_BITS = 13;                       // 8192 most-recent positions per wave: 16 KB of LDS
+constexpr int HASH_BITS = 12;                       // 4096 most-recent positions per wave: 8 KB of LDS
 constexpr int HASH_SIZE = 1 << HASH_BITS;
 constexpr int DFL_WAVES = 1;                        // wavefronts per workgroup: each works alone (no workgroup barrier anywhere), 18 KB of LDS
 constexpr int MIN_TAKE = 4;                         // shortest match the 4-byte hash can find
 constexpr uint32_t SLOT_BYTES = 65536 + 64;         // one finished block per slot; its bytes start at SLOT_SHIFT so that
 constexpr uint32_t SLOT_SHIFT = 6;                  // the DEFLATE stream (behind the 18-byte header) is 8-byte aligned
 constexpr uint32_t TOKENS_PER_WAVE = 65536;
+constexpr int PF = 4;                               // steps of 64 positions whose loads are in flight ahead of the one worked on
 
 struct DeflateArgs {
     const uint8_t *payload;     // n bytes (+ 16 readable bytes behind them)
@@ -37,7 +38,15 @@ struct DeflateArgs {
     uint8_t *slots;             // n_blocks x SLOT_BYTES, zeroed
     uint32_t *sizes;            // n_blocks: bytes of every finished block
     uint32_t *tokens;           // per wavefront of the grid: TOKENS_PER_WAVE words
+#ifdef KBBQ_DFL_PROFILE
+    unsigned long long *prof;   // (tools/deflate_probe.py, a build of its own) cycles per phase, summed over the wavefronts
+#endif
 };
+#ifdef KBBQ_DFL_PROFILE
+#define DFL_MARK(i) do { const unsigned long long _t = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&A.prof[i], _t - prof_t); prof_t = _t; } while (0)
+#else
+#define DFL_MARK(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ uint64_t load8(const uint8_t *p) {
     uint64_t v;
@@ -66,11 +75,13 @@ struct WaveLds {
             uint16_t order[N_LL];
             uint32_t w[N_LL];
             uint16_t runs[N_LL + N_D];
+            uint8_t all[N_LL + N_D];
         } hs;
     } u;
     uint32_t ll_freq[N_LL];
     uint32_t d_freq[N_D];
     BlockCodes codes;
+    uint32_t crc_tab[256];      // CRC-32 of one byte (reflected polynomial 0xEDB88320), filled once per launch
 };
 
 __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
@@ -81,6 +92,10 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
     const uint32_t wave = blockIdx.x * DFL_WAVES + wv, n_waves = gridDim.x * DFL_WAVES;
     uint32_t *tokens = A.tokens + (size_t)wave * TOKENS_PER_WAVE;
     const uint64_t lane_lt = (1ull << lane) - 1;
+    for (int i = lane; i < 256; i += 64) S.crc_tab[i] = crc_table_entry((uint32_t)i);
+    int xq_for = -1;            // the piece length the two factors below belong to
+    uint32_t xq = 0, xq4 = 0;   // x^(8 q), x^(32 q) mod P
+    __builtin_amdgcn_wave_barrier();
     for (uint32_t blk = wave; blk < A.n_blocks; blk += n_waves) {
         const uint8_t *in = A.payload + (uint64_t)blk * BGZF_PAYLOAD;
         const int len = (int)min((uint64_t)BGZF_PAYLOAD, A.n - (uint64_t)blk * BGZF_PAYLOAD);
@@ -88,124 +103,248 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
         uint8_t *block = slot + SLOT_SHIFT;                    // BGZF header here, the DEFLATE stream 18 bytes on
         unsigned long long *body64 = reinterpret_cast<unsigned long long *>(block + BGZF_HEAD);
 
+#ifdef KBBQ_DFL_PROFILE
+        unsigned long long prof_t = __builtin_readcyclecounter();
+#endif
         // ---- reset
         for (int i = lane; i < HASH_SIZE; i += 64) S.u.htab[i] = 0xFFFFu;
         for (int i = lane; i < N_LL; i += 64) S.ll_freq[i] = 0;
         if (lane < N_D) S.d_freq[lane] = 0;
         __builtin_amdgcn_wave_barrier();
 
-        // ---- CRC-32: 64 slices, one per lane, chained below
-        const int slice = (len + 63) / 64;
-        uint32_t crc_r = 0;
-        int my_len = 0;
+        DFL_MARK(0);
+        // ---- CRC-32: 256 pieces of q bytes, four per lane (four independent table walks keep the LDS pipe busy), every
+        // piece's register started at 0; the pieces are joined below: running B behind A is  r_AB = r_A * x^(8|B|) + r_B
+        // in GF(2)[x] mod P (crc_chain), an associative rule, so a lane folds its four and the wave reduces in six steps
+        const int q = (len + 255) / 256;
+        uint32_t crc_r = 0, crc_x = 0x80000000u;      // the lane's four pieces as one: register from 0, x^(8 * its bytes)
         {
-            const int a = min(len, lane * slice), b = min(len, a + slice);
-            my_len = b - a;
-            int i = a;
-            for (; i + 8 <= b; i += 8) {
-                uint64_t v = load8(in + i);
+            if (q != xq_for) { xq = crc_xpow8((uint64_t)q); xq4 = crc_mulmod(xq, xq); xq4 = crc_mulmod(xq4, xq4); xq_for = q; }
+            int a[4], n[4];
+            uint32_t c[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    crc_r ^= (uint32_t)(v & 0xFF);
-                    v >>= 8;
+            for (int j = 0; j < 4; ++j) { a[j] = min(len, (4 * lane + j) * q); n[j] = min(len, a[j] + q) - a[j]; }
+            int i = 0;
+            for (; i + 8 <= n[3]; i += 8) {      // (n[0] >= n[1] >= n[2] >= n[3])
+                uint64_t v[4];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) crc_r = (crc_r >> 1) ^ (0xEDB88320u & (0u - (crc_r & 1u)));
+                for (int j = 0; j < 4; ++j) v[j] = load8(in + a[j] + i);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { c[j] = S.crc_tab[(c[j] ^ (uint32_t)(v[j] >> (8 * k))) & 0xFFu] ^ (c[j] >> 8); }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                for (int t = i; t < n[j]; ++t) c[j] = S.crc_tab[(c[j] ^ in[a[j] + t]) & 0xFFu] ^ (c[j] >> 8);
+            // the lane's fold; only the block's last piece is shorter than q (and the ones behind it empty)
+            if (__ballot(n[3] != q) == 0) {
+                crc_r = crc_chain(crc_chain(crc_chain(c[0], c[1], xq), c[2], xq), c[3], xq);
+                crc_x = xq4;
+            } else {
+                crc_r = c[0];
+                crc_x = n[0] == q ? xq : crc_xpow8((uint64_t)n[0]);
+#pragma unroll
+                for (int j = 1; j < 4; ++j) {
+                    const uint32_t xj = n[j] == q ? xq : crc_xpow8((uint64_t)n[j]);
+                    crc_r = crc_chain(crc_r, c[j], xj);
+                    crc_x = crc_mulmod(crc_x, xj);
                 }
             }
-            for (; i < b; ++i) {
-                crc_r ^= in[i];
+        }
+
+        DFL_MARK(1);
+        // ---- LZ77 in three sweeps over the block, 64 positions per step.  A sweep never waits for a load that depends on
+        // another load of the same step's chain more than once, and what it needs next is already on its way: the text is
+        // read from HBM/L2, and a wave that followed hash table -> candidate -> text in one loop spent its time in those
+        // round trips (round 3: 1.2 ms per block before).  The sweeps hand their results on in the
+        // wave's token array (one word per position, overwritten in place).
+        // Sweep 1: the hash table.  tokens[p] = the most recent earlier position with p's hash (0xFFFF: none).  The text of
+        // four steps ahead is on its way while a step is worked on (a load from HBM takes longer than a step); the loads
+        // are unconditional (clamped addresses, steps past the end run with every lane idle) so that a loaded register is
+        // not touched before its step comes: a conditional load ends in a copy right behind it, and the wait with it.
+        {
+            uint64_t ahead[PF];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) crc_r = (crc_r >> 1) ^ (0xEDB88320u & (0u - (crc_r & 1u)));
+            for (int u = 0; u < PF; ++u) ahead[u] = load8(in + min(64 * u + lane, len));
+            for (int b1 = 0; b1 < len; b1 += 64 * PF) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int p = b1 + 64 * u + lane;
+                    const uint64_t cur = ahead[u];
+                    ahead[u] = load8(in + min(p + 64 * PF, len));
+                    const bool hashed = p + 4 <= len;
+                    const uint32_t h = hash4((uint32_t)cur);
+                    uint32_t cand = 0xFFFFu;
+                    if (hashed) { cand = S.u.htab[h]; S.u.htab[h] = (uint16_t)p; }
+                    __builtin_amdgcn_wave_barrier();
+                    // of several lanes with one hash the highest position stays
+                    for (;;) {
+                        const bool lose = hashed && S.u.htab[h] < (uint16_t)p;
+                        if (!__ballot(lose)) break;
+                        if (lose) S.u.htab[h] = (uint16_t)p;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    if (p < len) tokens[p] = cand;
+                }
             }
         }
-        const uint32_t my_xpow = crc_xpow8((uint64_t)my_len);
-
-        // ---- LZ77, 64 positions per step
+        DFL_MARK(2);
+        // Sweep 2: how far the candidate matches, four steps at a time; the positions' own text, candidate and the byte
+        // before them come a round ahead, the candidates' text goes out together at the top of the round.
+        // tokens[p] = length << 16 | distance, 0: no match.
+        {
+            uint64_t cur_n[PF];
+            uint32_t cand_n[PF];
+            uint32_t prev_n[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int p = min(64 * u + lane, len);
+                cur_n[u] = load8(in + p);
+                cand_n[u] = tokens[min(p, (int)TOKENS_PER_WAVE - 1)];
+                prev_n[u] = in[max(p, 1) - 1];
+            }
+            for (int b0 = 0; b0 < len; b0 += 64 * PF) {
+                int cand[PF];
+                uint64_t cur[PF], old[PF];
+                uint32_t prev[PF];
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int p = b0 + 64 * u + lane;
+                    cur[u] = cur_n[u];
+                    prev[u] = prev_n[u];
+                    cand[u] = (int)cand_n[u];
+                    if (!(p + 4 <= len && cand[u] != 0xFFFF && p - cand[u] <= MAX_DIST)) cand[u] = -1;
+                    old[u] = load8(in + max(cand[u], 0));
+                }
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int pn = min(b0 + 64 * (u + PF) + lane, len);
+                    cur_n[u] = load8(in + pn);
+                    cand_n[u] = tokens[min(pn, (int)TOKENS_PER_WAVE - 1)];
+                    prev_n[u] = in[pn - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int p = b0 + 64 * u + lane;
+                    const bool hashed = p + 4 <= len;
+                    int L = 0, D = 0;
+                    const int lim = min((int)MAX_MATCH, len - p);
+                    if (cand[u] >= 0) {
+                        const uint64_t x = cur[u] ^ old[u];
+                        int n = x ? (int)(__builtin_ctzll(x) >> 3) : 8 + match_length(in, cand[u] + 8, p + 8, max(0, lim - 8));
+                        n = min(n, lim);
+                        if (n >= MIN_TAKE) { L = n; D = p - cand[u]; }
+                    }
+                    // a run of one byte (the candidate the table cannot hold: the position just before, inside this step)
+                    if (hashed && p > 0 && (uint8_t)prev[u] == (uint8_t)cur[u]) {
+                        const uint64_t rep = (uint64_t)(uint8_t)cur[u] * 0x0101010101010101ull;
+                        const uint64_t x = cur[u] ^ rep;
+                        int n = x ? (int)(__builtin_ctzll(x) >> 3) : 8 + match_length(in, p + 7, p + 8, max(0, lim - 8));
+                        n = min(n, lim);
+                        if (n >= MIN_TAKE && n > L) { L = n; D = 1; }
+                    }
+                    if (p < len) tokens[p] = ((uint32_t)L << 16) | (uint32_t)D;
+                }
+            }
+        }
+        DFL_MARK(3);
+        // Sweep 3: greedy parse with one step of lazy evaluation (the positions where a token starts, and which are
+        // matches); the tokens are packed to the front of the same array, behind the positions already read.
         int next_free = 0;       // first position not covered by a token yet
         uint32_t n_tok = 0;
-        for (int b0 = 0; b0 < len; b0 += 64) {
-            const int p = b0 + lane;
-            const bool in_block = p < len;
-            const bool hashed = p + 4 <= len;
-            uint64_t cur = 0;
-            uint32_t h = 0;
-            int L = 0, D = 0;
-            if (in_block) cur = load8(in + p);
-            if (hashed) {
-                h = hash4((uint32_t)cur);
-                const int cand = S.u.htab[h];
-                const int lim = min((int)MAX_MATCH, len - p);
-                if (cand != 0xFFFF && p - cand <= MAX_DIST) {
-                    const int n = match_length(in, cand, p, lim);
-                    if (n >= MIN_TAKE) { L = n; D = p - cand; }
-                }
-                // a run of one byte (the candidate the table cannot hold: the position just before, inside this step)
-                if (p > 0 && in[p - 1] == (uint8_t)cur) {
-                    const int n = match_length(in, p - 1, p, lim);
-                    if (n >= MIN_TAKE && n > L) { L = n; D = 1; }
+#ifdef KBBQ_DFL_PROFILE
+        unsigned long long prof_parse = 0, prof_emit = 0;
+#endif
+        {
+            uint32_t ld_ahead[PF], byte_ahead[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int p = min(64 * u + lane, len);
+                ld_ahead[u] = tokens[min(p, (int)TOKENS_PER_WAVE - 1)];
+                byte_ahead[u] = in[p];
+            }
+            for (int b1 = 0; b1 < len; b1 += 64 * PF) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int b0 = b1 + 64 * u;
+                    const int p = b0 + lane;
+                    const bool in_block = p < len;
+                    const uint32_t ld = ld_ahead[u];
+                    const uint8_t byte = (uint8_t)byte_ahead[u];
+                    // (the tokens of this step are written below the positions read so far: never where a step ahead was or
+                    // will be read; the loads are unconditional, see sweep 1)
+                    {
+                        const int pn = min(p + 64 * PF, len);
+                        ld_ahead[u] = tokens[min(pn, (int)TOKENS_PER_WAVE - 1)];
+                        byte_ahead[u] = in[pn];
+                    }
+                    const int L = in_block ? (int)(ld >> 16) : 0, D = (int)(ld & 0xFFFFu);      // (past the end: whatever the clamped load found)
+#ifdef KBBQ_DFL_PROFILE
+                    const unsigned long long pt0 = __builtin_readcyclecounter();
+#endif
+                    // Every lane first says where the next token would start if one started at its position: behind its match,
+                    // or one byte on when it has none or the position after it has a longer one (one step of lazy evaluation;
+                    // lane 63 cannot see the next step's first position and takes what it has).  The walk from the first free
+                    // position is then one lane read per token.
+                    const uint64_t valid = __ballot(in_block);
+                    const int L1 = __shfl_down(L, 1);
+                    const bool take = L >= MIN_TAKE && !(lane < 63 && L1 > L);
+                    const int nxt = lane + (take ? L : 1);
+                    const uint64_t takes = __ballot(take);
+                    uint64_t starts = 0;
+                    int rel = next_free - b0;
+                    while (rel < 64) {
+                        starts |= 1ull << rel;
+                        rel = __builtin_amdgcn_readlane(nxt, rel);
+                    }
+                    starts &= valid;
+                    const uint64_t taken = starts & takes;
+                    next_free = b0 + rel;
+#ifdef KBBQ_DFL_PROFILE
+                    const unsigned long long pt1 = __builtin_readcyclecounter();
+                    prof_parse += pt1 - pt0;
+#endif
+                    const bool start = (starts >> lane) & 1, is_match = (taken >> lane) & 1;
+                    if (start) {
+                        uint32_t t;
+                        if (is_match) {
+                            t = token_match(L, D);
+                            int ls, e, v, ds;
+                            length_symbol(L, ls, e, v);
+                            distance_symbol(D, ds, e, v);
+                            atomicAdd(&S.ll_freq[ls], 1u);
+                            atomicAdd(&S.d_freq[ds], 1u);
+                        } else {
+                            t = token_literal(byte);
+                            atomicAdd(&S.ll_freq[byte], 1u);
+                        }
+                        tokens[n_tok + (uint32_t)__popcll(starts & lane_lt)] = t;
+                    }
+                    n_tok += (uint32_t)__popcll(starts);
+#ifdef KBBQ_DFL_PROFILE
+                    prof_emit += __builtin_readcyclecounter() - pt1;
+#endif
                 }
             }
-            // the step's positions go into the table; of several lanes with one hash the highest position stays
-            if (hashed) S.u.htab[h] = (uint16_t)p;
-            __builtin_amdgcn_wave_barrier();
-            for (;;) {
-                const bool lose = hashed && S.u.htab[h] < (uint16_t)p;
-                if (!__ballot(lose)) break;
-                if (lose) S.u.htab[h] = (uint16_t)p;
-                __builtin_amdgcn_wave_barrier();
-            }
-            // greedy parse with one step of lazy evaluation: the positions where a token starts, and which are matches
-            const uint64_t valid = __ballot(in_block);
-            const uint64_t mm = __ballot(L >= MIN_TAKE);
-            uint64_t starts = 0, taken = 0;
-            int rel = next_free - b0;
-            while (rel < 64) {
-                const uint64_t from = ~0ull << rel;
-                const uint64_t ahead = mm & from;
-                if (!ahead) { starts |= from & valid; rel = 64; break; }
-                const int m = (int)__builtin_ctzll(ahead);
-                starts |= from & ((1ull << m) - 1);              // literals up to the match
-                const int Lm = __builtin_amdgcn_readlane(L, m);
-                if (m + 1 < 64 && ((mm >> (m + 1)) & 1) && __builtin_amdgcn_readlane(L, m + 1) > Lm) {
-                    starts |= 1ull << m;                         // a longer match starts one byte on: this byte is a literal
-                    rel = m + 1;
-                    continue;
-                }
-                starts |= 1ull << m;
-                taken |= 1ull << m;
-                rel = m + Lm;
-            }
-            next_free = b0 + rel;
-            const bool start = (starts >> lane) & 1, is_match = (taken >> lane) & 1;
-            if (start) {
-                uint32_t t;
-                if (is_match) {
-                    t = token_match(L, D);
-                    int ls, e, v, ds;
-                    length_symbol(L, ls, e, v);
-                    distance_symbol(D, ds, e, v);
-                    atomicAdd(&S.ll_freq[ls], 1u);
-                    atomicAdd(&S.d_freq[ds], 1u);
-                } else {
-                    t = token_literal((uint8_t)cur);
-                    atomicAdd(&S.ll_freq[(uint8_t)cur], 1u);
-                }
-                tokens[n_tok + (uint32_t)__popcll(starts & lane_lt)] = t;
-            }
-            n_tok += (uint32_t)__popcll(starts);
         }
+#ifdef KBBQ_DFL_PROFILE
+        if (lane == 0) { atomicAdd(&A.prof[8], prof_parse); atomicAdd(&A.prof[9], prof_emit); }
+#endif
         __builtin_amdgcn_wave_barrier();
 
+        DFL_MARK(4);
         // ---- codes and header (lane 0; the scratch lies over the hash table, which is done with)
         for (int i = lane; i < HEAD_BYTES; i += 64) S.u.hs.head[i] = 0;
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
             S.ll_freq[256] += 1;      // end of block
-            build_block_codes(S.ll_freq, S.d_freq, S.codes, S.u.hs.head, S.u.hs.order, S.u.hs.w, S.u.hs.runs);
+            build_block_codes(S.ll_freq, S.d_freq, S.codes, S.u.hs.head, S.u.hs.order, S.u.hs.w, S.u.hs.runs, S.u.hs.all);
         }
         __builtin_amdgcn_wave_barrier();
         const uint32_t head_bits = S.codes.head_bits;
 
+        DFL_MARK(5);
         // ---- how long is the dynamic form?  counts x code lengths (+ extra bits) over the two alphabets; the end-of-block
         // symbol is in the counts
         uint64_t my_bits = 0;
@@ -227,20 +366,28 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
                 if (v) atomicOr(&body64[i], (unsigned long long)v);
             }
             uint64_t base = head_bits;
-            for (uint32_t i0 = 0; i0 < n_tok; i0 += 64) {
-                const uint32_t i = i0 + lane;
-                uint64_t v = 0;
-                int nb = 0;
-                if (i < n_tok) token_bits(tokens[i], S.codes, v, nb);
-                int incl = nb;
-                for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
-                const uint64_t at = base + (uint64_t)(incl - nb);
-                if (nb) {
-                    const uint32_t word = (uint32_t)(at >> 6), sh = (uint32_t)(at & 63);
-                    atomicOr(&body64[word], (unsigned long long)(v << sh));
-                    if (sh + (uint32_t)nb > 64) atomicOr(&body64[word + 1], (unsigned long long)(v >> (64 - sh)));
+            uint32_t tok_ahead[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) tok_ahead[u] = tokens[min(64u * u + lane, TOKENS_PER_WAVE - 1)];
+            for (uint32_t i1 = 0; i1 < n_tok; i1 += 64 * PF) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const uint32_t i = i1 + 64 * u + lane;
+                    const uint32_t tok = tok_ahead[u];
+                    tok_ahead[u] = tokens[min(i + 64 * PF, TOKENS_PER_WAVE - 1)];
+                    uint64_t v = 0;
+                    int nb = 0;
+                    if (i < n_tok) token_bits(tok, S.codes, v, nb);
+                    int incl = nb;
+                    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+                    const uint64_t at = base + (uint64_t)(incl - nb);
+                    if (nb) {
+                        const uint32_t word = (uint32_t)(at >> 6), sh = (uint32_t)(at & 63);
+                        atomicOr(&body64[word], (unsigned long long)(v << sh));
+                        if (sh + (uint32_t)nb > 64) atomicOr(&body64[word + 1], (unsigned long long)(v >> (64 - sh)));
+                    }
+                    base += (uint64_t)__shfl(incl, 63);
                 }
-                base += (uint64_t)__shfl(incl, 63);
             }
             if (lane == 0) {
                 const uint64_t v = S.codes.ll_code[256];
@@ -260,13 +407,15 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
             for (int i = lane; i < len; i += 64) body[5 + i] = in[i];
             body_bytes = stored_bytes;
         }
+        DFL_MARK(6);
         // ---- CRC chain, framing
-        uint32_t reg = 0xFFFFFFFFu;
-        for (int l = 0; l < 64; ++l) {
-            const uint32_t r = __builtin_amdgcn_readlane(crc_r, l), x = __builtin_amdgcn_readlane(my_xpow, l);
-            const int n = __builtin_amdgcn_readlane(my_len, l);
-            if (n) reg = crc_chain(reg, r, x);
+        // lanes 2o apart join their runs of o lanes: (r, x) <- (r * x' + r', x * x'); lane 0 ends up with the whole block
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t r2 = __shfl_down(crc_r, o), x2 = __shfl_down(crc_x, o);
+            crc_r = crc_chain(crc_r, r2, x2);
+            crc_x = crc_mulmod(crc_x, x2);
         }
+        const uint32_t reg = crc_chain(0xFFFFFFFFu, (uint32_t)__builtin_amdgcn_readfirstlane((int)crc_r), (uint32_t)__builtin_amdgcn_readfirstlane((int)crc_x));
         // (atomic / plain stores of this wave to its own slot: complete before the kernel ends, nobody else reads them earlier)
         if (lane == 0) {
             const uint32_t total = BGZF_HEAD + body_bytes + BGZF_TAIL;
@@ -276,6 +425,7 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
         // (the trailer may share an 8-byte word with the last bits of the stream: a byte store and an atomic OR of zeros
         // into those bytes give the same word in either order)
         if (lane == 0) bgzf_trailer(block + BGZF_HEAD + body_bytes, reg ^ 0xFFFFFFFFu, (uint32_t)len);
+        DFL_MARK(7);
     }
 }
 

@@ -65,6 +65,9 @@ struct kbbq_bgzf {
     Submission sub[2];
     int head = 0, tail = 0, in_flight = 0;
     Buf tokens;
+#ifdef KBBQ_DFL_PROFILE
+    void *prof = nullptr;
+#endif
     int grid = 0;
     double ms_format = 0, ms_deflate = 0, ms_gather = 0;
 };
@@ -81,11 +84,13 @@ int launch_deflate(kbbq_bgzf *z, Submission &s) {
     if ((rc = s.out.reserve(bound))) return rc;
     if ((rc = s.h_out.reserve(bound))) return rc;
     if ((rc = s.h_meta.reserve(64))) return rc;
-    // one wavefront per block in flight; the chip holds 8 of these workgroups per CU (18 KB of LDS each)
+    // one wavefront per block in flight, as many as stay resident (11 KB of LDS, 152 registers: 12 per CU)
     if (!z->grid) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, z->device));
-        z->grid = std::max(1, prop.multiProcessorCount) * 8;
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_deflate, 64 * DFL_WAVES, 0));
+        z->grid = std::max(1, prop.multiProcessorCount) * std::max(1, per_cu);
     }
     const int grid = (int)std::min<uint32_t>(s.n_blocks, (uint32_t)z->grid);
     if ((rc = z->tokens.reserve((size_t)z->grid * DFL_WAVES * TOKENS_PER_WAVE * 4))) return rc;
@@ -98,6 +103,10 @@ int launch_deflate(kbbq_bgzf *z, Submission &s) {
     A.slots = (uint8_t *)s.slots.p;
     A.sizes = (uint32_t *)s.sizes.p;
     A.tokens = (uint32_t *)z->tokens.p;
+#ifdef KBBQ_DFL_PROFILE
+    if (!z->prof && hipMalloc(&z->prof, 16 * 8) == hipSuccess) (void)hipMemset(z->prof, 0, 16 * 8);
+    A.prof = (unsigned long long *)z->prof;
+#endif
     hipLaunchKernelGGL(k_deflate, dim3(grid), dim3(64 * DFL_WAVES), 0, z->st, A);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s.t2, z->st));
@@ -285,6 +294,17 @@ int kbbq_bgzf_collect(kbbq_bgzf *z, const uint8_t **blocks, uint64_t *n_bytes, u
     return KBBQ_OK;
 }
 
+#ifdef KBBQ_DFL_PROFILE
+// (a build of its own for tools/deflate_probe.py: cycles per phase of k_deflate, summed over the wavefronts)
+int kbbq_bgzf_debug_profile(kbbq_bgzf *z, uint64_t *out) {
+    if (!z || !out || !z->prof) return fail(KBBQ_EINVAL, "no profile");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, z->prof, 16 * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(z->prof, 0, 16 * 8));
+    return KBBQ_OK;
+}
+#endif
+
 const uint8_t *kbbq_bgzf_eof_block(void) {
     static const uint8_t eof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43,
                                     0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -313,6 +333,8 @@ struct kbbq_fastq_reader {
     Buf idx_u32, idx_second, base_sz, text_sz, flags;      // record index (FastqIndex)
     Buf carry;                              // text of the record the previous chunk's end cut (device)
     Buf h_small;                            // page-locked scratch for small read-backs
+    Buf seq_text, counter;                  // scratch of kbbq_fastq_reader_batch (the chunk's sequence lines back to back)
+    unsigned inflate_grid = 0;
     uint64_t carry_bytes = 0;
     // the current chunk
     uint64_t text_bytes = 0, n_records = 0, n_bases = 0;
@@ -414,7 +436,7 @@ void kbbq_fastq_reader_destroy(kbbq_fastq_reader *r) {
     KbbqDeviceGuard guard(r->device);
     if (r->st) (void)hipStreamSynchronize(r->st);
     Buf *all[] = {&r->comp, &r->text, &r->status, &r->blk_meta, &r->h_meta, &r->tile_counts, &r->tile_sums, &r->nl_pos, &r->idx_u32,
-                  &r->idx_second, &r->base_sz, &r->text_sz, &r->flags, &r->carry, &r->h_small};
+                  &r->idx_second, &r->base_sz, &r->text_sz, &r->flags, &r->carry, &r->h_small, &r->seq_text, &r->counter};
     for (Buf *b : all) b->release();
     release_kept(r);
     hipEvent_t evs[] = {r->t0, r->t1, r->t2};
@@ -565,13 +587,16 @@ int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uin
         A.out = (uint8_t *)r->text.p;
         A.n_blocks = nb;
         A.status = (uint32_t *)r->status.p;
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, r->device));
         // as many wavefronts as stay resident (13 KB of LDS each): blocks are handed out round-robin, a second round of
         // workgroups would only queue behind the first
-        int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate, 64 * INF_WAVES, 0));
-        const unsigned grid = std::min<unsigned>(nb, (unsigned)std::max(1, prop.multiProcessorCount) * (unsigned)std::max(1, per_cu));
+        if (!r->inflate_grid) {
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, r->device));
+            int per_cu = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate, 64 * INF_WAVES, 0));
+            r->inflate_grid = (unsigned)std::max(1, prop.multiProcessorCount) * (unsigned)std::max(1, per_cu);
+        }
+        const unsigned grid = std::min<unsigned>(nb, r->inflate_grid);
         hipLaunchKernelGGL(k_inflate, dim3(grid), dim3(64 * INF_WAVES), 0, r->st, A);
         HIP_TRY(hipGetLastError());
     }
@@ -667,8 +692,12 @@ int kbbq_fastq_reader_batch(kbbq_fastq_reader *r, kbbq_reads *dev) {
     dev->n_reads = n;
     dev->n_bases = nbases;
     dev->on_device = 1;
-    void *b = nullptr, *m = nullptr, *q = nullptr, *oc = nullptr, *off = nullptr, *fl = nullptr, *seq_text = nullptr, *cnt = nullptr;
-    auto release = [&]() { void *all[] = {b, m, q, oc, off, fl, seq_text, cnt}; for (void *x : all) (void)hipFree(x); };
+    void *b = nullptr, *m = nullptr, *q = nullptr, *oc = nullptr, *off = nullptr, *fl = nullptr;
+    auto release = [&]() { void *all[] = {b, m, q, oc, off, fl}; for (void *x : all) (void)hipFree(x); };
+    int rc0;
+    if ((rc0 = r->seq_text.reserve(nbases + 64))) return rc0;
+    if ((rc0 = r->counter.reserve(64))) return rc0;
+    void *seq_text = r->seq_text.p, *cnt = r->counter.p;
 #define RB_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { release(); return fail(_e == hipErrorOutOfMemory ? KBBQ_ENOMEM : KBBQ_EIO, "%s: %s", #expr, hipGetErrorString(_e)); } } while (0)
     const uint64_t words = nbases / 64 + 1;
     RB_TRY(hipMalloc(&b, (2 * words + 2) * 8));
@@ -676,8 +705,6 @@ int kbbq_fastq_reader_batch(kbbq_fastq_reader *r, kbbq_reads *dev) {
     RB_TRY(hipMalloc(&oc, (words + 2) * 8));
     RB_TRY(hipMalloc(&q, nbases + 16));
     RB_TRY(hipMalloc(&fl, n));
-    RB_TRY(hipMalloc(&seq_text, nbases + 64));
-    RB_TRY(hipMalloc(&cnt, 8));
     const bool uniform = r->longest == r->shortest;
     if (!uniform) RB_TRY(hipMalloc(&off, (n + 1) * 8));
     RB_TRY(hipMemsetAsync(cnt, 0, 8, r->st));
@@ -696,8 +723,6 @@ int kbbq_fastq_reader_batch(kbbq_fastq_reader *r, kbbq_reads *dev) {
     RB_TRY(hipMemcpyAsync(&n_off, cnt, 8, hipMemcpyDeviceToHost, r->st));
     RB_TRY(hipStreamSynchronize(r->st));
 #undef RB_TRY
-    (void)hipFree(seq_text);
-    (void)hipFree(cnt);
     if (!n_off) { (void)hipFree(oc); oc = nullptr; }
     dev->bases = (const uint64_t *)b;
     dev->nmask = (const uint64_t *)m;

@@ -63,7 +63,8 @@ size_t encode_block(const uint8_t *in, size_t len, uint8_t *out) {
     memset(head, 0, sizeof head);
     uint16_t order[N_LL], runs[N_LL + N_D];
     uint32_t w[N_LL];
-    build_block_codes(ll_freq.data(), d_freq.data(), B, head, order, w, runs);
+    uint8_t all[N_LL + N_D];
+    build_block_codes(ll_freq.data(), d_freq.data(), B, head, order, w, runs, all);
     uint64_t bits = B.head_bits;
     for (uint32_t t : tokens) { uint64_t v; int nb; token_bits(t, B, v, nb); bits += (uint64_t)nb; }
     bits += B.ll_len[256];
@@ -73,9 +74,10 @@ size_t encode_block(const uint8_t *in, size_t len, uint8_t *out) {
     if (dyn_bytes < stored_bytes && dyn_bytes + BGZF_HEAD + BGZF_TAIL <= (size_t)BGZF_MAX_BLOCK) {
         memset(body, 0, dyn_bytes);
         memcpy(body, head, (B.head_bits + 7) / 8);
-        BitSink s = {body, B.head_bits};
+        BitSink s = {body, B.head_bits, body[B.head_bits >> 3], (int)(B.head_bits & 7)};      // goes on inside the header's last byte
         for (uint32_t t : tokens) { uint64_t v; int nb; token_bits(t, B, v, nb); s.put(v, nb); }
         s.put(B.ll_code[256], B.ll_len[256]);
+        s.finish();
         body_bytes = dyn_bytes;
     } else {      // stored: BFINAL = 1, BTYPE = 00, LEN, ~LEN, the bytes
         body[0] = 1;

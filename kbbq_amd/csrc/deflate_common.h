@@ -167,11 +167,16 @@ DFL_HD int cl_order(int i) {
 // A little-endian bit writer over a zeroed byte buffer (one lane, or the host)
 struct BitSink {
     uint8_t *p;
-    uint64_t bitpos;
-    DFL_HD void put(uint64_t value, int nbits) {
-        for (int i = 0; i < nbits; ++i, ++bitpos)
-            if ((value >> i) & 1) p[bitpos >> 3] |= (uint8_t)(1u << (bitpos & 7));
+    uint64_t bitpos;      // bits put so far (whole bytes of them are in p, the rest in acc)
+    uint64_t acc;
+    int n_acc;            // < 8 between calls
+    DFL_HD void put(uint64_t value, int nbits) {      // nbits <= 56; bits of value above nbits are zero
+        acc |= value << n_acc;
+        n_acc += nbits;
+        bitpos += (uint64_t)nbits;
+        while (n_acc >= 8) { p[(bitpos - (uint64_t)n_acc) >> 3] = (uint8_t)acc; acc >>= 8; n_acc -= 8; }
     }
+    DFL_HD void finish() { if (n_acc) p[(bitpos - (uint64_t)n_acc) >> 3] = (uint8_t)acc; }      // the last, partial byte (zero bits above)
 };
 
 // Everything one dynamic block needs beside its tokens: code lengths and codes of the two alphabets and the header
@@ -184,9 +189,10 @@ struct BlockCodes {
 };
 constexpr int HEAD_BYTES = 640;
 
-// scratch: order[N_LL], w[N_LL], runs[N_LL + N_D]
+// scratch: order[N_LL], w[N_LL], runs[N_LL + N_D], all[N_LL + N_D] (on the device all of it in LDS: an array of the
+// function's own would live in scratch memory, a trip to HBM per access)
 DFL_HD void build_block_codes(const uint32_t *ll_freq, const uint32_t *d_freq, BlockCodes &B, uint8_t *head, uint16_t *order, uint32_t *w,
-                              uint16_t *runs) {
+                              uint16_t *runs, uint8_t *all) {
     huffman_lengths(ll_freq, N_LL, MAX_BITS, B.ll_len, order, w);
     huffman_lengths(d_freq, N_D, MAX_BITS, B.d_len, order, w);
     canonical_codes(B.ll_len, N_LL, MAX_BITS, B.ll_code);
@@ -194,7 +200,6 @@ DFL_HD void build_block_codes(const uint32_t *ll_freq, const uint32_t *d_freq, B
     int n_ll = N_LL, n_d = N_D;
     while (n_ll > 257 && B.ll_len[n_ll - 1] == 0) --n_ll;
     while (n_d > 1 && B.d_len[n_d - 1] == 0) --n_d;
-    uint8_t all[N_LL + N_D];
     for (int i = 0; i < n_ll; ++i) all[i] = B.ll_len[i];
     for (int i = 0; i < n_d; ++i) all[n_ll + i] = B.d_len[i];
     const int n_runs = code_length_runs(all, n_ll + n_d, runs);
@@ -207,7 +212,7 @@ DFL_HD void build_block_codes(const uint32_t *ll_freq, const uint32_t *d_freq, B
     canonical_codes(cl_len, N_CL, MAX_CL_BITS, cl_code);
     int n_cl = N_CL;
     while (n_cl > 4 && cl_len[cl_order(n_cl - 1)] == 0) --n_cl;
-    BitSink s = {head, 0};
+    BitSink s = {head, 0, 0, 0};
     s.put(1, 1);      // BFINAL: a BGZF block is one complete DEFLATE stream
     s.put(2, 2);      // BTYPE = dynamic Huffman
     s.put((uint32_t)(n_ll - 257), 5);
@@ -220,6 +225,7 @@ DFL_HD void build_block_codes(const uint32_t *ll_freq, const uint32_t *d_freq, B
         const int eb = cl_extra_bits(sym);
         if (eb) s.put((uint32_t)(runs[i] >> 8), eb);
     }
+    s.finish();
     B.head_bits = (uint32_t)s.bitpos;
 }
 

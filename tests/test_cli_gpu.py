@@ -386,6 +386,30 @@ def test_cli_output_does_not_depend_on_the_batch_size(tmp_path):
         assert bamutil.bgzf_decompress(out) == one_b, env
 
 
+def test_cli_output_into_a_file_is_written_in_ranges(tmp_path):
+    """Standard output that is a regular file gets its blocks by pwrite from several threads (kbbq_cli.cc:
+    DeviceBgzfWriter::put); the file must hold the bytes a pipe receives, behind whatever the file held before, and a file
+    opened for appending or KBBQ_WRITE_THREADS=1 takes the sequential writes."""
+    d, names, n_rg = named_dataset(seed=515, genome_len=30000, coverage=30, n_per_million=2000, ragged=True, extra_errors=80)
+    fq = tmp_path / "in.fq.gz"
+    write_fastq(fq, d, names)
+    rc, piped, err = run_cli(["-g", d["genome_len"], fq], {"KBBQ_SEED": "5"})
+    assert rc == 0, err
+    assert len(piped) > 4 * 65536          # enough for four ranges
+    env = dict(os.environ, KBBQ_SEED="5")
+    for mode, extra, prefix in (("wb", {}, b""), ("wb", {}, b"what was there before"), ("ab", {}, b"appended to"), ("wb", {"KBBQ_WRITE_THREADS": "1"}, b"")):
+        out = tmp_path / "out.fq.gz"
+        with open(out, "wb") as f:
+            f.write(prefix)
+        with open(out, mode) as f:
+            if mode == "wb":
+                f.write(prefix)
+                f.flush()
+            p = subprocess.run([CLI, "-g", str(d["genome_len"]), str(fq)], stdout=f, stderr=subprocess.PIPE, env=dict(env, **extra), timeout=600)
+        assert p.returncode == 0, p.stderr.decode()
+        assert out.read_bytes() == prefix + piped, (mode, extra, prefix)
+
+
 def test_cli_block_parallel_and_serial_fastq_parse_agree(tmp_path):
     """The first scan parses strictly four-line FASTQ with a pool (fastq_io.h: FastqChunkParser) and starts over with the
     serial reader when the file turns out not to be of that shape: same bytes out either way, for a plain file, a

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/r03_e2e_big.sh [TAG] -- the command line at 3e10 bases (BASELINE configs[1] at one third): the 3e9-base BGZF FASTQ of
+# tools/r03_e2e_big.sh [TAG] ["RUNS"] -- the command line at 3e10 bases (BASELINE configs[1] at one third): the 3e9-base BGZF FASTQ of
 # tools/r03_e2e.sh ten times over (BGZF files concatenate), -g 1000000000; per-phase split, peak host RSS, device budgets.
 set -o pipefail
 tag=${1:-a}
@@ -17,7 +17,7 @@ ls -l $D/part.fq.gz $D/big.fq.gz >> $L
 echo "files ready"
 # first / second: the output through a pipe into wc; file: into a file on the box's disk (what a user does); rescan: pass 4
 # reads and inflates the input again (KBBQ_KEEP_TEXT=0: the text of the first scan is not kept in HBM)
-for name in first second file rescan; do
+for name in ${2:-first second file rescan}; do
     s=$(date +%s%N)
     if [ $name = file ]; then
         KBBQ_TIMING=1 KBBQ_SEED=777 $R/kbbq_amd/kbbq -g 1000000000 $D/big.fq.gz 2> $D/err_$name.txt > $D/out.fq.gz || { echo "$name failed"; tail -3 $D/err_$name.txt; exit 1; }
