@@ -30,6 +30,7 @@ constexpr uint32_t SLOT_BYTES = 65536 + 64;         // one finished block per sl
 constexpr uint32_t SLOT_SHIFT = 6;                  // the DEFLATE stream (behind the 18-byte header) is 8-byte aligned
 constexpr uint32_t TOKENS_PER_WAVE = 65536;
 constexpr int PF = 4;                               // steps of 64 positions whose loads are in flight ahead of the one worked on
+constexpr int PF2 = 2;                              // steps per round of the match-length sweep (two rounds in flight: registers)
 
 struct DeflateArgs {
     const uint8_t *payload;     // n bytes (+ 16 readable bytes behind them)
@@ -190,57 +191,64 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
             }
         }
         DFL_MARK(2);
-        // Sweep 2: how far the candidate matches, four steps at a time; the positions' own text, candidate and the byte
-        // before them come a round ahead, the candidates' text goes out together at the top of the round.
+        // Sweep 2: how far the candidate matches, two steps at a time, 16 bytes by two compares before any loop (a FASTQ
+        // match is 6 bytes on average, a read name's 9-17).  Nothing a round needs is asked for inside it: the candidates
+        // come two rounds ahead, and with them -- one round ahead -- the text at the positions and at their candidates.
         // tokens[p] = length << 16 | distance, 0: no match.
         {
-            uint64_t cur_n[PF];
-            uint32_t cand_n[PF];
-            uint32_t prev_n[PF];
+            uint64_t cur_n[PF2], cur2_n[PF2], old_n[PF2], old2_n[PF2];
+            uint32_t cand_nn[PF2], prev_n[PF2];
+            int cand_n[PF2];
+            auto clean = [&](int p, uint32_t c) -> int { return (p + 4 <= len && c != 0xFFFFu && p - (int)c <= MAX_DIST) ? (int)c : -1; };
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int p = min(64 * u + lane, len);
+            for (int u = 0; u < PF2; ++u) {      // round 0: everything; round 1: the candidates
+                const int p = min(64 * u + lane, len), pn = min(64 * (u + PF2) + lane, len);
+                cand_n[u] = clean(64 * u + lane, tokens[min(p, (int)TOKENS_PER_WAVE - 1)]);
+                cand_nn[u] = tokens[min(pn, (int)TOKENS_PER_WAVE - 1)];
                 cur_n[u] = load8(in + p);
-                cand_n[u] = tokens[min(p, (int)TOKENS_PER_WAVE - 1)];
+                cur2_n[u] = load8(in + p + 8);
                 prev_n[u] = in[max(p, 1) - 1];
+                old_n[u] = load8(in + max(cand_n[u], 0));
+                old2_n[u] = load8(in + max(cand_n[u], 0) + 8);
             }
-            for (int b0 = 0; b0 < len; b0 += 64 * PF) {
-                int cand[PF];
-                uint64_t cur[PF], old[PF];
-                uint32_t prev[PF];
+            for (int b0 = 0; b0 < len; b0 += 64 * PF2) {
+                int cand[PF2];
+                uint64_t cur[PF2], cur2[PF2], old[PF2], old2[PF2];
+                uint32_t prev[PF2];
 #pragma unroll
-                for (int u = 0; u < PF; ++u) {
-                    const int p = b0 + 64 * u + lane;
-                    cur[u] = cur_n[u];
-                    prev[u] = prev_n[u];
-                    cand[u] = (int)cand_n[u];
-                    if (!(p + 4 <= len && cand[u] != 0xFFFF && p - cand[u] <= MAX_DIST)) cand[u] = -1;
-                    old[u] = load8(in + max(cand[u], 0));
+                for (int u = 0; u < PF2; ++u) {
+                    cur[u] = cur_n[u]; cur2[u] = cur2_n[u]; old[u] = old_n[u]; old2[u] = old2_n[u]; prev[u] = prev_n[u]; cand[u] = cand_n[u];
                 }
 #pragma unroll
-                for (int u = 0; u < PF; ++u) {
-                    const int pn = min(b0 + 64 * (u + PF) + lane, len);
-                    cur_n[u] = load8(in + pn);
-                    cand_n[u] = tokens[min(pn, (int)TOKENS_PER_WAVE - 1)];
-                    prev_n[u] = in[pn - 1];
+                for (int u = 0; u < PF2; ++u) {
+                    const int q1 = b0 + 64 * (u + PF2) + lane, p1 = min(q1, len), p2 = min(q1 + 64 * PF2, len);
+                    cand_n[u] = clean(q1, cand_nn[u]);
+                    cand_nn[u] = tokens[min(p2, (int)TOKENS_PER_WAVE - 1)];
+                    cur_n[u] = load8(in + p1);
+                    cur2_n[u] = load8(in + p1 + 8);
+                    prev_n[u] = in[p1 - 1];
+                    old_n[u] = load8(in + max(cand_n[u], 0));
+                    old2_n[u] = load8(in + max(cand_n[u], 0) + 8);
                 }
 #pragma unroll
-                for (int u = 0; u < PF; ++u) {
+                for (int u = 0; u < PF2; ++u) {
                     const int p = b0 + 64 * u + lane;
                     const bool hashed = p + 4 <= len;
                     int L = 0, D = 0;
                     const int lim = min((int)MAX_MATCH, len - p);
                     if (cand[u] >= 0) {
-                        const uint64_t x = cur[u] ^ old[u];
-                        int n = x ? (int)(__builtin_ctzll(x) >> 3) : 8 + match_length(in, cand[u] + 8, p + 8, max(0, lim - 8));
+                        const uint64_t x = cur[u] ^ old[u], x2 = cur2[u] ^ old2[u];
+                        int n = x ? (int)(__builtin_ctzll(x) >> 3) : x2 ? 8 + (int)(__builtin_ctzll(x2) >> 3)
+                                                                       : 16 + match_length(in, cand[u] + 16, p + 16, max(0, lim - 16));
                         n = min(n, lim);
                         if (n >= MIN_TAKE) { L = n; D = p - cand[u]; }
                     }
                     // a run of one byte (the candidate the table cannot hold: the position just before, inside this step)
                     if (hashed && p > 0 && (uint8_t)prev[u] == (uint8_t)cur[u]) {
                         const uint64_t rep = (uint64_t)(uint8_t)cur[u] * 0x0101010101010101ull;
-                        const uint64_t x = cur[u] ^ rep;
-                        int n = x ? (int)(__builtin_ctzll(x) >> 3) : 8 + match_length(in, p + 7, p + 8, max(0, lim - 8));
+                        const uint64_t x = cur[u] ^ rep, x2 = cur2[u] ^ rep;
+                        int n = x ? (int)(__builtin_ctzll(x) >> 3) : x2 ? 8 + (int)(__builtin_ctzll(x2) >> 3)
+                                                                       : 16 + match_length(in, p + 15, p + 16, max(0, lim - 16));
                         n = min(n, lim);
                         if (n >= MIN_TAKE && n > L) { L = n; D = 1; }
                     }
