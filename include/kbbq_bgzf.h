@@ -94,8 +94,13 @@ int kbbq_fastq_reader_rewind(kbbq_fastq_reader *r);
 int kbbq_fastq_reader_keep(kbbq_fastq_reader *r, int32_t on);
 int kbbq_fastq_reader_kept(kbbq_fastq_reader *r, uint64_t *n_chunks, uint64_t *n_bytes);
 /* Kept chunk i (in the order of the first scan, chunks without records not counted) becomes the current chunk for
- * kbbq_fastq_reader_write; info (may be NULL) gets its counts. */
+ * kbbq_fastq_reader_write; info (may be NULL) gets its counts.
+ * A chunk whose batch was built (kbbq_fastq_reader_batch) and whose sequence lines hold nothing but ACGTN and acgt is kept
+ * in a short form -- names and comments only, a seventh of the memory -- because the packed batch gives those lines back
+ * exactly; kbbq_fastq_reader_attach hands the selected chunk its batch (the one kbbq_fastq_reader_batch returned for it)
+ * before kbbq_fastq_reader_write.  Attaching is harmless for a chunk kept whole. */
 int kbbq_fastq_reader_select(kbbq_fastq_reader *r, uint64_t i, kbbq_fastq_chunk *info);
+int kbbq_fastq_reader_attach(kbbq_fastq_reader *r, const kbbq_reads *batch);
 /* The next bytes of the file (host memory; page-locked memory is copied by DMA).  last != 0: nothing follows. */
 int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uint64_t n_bytes, int32_t last, kbbq_fastq_chunk *info);
 /* The current chunk's records as a device batch (arrays owned by the library: kbbq_reads_free): bases, N mask, qualities,

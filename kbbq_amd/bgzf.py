@@ -117,3 +117,6 @@ class FastqReader:
         info = _lib.FastqChunk()
         _lib.check(self.L.kbbq_fastq_reader_select(self.h, i, ctypes.byref(info)))
         return {k: getattr(info, k) for k, _ in _lib.FastqChunk._fields_}
+
+    def attach(self, batch):
+        _lib.check(self.L.kbbq_fastq_reader_attach(self.h, ctypes.byref(batch)))

@@ -497,7 +497,22 @@ __global__ void k_fastq_sizes(const uint32_t *lens, uint64_t n, uint64_t *blob_s
 // "@" name "\n" seq "\n+" comment "\n" qual "\n" of one record, written by one wavefront: lane l takes the bytes l, l + 64, ...;
 // four of them per round, their source bytes loaded before any is stored (the record's pieces are a few hundred bytes
 // spread over four places: what bounds this is the latency of those loads, so they travel together)
-__device__ __forceinline__ void emit_fastq_record(int lane, const uint8_t *name, uint32_t nl, const uint8_t *comment, uint32_t cl, const uint8_t *seq,
+// The sequence line of a record either as text or rebuilt from the engine's packed batch (2 bit per base, the non-ACGT mask
+// and the off-case bits: exact for text over ACGTN and acgt, which is what a chunk kept without its text was checked for).
+struct SeqSource {
+    const uint8_t *text;           // the sequence characters, or null: from the packed arrays at base index `first`
+    const uint64_t *bases, *nmask, *offcase;
+    uint64_t first;
+    __device__ __forceinline__ uint8_t at(uint32_t j) const {
+        if (text) return text[j];
+        const uint64_t g = first + j;
+        const uint32_t b = (uint32_t)(bases[g >> 5] >> ((g & 31) * 2)) & 3u;
+        const bool n = (nmask[g >> 6] >> (g & 63)) & 1, low = offcase && ((offcase[g >> 6] >> (g & 63)) & 1);
+        const uint8_t c = n ? (uint8_t)'N' : (uint8_t)((0x54474341u >> (8 * b)) & 0xFFu);      // "ACGT"
+        return low ? (uint8_t)(c | 0x20) : c;
+    }
+};
+__device__ __forceinline__ void emit_fastq_record(int lane, const uint8_t *name, uint32_t nl, const uint8_t *comment, uint32_t cl, const SeqSource &seq,
                                                   uint32_t sl, const uint8_t *q, uint8_t *out) {
     const uint32_t a_seq = 1 + nl + 1, a_plus = a_seq + sl, a_com = a_plus + 2, a_q = a_com + cl + 1, total = a_q + sl + 1;
     for (uint32_t i0 = 0; i0 < total; i0 += 256) {
@@ -510,7 +525,7 @@ __device__ __forceinline__ void emit_fastq_record(int lane, const uint8_t *name,
             if (i == 0) k = '@';
             else if (i < 1 + nl) sp = name + (i - 1);
             else if (i < a_seq) k = '\n';
-            else if (i < a_plus) sp = seq + (i - a_seq);
+            else if (i < a_plus) { if (seq.text) sp = seq.text + (i - a_seq); else k = seq.at(i - a_seq); }
             else if (i == a_plus) k = '\n';
             else if (i == a_plus + 1) k = '+';
             else if (i < a_com + cl) sp = comment + (i - a_com);
@@ -533,7 +548,8 @@ __global__ void __launch_bounds__(256) k_fastq_text(FastqArgs F) {
         const uint32_t nl = F.lens[3 * r], cl = F.lens[3 * r + 1], sl = F.lens[3 * r + 2];
         const uint8_t *name = F.blob + F.blob_off[r], *comment = name + nl, *seq = comment + cl;
         const uint8_t *q = F.qual + (F.qual_off ? F.qual_off[r] : r * (uint64_t)F.uniform_len);
-        emit_fastq_record(lane, name, nl, comment, cl, seq, sl, q, F.text + F.text_off[r]);
+        const SeqSource from = {seq, nullptr, nullptr, nullptr, 0};
+        emit_fastq_record(lane, name, nl, comment, cl, from, sl, q, F.text + F.text_off[r]);
     }
 }
 

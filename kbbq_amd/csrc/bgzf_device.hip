@@ -343,11 +343,18 @@ struct kbbq_fastq_reader {
     bool have_chunk = false;
     double ms_inflate = 0, ms_index = 0;
     // chunks of the first scan that stay in device memory (kbbq_fastq_reader_keep): their text and record index
+    // Two forms: the whole text with its record index, or -- when the chunk's batch was built and its sequence lines hold
+    // nothing but ACGTN / acgt, so that the packed batch gives them back exactly -- only names and comments (a seventh of the
+    // memory: what is not allocated need not be cleared by the driver either, 20-36 ms per GB of re-used memory).
     struct Kept {
         Buf text, idx_u32, base_sz, text_sz;
+        Buf names, lens;            // the short form: names + comments back to back, (name, comment) lengths
+        bool short_form = false;
         uint64_t text_bytes = 0, n_records = 0, n_bases = 0, out_text_bytes = 0;
         uint32_t longest = 0, shortest = 0;
     };
+    bool packed_is_exact = false;              // the current chunk's batch gives its sequence text back (set by batch())
+    const uint64_t *att_bases = nullptr, *att_nmask = nullptr, *att_offcase = nullptr;      // kbbq_fastq_reader_attach
     std::vector<Kept> kept;
     bool keeping = false;
     int64_t selected = -1;      // the kept chunk that is the current one (pass 4), or -1: the live buffers
@@ -384,7 +391,7 @@ FastqIndex index_of(kbbq_fastq_reader *r, uint64_t cap) {
 }
 
 void release_kept(kbbq_fastq_reader *r) {
-    for (auto &k : r->kept) { k.text.release(); k.idx_u32.release(); k.base_sz.release(); k.text_sz.release(); }
+    for (auto &k : r->kept) { k.text.release(); k.idx_u32.release(); k.base_sz.release(); k.text_sz.release(); k.names.release(); k.lens.release(); }
     r->kept.clear();
     r->kept_bytes = 0;
     r->selected = -1;
@@ -394,15 +401,38 @@ void release_kept(kbbq_fastq_reader *r) {
 void stash_current(kbbq_fastq_reader *r) {
     if (!r->keeping || r->selected >= 0 || !r->have_chunk || !r->n_records) return;
     kbbq_fastq_reader::Kept k;
-    k.text = r->text; k.idx_u32 = r->idx_u32; k.base_sz = r->base_sz; k.text_sz = r->text_sz;
-    r->text = Buf(); r->idx_u32 = Buf(); r->base_sz = Buf(); r->text_sz = Buf();
-    r->text.exact = r->idx_u32.exact = r->base_sz.exact = r->text_sz.exact = true;
     k.text_bytes = r->text_bytes; k.n_records = r->n_records; k.n_bases = r->n_bases;
     k.longest = r->longest; k.shortest = r->shortest;
     k.out_text_bytes = r->out_text_bytes;
-    r->kept_bytes += k.text.bytes + k.idx_u32.bytes + k.base_sz.bytes + k.text_sz.bytes;
+    const uint64_t n = r->n_records;
+    const uint64_t names_bytes = r->out_text_bytes - 2 * r->n_bases - 6 * n;      // sum of name + comment lengths
+    bool short_form = r->packed_is_exact;
+    if (short_form) {
+        // names, lengths and the two scans into buffers of exactly their size; the working buffers stay the reader's
+        k.names.exact = k.lens.exact = k.base_sz.exact = k.text_sz.exact = true;
+        if (k.names.reserve(names_bytes + 64) || k.lens.reserve(n * 8) || k.base_sz.reserve((n + 1) * 8) || k.text_sz.reserve((n + 1) * 8)) {
+            (void)hipGetLastError();
+            k.names.release(); k.lens.release(); k.base_sz.release(); k.text_sz.release();
+            short_form = false;      // (the long form below takes the buffers that exist already)
+        } else {
+            const FastqIndex X = index_of(r, n);
+            hipLaunchKernelGGL(k_fastq_keep_names, dim3((unsigned)std::min<uint64_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, r->st, (const uint8_t *)r->text.p, X,
+                               (const uint64_t *)X.text_sz, (const uint64_t *)X.base_sz, n, (uint8_t *)k.names.p, (uint32_t *)k.lens.p);
+            (void)hipMemcpyAsync(k.base_sz.p, X.base_sz, (n + 1) * 8, hipMemcpyDeviceToDevice, r->st);
+            (void)hipMemcpyAsync(k.text_sz.p, X.text_sz, (n + 1) * 8, hipMemcpyDeviceToDevice, r->st);
+            // (the reader's next chunk is queued on the same stream: it overwrites the working buffers behind these)
+            k.short_form = true;
+            r->kept_bytes += k.names.bytes + k.lens.bytes + k.base_sz.bytes + k.text_sz.bytes;
+        }
+    }
+    if (!short_form) {
+        k.text = r->text; k.idx_u32 = r->idx_u32; k.base_sz = r->base_sz; k.text_sz = r->text_sz;
+        r->text = Buf(); r->idx_u32 = Buf(); r->base_sz = Buf(); r->text_sz = Buf();
+        r->kept_bytes += k.text.bytes + k.idx_u32.bytes + k.base_sz.bytes + k.text_sz.bytes;
+    }
     r->kept.push_back(k);
     r->have_chunk = false;
+    r->packed_is_exact = false;
 }
 
 }  // namespace
@@ -462,12 +492,10 @@ int kbbq_fastq_reader_keep(kbbq_fastq_reader *r, int32_t on) {
     if (on) {
         if (r->have_chunk || !r->kept.empty()) return fail(KBBQ_ESTATE, "keeping starts before the first chunk of a scan");
         r->keeping = true;
-        r->text.exact = r->idx_u32.exact = r->base_sz.exact = r->text_sz.exact = true;
     } else {
         HIP_TRY(hipStreamSynchronize(r->st));
         release_kept(r);
         r->keeping = false;
-        r->text.exact = r->idx_u32.exact = r->base_sz.exact = r->text_sz.exact = false;
     }
     return KBBQ_OK;
 }
@@ -487,6 +515,7 @@ int kbbq_fastq_reader_select(kbbq_fastq_reader *r, uint64_t i, kbbq_fastq_chunk 
     const kbbq_fastq_reader::Kept &k = r->kept[i];
     r->selected = (int64_t)i;
     r->have_chunk = true;
+    r->att_bases = r->att_nmask = r->att_offcase = nullptr;
     r->text_bytes = k.text_bytes; r->n_records = k.n_records; r->n_bases = k.n_bases;
     r->longest = k.longest; r->shortest = k.shortest;
     r->out_text_bytes = k.out_text_bytes;
@@ -506,6 +535,7 @@ int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uin
     stash_current(r);
     r->selected = -1;
     r->have_chunk = false;
+    r->packed_is_exact = false;
     // ---- the block boundaries: hop from header to header (RFC 1952 member with the 'BC' extra subfield, SAM spec 4.1)
     std::vector<uint64_t> c_off, o_off;
     std::vector<uint32_t> c_len, o_len;
@@ -707,7 +737,7 @@ int kbbq_fastq_reader_batch(kbbq_fastq_reader *r, kbbq_reads *dev) {
     RB_TRY(hipMalloc(&fl, n));
     const bool uniform = r->longest == r->shortest;
     if (!uniform) RB_TRY(hipMalloc(&off, (n + 1) * 8));
-    RB_TRY(hipMemsetAsync(cnt, 0, 8, r->st));
+    RB_TRY(hipMemsetAsync(cnt, 0, 16, r->st));
     RB_TRY(hipMemsetAsync((char *)b + 2 * words * 8, 0, 16, r->st));
     RB_TRY(hipMemsetAsync((char *)m + words * 8, 0, 16, r->st));
     RB_TRY(hipMemsetAsync((char *)oc + words * 8, 0, 16, r->st));
@@ -719,10 +749,12 @@ int kbbq_fastq_reader_batch(kbbq_fastq_reader *r, kbbq_reads *dev) {
     RB_TRY(hipGetLastError());
     RB_TRY(hipMemcpyAsync(fl, X.second, n, hipMemcpyDeviceToDevice, r->st));
     if (!uniform) RB_TRY(hipMemcpyAsync(off, X.base_sz, (n + 1) * 8, hipMemcpyDeviceToDevice, r->st));
-    unsigned long long n_off = 0;
-    RB_TRY(hipMemcpyAsync(&n_off, cnt, 8, hipMemcpyDeviceToHost, r->st));
+    unsigned long long counts[2] = {0, 0};      // off-case bases; characters the packed form cannot give back
+    RB_TRY(hipMemcpyAsync(counts, cnt, 16, hipMemcpyDeviceToHost, r->st));
     RB_TRY(hipStreamSynchronize(r->st));
 #undef RB_TRY
+    const unsigned long long n_off = counts[0];
+    r->packed_is_exact = counts[1] == 0;
     if (!n_off) { (void)hipFree(oc); oc = nullptr; }
     dev->bases = (const uint64_t *)b;
     dev->nmask = (const uint64_t *)m;
@@ -741,6 +773,8 @@ int kbbq_fastq_reader_write(kbbq_fastq_reader *r, kbbq_bgzf *z, const uint8_t *d
     if (r->device != z->device) return fail(KBBQ_EINVAL, "reader and writer are on different devices");
     KbbqDeviceGuard guard(z->device);
     HIP_TRY(guard.err);
+    if (r->selected >= 0 && r->kept[(size_t)r->selected].short_form && !r->att_bases)
+        return fail(KBBQ_ESTATE, "the chunk was kept without its sequence text: attach its batch first (kbbq_fastq_reader_attach)");
     Submission *sp;
     int rc = begin_submission(z, after_stream, &sp);
     if (rc) return rc;
@@ -756,13 +790,30 @@ int kbbq_fastq_reader_write(kbbq_fastq_reader *r, kbbq_bgzf *z, const uint8_t *d
     if ((rc = s.payload.reserve(t + 16))) return rc;
     HIP_TRY(hipMemsetAsync((char *)s.payload.p + t, 0, 16, z->st));
     HIP_TRY(hipEventRecord(s.t0, z->st));
-    hipLaunchKernelGGL(k_fastq_text_indexed, dim3((unsigned)std::min<uint64_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, z->st, text, X,
-                       (const uint64_t *)X.text_sz, (const uint64_t *)X.base_sz, d_qual, n, (uint8_t *)s.payload.p);
+    if (from_kept && k->short_form)
+        hipLaunchKernelGGL(k_fastq_text_packed, dim3((unsigned)std::min<uint64_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, z->st, (const uint8_t *)k->names.p,
+                           (const uint32_t *)k->lens.p, (const uint64_t *)k->text_sz.p, (const uint64_t *)k->base_sz.p, r->att_bases, r->att_nmask,
+                           r->att_offcase, d_qual, n, (uint8_t *)s.payload.p);
+    else
+        hipLaunchKernelGGL(k_fastq_text_indexed, dim3((unsigned)std::min<uint64_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, z->st, text, X,
+                           (const uint64_t *)X.text_sz, (const uint64_t *)X.base_sz, d_qual, n, (uint8_t *)s.payload.p);
     HIP_TRY(hipGetLastError());
     if ((rc = launch_deflate(z, s))) return rc;
     // the reader's live text and index are read by the kernel just queued: the next kbbq_fastq_reader_chunk must not
     // overwrite them before it has run (a kept chunk's buffers stay as they are)
     if (!from_kept) HIP_TRY(hipEventSynchronize(s.t1));
+    return KBBQ_OK;
+}
+
+int kbbq_fastq_reader_attach(kbbq_fastq_reader *r, const kbbq_reads *batch) {
+    if (!r || !batch) return fail(KBBQ_EINVAL, "null argument");
+    if (!batch->on_device || !batch->bases || !batch->nmask) return fail(KBBQ_EINVAL, "not a device batch");
+    if (r->selected < 0) return fail(KBBQ_ESTATE, "no kept chunk is selected");
+    const kbbq_fastq_reader::Kept &k = r->kept[(size_t)r->selected];
+    if (batch->n_reads != k.n_records || batch->n_bases != k.n_bases) return fail(KBBQ_EINVAL, "the batch is not this chunk's");
+    r->att_bases = batch->bases;
+    r->att_nmask = batch->nmask;
+    r->att_offcase = batch->offcase;
     return KBBQ_OK;
 }
 

@@ -693,6 +693,8 @@ __global__ void __launch_bounds__(256) k_fastq_gather(const uint8_t *text, Fastq
 }
 
 // 64 bases per lane: the 2-bit words, the non-ACGT mask and the off-case bits (kbbq_pack_bases_case, engine.hip: same table)
+// n_offcase[0] counts the off-case bases, n_offcase[1] the characters that the packed form cannot give back (anything but
+// ACGTN and acgt: digits, IUPAC codes, a lower-case n)
 __global__ void __launch_bounds__(256) k_pack_text(const uint8_t *seq_text, uint64_t n_bases, uint64_t *bases, uint64_t *nmask, uint64_t *offcase,
                                                     unsigned long long *n_offcase) {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -701,8 +703,10 @@ __global__ void __launch_bounds__(256) k_pack_text(const uint8_t *seq_text, uint
     const uint64_t first = w * 64;
     const int n = (int)min((uint64_t)64, n_bases > first ? n_bases - first : 0);
     uint64_t b0 = 0, b1 = 0, nm = 0, oc = 0;
+    uint32_t exotic = 0;
     for (int j = 0; j < n; ++j) {
         const uint8_t ch = seq_text[first + j];
+        exotic += !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == 'N' || ch == 'a' || ch == 'c' || ch == 'g' || ch == 't');
         // seq_nt16_int[seq_nt16_table[ch]] (bloom.hh:351): A/a/0 = 0, C/c/1 = 1, G/g/2 = 2, T/t/3 = 3, everything else non-ACGT
         uint32_t code = 4, odd = 0;
         switch (ch) {
@@ -721,6 +725,7 @@ __global__ void __launch_bounds__(256) k_pack_text(const uint8_t *seq_text, uint
     nmask[w] = nm;
     offcase[w] = oc;
     if (oc) atomicAdd(n_offcase, (unsigned long long)__popcll(oc));
+    if (exotic) atomicAdd(n_offcase + 1, (unsigned long long)exotic);
 }
 
 // the output text of a batch assembled from the DEVICE copy of the input text (pass 4 of the device path): the same
@@ -732,7 +737,38 @@ __global__ void __launch_bounds__(256) k_fastq_text_indexed(const uint8_t *text,
     for (uint64_t r = wave; r < n_records; r += n_waves) {
         const uint32_t nl = X.name_len[r], cl = X.com_len[r], sl = X.seq_len[r];
         const uint8_t *name = text + X.name_off[r], *comment = text + X.com_off[r], *seq = text + X.seq_off[r];
-        emit_fastq_record(lane, name, nl, comment, cl, seq, sl, new_qual + base_off[r], out + text_off[r]);
+        const SeqSource from = {seq, nullptr, nullptr, nullptr, 0};
+        emit_fastq_record(lane, name, nl, comment, cl, from, sl, new_qual + base_off[r], out + text_off[r]);
+    }
+}
+
+// A chunk kept without its text (kbbq_fastq_reader_keep): the names and comments of its records back to back -- record r's at
+// text_off[r] - 2 base_off[r] - 6 r, the sum of the name and comment lengths before it (a record's output text is name +
+// comment + 2 x sequence + 6 bytes) -- and the two lengths; the sequence line comes back from the packed batch.
+__global__ void __launch_bounds__(256) k_fastq_keep_names(const uint8_t *text, FastqIndex X, const uint64_t *text_off, const uint64_t *base_off,
+                                                           uint64_t n_records, uint8_t *names, uint32_t *lens) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * 4;
+    for (uint64_t r = wave; r < n_records; r += n_waves) {
+        const uint32_t nl = X.name_len[r], cl = X.com_len[r];
+        uint8_t *to = names + (text_off[r] - 2 * base_off[r] - 6 * r);
+        const uint8_t *name = text + X.name_off[r], *comment = text + X.com_off[r];
+        for (uint32_t i = lane; i < nl + cl; i += 64) to[i] = i < nl ? name[i] : comment[i - nl];
+        if (lane == 0) { lens[2 * r] = nl; lens[2 * r + 1] = cl; }
+    }
+}
+__global__ void __launch_bounds__(256) k_fastq_text_packed(const uint8_t *names, const uint32_t *lens, const uint64_t *text_off, const uint64_t *base_off,
+                                                            const uint64_t *bases, const uint64_t *nmask, const uint64_t *offcase,
+                                                            const uint8_t *new_qual, uint64_t n_records, uint8_t *out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * 4;
+    for (uint64_t r = wave; r < n_records; r += n_waves) {
+        const uint32_t nl = lens[2 * r], cl = lens[2 * r + 1];
+        const uint64_t b0 = base_off[r];
+        const uint32_t sl = (uint32_t)(base_off[r + 1] - b0);
+        const uint8_t *name = names + (text_off[r] - 2 * b0 - 6 * r);
+        const SeqSource from = {nullptr, bases, nmask, offcase, b0};
+        emit_fastq_record(lane, name, nl, name + nl, cl, from, sl, new_qual + b0, out + text_off[r]);
     }
 }
 

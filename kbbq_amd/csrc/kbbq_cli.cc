@@ -1239,7 +1239,9 @@ int main(int argc, char *argv[]) {
                 if (dev_in.text_kept) {
                     // the chunk's text and index are still on the device
                     if (!dev_in.chunk_records[ci]) continue;
-                    if (kbbq_fastq_reader_select(dev_in.reader, bi, &info) < 0 || info.n_records != dev_in.chunk_records[ci]) return fail_engine("recalibrating");
+                    if (kbbq_fastq_reader_select(dev_in.reader, bi, &info) < 0 || info.n_records != dev_in.chunk_records[ci] ||
+                        kbbq_fastq_reader_attach(dev_in.reader, &resident.dev[bi]) < 0)
+                        return fail_engine("recalibrating");
                 } else if (dev_in.next_chunk(info) != 1 || info.n_records != dev_in.chunk_records[ci]) {
                     std::cerr << put_now << " Error: the input changed between the passes." << std::endl;
                     return 1;

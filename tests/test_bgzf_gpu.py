@@ -240,24 +240,40 @@ def test_reader_and_writer_round_trip_with_new_qualities(writer):
     r.close()
 
 
-def test_kept_chunks_are_written_without_a_second_scan(writer):
+@pytest.mark.parametrize("form", ["whole", "names", "names_lower", "exotic"])
+def test_kept_chunks_are_written_without_a_second_scan(writer, form):
     """kbbq_fastq_reader_keep: the chunks of the first scan stay on the device; pass 4 selects them one by one and gets the
-    same text as a second inflation would give.  A file in three pieces, the cuts inside records."""
+    same text as a second inflation would give.  A file in three pieces, the cuts inside records.  whole: no batch was
+    built, the text stays; names: the batch gives the sequence lines back (ACGTN), only names and comments stay;
+    names_lower: the same with soft-masked bases; exotic: an IUPAC code in a read -- that chunk keeps its text."""
     import torch
-    recs, text = make_records(9000, seed=41, uniform=False)
+    recs, text = make_records(9000, seed=41, uniform=False, lower=form == "names_lower")
+    if form == "exotic":
+        nm, cm, sq, q, pl = recs[100]
+        recs[100] = (nm, cm, "R" + sq[1:], q, pl)
+        text = "".join("@%s%s\n%s\n%s\n%s\n" % (nm, cm, sq, pl, q) for nm, cm, sq, q, pl in recs).encode()
     comp = bgzip(text, 6, block=20000)
     # cut at BGZF block boundaries (the reader takes whole blocks and reports what it consumed)
     r = bgzf.FastqReader()
     r.keep(True)
-    pieces, at, counts = [len(comp) // 3, 2 * len(comp) // 3, len(comp)], 0, []
+    pieces, at, counts, batches = [len(comp) // 3, 2 * len(comp) // 3, len(comp)], 0, [], []
     for end in pieces:
         info = r.chunk(comp[at:end], end == len(comp))
         assert info["flags"] == 0
         at += info["consumed"]
         counts.append((info["n_records"], info["n_bases"]))
+        if form != "whole" and info["n_records"]:
+            batches.append(r.batch())
     assert sum(c[0] for c in counts) == len(recs)
+    r.rewind()
     n_kept, n_bytes = r.kept()
-    assert n_kept == sum(1 for c in counts if c[0]) and n_bytes > len(text)
+    assert n_kept == sum(1 for c in counts if c[0])
+    if form in ("names", "names_lower"):
+        assert n_bytes < len(text) // 2          # names, comments, lengths and two scans
+    elif form == "whole":
+        assert n_bytes > len(text)
+    else:
+        assert len(text) // 3 < n_bytes          # the first chunk whole, the others short
     r.rewind()
     assert r.kept()[0] == n_kept
     rng = np.random.RandomState(2)
@@ -267,6 +283,11 @@ def test_kept_chunks_are_written_without_a_second_scan(writer):
         if not n_rec:
             continue
         info = r.select(k)
+        if form != "whole":
+            if form != "exotic" or k > 0:
+                with pytest.raises(Exception):       # a chunk kept without its text needs its batch
+                    r.write(writer, 0x1000)
+            r.attach(batches[k])
         k += 1
         assert info["n_records"] == n_rec and info["n_bases"] == n_bases
         newq = rng.randint(0, 94, n_bases).astype(np.uint8)
@@ -282,6 +303,8 @@ def test_kept_chunks_are_written_without_a_second_scan(writer):
             qa += l
         rec_at += n_rec
     assert b"".join(got) == b"".join(want)
+    for d in batches:
+        _lib.check(_lib.lib().kbbq_reads_free(None, ctypes.byref(d)))
     # giving the kept chunks up: nothing left to select
     r.keep(False)
     assert r.kept() == (0, 0)

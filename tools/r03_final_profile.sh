@@ -2,6 +2,7 @@
 # tools/r03_final_profile.sh TAG -- the round's profiler record for HEAD at full scale (BASELINE configs[1]):
 #   gpurun_out/r03_bench_driver_TAG.json        python bench.py --gpus 1 --steps 20 --warmup 5 (what the driver runs)
 #   gpurun_out/r03_kernel_stats_TAG.csv         rocprofv3 --kernel-trace --stats of one step of the same command
+#   gpurun_out/r03_kernel_stats_inorder_TAG.csv the same with KBBQ_NO_OVERLAP=1 (exclusive durations)
 #   gpurun_out/r03_pmc_TAG_summary.txt          rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of one in-order 3e8-genome step
 #   gpurun_out/r03_pmc_latest_TAG.json          the same as the JSON bench.py quotes (copy to profiles/r03_pmc_latest.json)
 set -o pipefail
@@ -13,6 +14,11 @@ timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpu
 find $R/gpurun_out/prof$tag -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/r03_kernel_stats_$tag.csv \;
 rm -rf $R/gpurun_out/prof$tag
 echo "profile done"
+# the same with every kernel in order on one stream: the exclusive durations the roofline object quotes
+KBBQ_NO_OVERLAP=1 timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/profi$tag -o r03 -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pcie --no-exclusive-step > $R/gpurun_out/profi$tag.json 2> $R/gpurun_out/profi$tag.log || { tail -5 $R/gpurun_out/profi$tag.log; exit 1; }
+find $R/gpurun_out/profi$tag -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/r03_kernel_stats_inorder_$tag.csv \;
+rm -rf $R/gpurun_out/profi$tag
+echo "in-order profile done"
 export KBBQ_NO_OVERLAP=1
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc${tag}_$c -- \
