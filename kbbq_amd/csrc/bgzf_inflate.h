@@ -27,12 +27,17 @@
 namespace kbbq {
 namespace dfl {
 
-constexpr int INF_RING = 8192;               // the recent output of one wavefront in LDS: matches that reach no further back are
+// Ring, table and register budget were chosen by measurement (tools/inflate_probe.py over builds with other values,
+// profiles/r03_inflate_variants.txt): the decoder is bound by the latency of its own serial chain, so what counts is how many
+// wavefronts a CU holds -- 8 KB ring + 10-bit table, 12 per CU: 17.8 GB/s of zlib-6 FASTQ text; 4 KB + 10 bits, 16: 28.7;
+// 2 KB + 9 bits at six waves per SIMD (80 registers), 24: 32.7 -- although most matches of a 32 KB window then come back
+// from HBM.
+constexpr int INF_RING = 2048;               // the recent output of one wavefront in LDS: matches that reach no further back are
                                              // LDS-to-LDS copies; the rest of DEFLATE's 32 KB window is read back from HBM
 constexpr int INF_FLUSH = 256;               // bytes that leave the ring for HBM at a time: one aligned 256-byte line of the output
 constexpr int INF_NEAR = INF_RING - 512;     // a match at most this far back still lies in the ring (the 512: lanes write up to 63
                                              // bytes ahead of the output position, see the literal and match copies)
-constexpr int INF_TBITS = 10;                // the literal/length table is indexed by the next 10 bits of the stream
+constexpr int INF_TBITS = 9;                 // the literal/length table is indexed by the next 9 bits of the stream
 constexpr int INF_WAVES = 1;                 // one wavefront per workgroup
 constexpr int INF_LDS_PER_WAVE = INF_RING + (4 << INF_TBITS) + 1536;
 
@@ -187,8 +192,8 @@ __device__ __forceinline__ void length_base(int li, int *base, int *eb) {
     else { *eb = (li >> 2) - 1; *base = 3 + ((4 + (li & 3)) << *eb); }
 }
 
-// The literal/length table of a block from its bounds and sorted symbols: every lane decodes 16 of the 1024 bit patterns
-// the slow way, then looks whether one or two more literals fit behind a literal in the same ten bits.
+// The literal/length table of a block from its bounds and sorted symbols: every lane decodes its share of the 2^INF_TBITS bit
+// patterns the slow way, then looks whether one or two more literals fit behind a literal in the same bits.
 __device__ __forceinline__ void build_ll_table(InflateLds &S, const CodeBounds &LL, uint32_t n_coded, int lane) {
     constexpr int PER = (1 << INF_TBITS) / 64;
     uint32_t e[PER];
@@ -256,7 +261,7 @@ __device__ __forceinline__ uint32_t distance_info(uint32_t ds) {
     return (1u + ((2u + (ds & 1u)) << de)) | (de << 16);
 }
 
-__global__ void __launch_bounds__(64 * INF_WAVES) k_inflate(InflateArgs A) {
+__global__ void __launch_bounds__(64 * INF_WAVES, 6) k_inflate(InflateArgs A) {
     __shared__ InflateLds lds_all[INF_WAVES];
     const int lane = threadIdx.x & 63;
     InflateLds &S = lds_all[0];
