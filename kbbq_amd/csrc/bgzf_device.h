@@ -22,13 +22,8 @@
 namespace kbbq {
 namespace dfl {
 
-#ifndef KBBQ_DFL_HASH_BITS
-#define KBBQ_DFL_HASH_BITS 12
-#endif
-#ifndef KBBQ_DFL_MINWAVES
-#define KBBQ_DFL_MINWAVES 1
-#endif
-constexpr int HASH_BITS = KBBQ_DFL_HASH_BITS;                       // 4096 most-recent positions per wave: 8 KB of LDS
+constexpr int HASH_BITS = 12;                       // 4096 most-recent positions per wave: 8 KB of LDS (8192: 0.5 % smaller output, 15 % slower;
+                                                    // 2048 with five waves per SIMD: 7 % faster, 0.5 % larger: profiles/r03_deflate_variants.txt)
 constexpr int HASH_SIZE = 1 << HASH_BITS;
 constexpr int DFL_WAVES = 1;                        // wavefronts per workgroup: each works alone (no workgroup barrier anywhere), 18 KB of LDS
 constexpr int MIN_TAKE = 4;                         // shortest match the 4-byte hash can find
@@ -91,7 +86,7 @@ struct WaveLds {
     uint32_t crc_tab[256];      // CRC-32 of one byte (reflected polynomial 0xEDB88320), filled once per launch
 };
 
-__global__ void __launch_bounds__(64 * DFL_WAVES, KBBQ_DFL_MINWAVES) k_deflate(DeflateArgs A) {
+__global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
     __shared__ WaveLds lds_all[DFL_WAVES];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
