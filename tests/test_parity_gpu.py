@@ -423,6 +423,69 @@ print("rccl one-rank exchange ok")
     assert out.returncode == 0 and "rccl one-rank exchange ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
+def test_exchange_steps_over_rccl_with_two_ranks():
+    """Two ranks over RCCL, one GPU each (runs where two devices are visible; the driver's one-GPU box skips it): each rank
+    works through its shard of the reads, the filters are OR-ed through the pipelined slab loop (several slabs and a ragged
+    last one: slab_words = 2^14), histograms summed, delta-Q broadcast -- filters, inserted counts, covariates and the
+    recalibrated qualities of every rank's shard must equal the one-rank run's.  The same equality is proven over gloo on
+    the CPU in tests/test_dist_cpu.py."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    code = r'''
+import os, sys
+sys.path.insert(0, "tests")
+import numpy as np, torch, torch.distributed as dist
+import common
+from kbbq_amd.dist import EnginePeer, Exchange, shard_range
+from kbbq_amd.engine import Engine
+from kbbq_amd.reads import ReadBatch
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+d = common.make_dataset(seed=8, genome_len=12000, coverage=20, n_rg=2, paired=True, extra_errors=50)
+ref = common.run_engine(d, n_rg=2, uniform=True)              # the whole input on this rank's GPU, no exchange
+alpha_ld, cov, approx = common.plan_parameters(d["genome_len"], d["coverage"], None)
+e = Engine(32, alpha_ld, 777, approx, n_rg=2, max_read_len=150, device=rank)
+x = Exchange(EnginePeer(e), slab_words=1 << 14, device=torch.device("cuda", rank))
+n = len(d["off"]) - 1
+lo, hi = shard_range(n, rank, world)
+off = d["off"]
+sl = slice(int(off[lo]), int(off[hi]))
+b = e.upload(ReadBatch(d["seq"][sl], d["qual"][sl], off[lo:hi + 1] - off[lo], d["rg"][lo:hi], d["second"][lo:hi], uniform=True))
+e.subsample_kmers(b, lo * (150 - 32 + 1)); e.sample_finish()
+assert x.filter_done(0) == ref["sampled_inserted"]
+assert np.array_equal(e.filter_table(0), ref["sampled_table"])
+e.compute_thresholds()
+e.find_trusted_kmers(b); e.trusted_finish()
+assert x.filter_done(1) == ref["trusted_inserted"]
+assert np.array_equal(e.filter_table(1), ref["trusted_table"])
+e.get_covariatedata(b)
+x.histograms_done()
+c = e.covariates()
+assert np.array_equal(c["cycle"], ref["cov"]["cycle"]) and np.array_equal(c["dinuc"], ref["cov"]["dinuc"])
+dq = x.train_and_share()
+assert np.array_equal(dq["cycle"], ref["dq"]["cycle"]) and np.array_equal(dq["q"], ref["dq"]["q"])
+out = torch.zeros(b.n_bases + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+e.recalibrate(b, out.data_ptr()); e.sync()
+assert np.array_equal(out.cpu().numpy()[:b.n_bases], ref["recal"][sl])
+dist.barrier()
+dist.destroy_process_group()
+print("rccl two-rank exchange ok", rank)
+'''
+    script = os.path.join(common.ROOT, "gpurun_out", "rccl_two_ranks.py")
+    os.makedirs(os.path.dirname(script), exist_ok=True)
+    with open(script, "w") as f:
+        f.write(code)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29741", script], cwd=common.ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0 and out.stdout.count("rccl two-rank exchange ok") == 2, out.stdout[-2000:] + out.stderr[-4000:]
+
+
 def test_single_rank_exchange_is_a_no_op():
     from kbbq_amd.dist import EnginePeer, Exchange
     d = common.make_dataset(seed=8, genome_len=6000, coverage=20)
