@@ -101,7 +101,9 @@ int kbbq_fastq_reader_kept(kbbq_fastq_reader *r, uint64_t *n_chunks, uint64_t *n
  * before kbbq_fastq_reader_write.  Attaching is harmless for a chunk kept whole. */
 int kbbq_fastq_reader_select(kbbq_fastq_reader *r, uint64_t i, kbbq_fastq_chunk *info);
 int kbbq_fastq_reader_attach(kbbq_fastq_reader *r, const kbbq_reads *batch);
-/* The next bytes of the file (host memory; page-locked memory is copied by DMA).  last != 0: nothing follows. */
+/* The next bytes of the file (host memory; page-locked memory is copied by DMA).  last != 0: nothing follows.
+ * Every block's CRC-32 and ISIZE are checked as bgzf_read checks them; a block that does not inflate to them is
+ * KBBQ_EIO ("CRC32 checksum mismatch" / "does not inflate"). */
 int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uint64_t n_bytes, int32_t last, kbbq_fastq_chunk *info);
 /* The current chunk's records as a device batch (arrays owned by the library: kbbq_reads_free): bases, N mask, qualities,
  * offsets (NULL and read_len for equally long reads), second-in-pair flags, off-case bits when a base is not upper-case. */

@@ -68,6 +68,55 @@ __device__ __forceinline__ int match_length(const uint8_t *in, int a, int b, int
     return n < lim ? n : lim;
 }
 
+// CRC-32 (gzip polynomial, reflected) of len bytes by one wavefront: 256 pieces of q bytes, four per lane (four
+// independent table walks keep the LDS pipe busy), every piece's register started at 0; the pieces are joined by the rule
+// for running B behind A, r_AB = r_A * x^(8|B|) + r_B in GF(2)[x] mod P (crc_chain), an associative rule: a lane folds its
+// four, the wave reduces in six steps.  tab: crc_table_entry(0..255) in LDS; xq_for / xq / xq4: the caller's cache of
+// x^(8 q), x^(32 q) for the piece length last seen (blocks are nearly all of one length).  Returns the value of the trailer.
+__device__ __forceinline__ uint32_t wave_crc32(const uint8_t *in, int len, const uint32_t *tab, int lane, int &xq_for, uint32_t &xq, uint32_t &xq4) {
+    const int q = (len + 255) / 256;
+    uint32_t crc_r = 0, crc_x = 0x80000000u;      // the lane's four pieces as one: register from 0, x^(8 * its bytes)
+    if (q != xq_for) { xq = crc_xpow8((uint64_t)q); xq4 = crc_mulmod(xq, xq); xq4 = crc_mulmod(xq4, xq4); xq_for = q; }
+    int a[4], n[4];
+    uint32_t c[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = min(len, (4 * lane + j) * q); n[j] = min(len, a[j] + q) - a[j]; }
+    int i = 0;
+    for (; i + 8 <= n[3]; i += 8) {      // (n[0] >= n[1] >= n[2] >= n[3])
+        uint64_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = load8(in + a[j] + i);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { c[j] = tab[(c[j] ^ (uint32_t)(v[j] >> (8 * k))) & 0xFFu] ^ (c[j] >> 8); }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        for (int t = i; t < n[j]; ++t) c[j] = tab[(c[j] ^ in[a[j] + t]) & 0xFFu] ^ (c[j] >> 8);
+    // the lane's fold; only the block's last piece is shorter than q (and the ones behind it empty)
+    if (__ballot(n[3] != q) == 0) {
+        crc_r = crc_chain(crc_chain(crc_chain(c[0], c[1], xq), c[2], xq), c[3], xq);
+        crc_x = xq4;
+    } else {
+        crc_r = c[0];
+        crc_x = n[0] == q ? xq : crc_xpow8((uint64_t)n[0]);
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+            const uint32_t xj = n[j] == q ? xq : crc_xpow8((uint64_t)n[j]);
+            crc_r = crc_chain(crc_r, c[j], xj);
+            crc_x = crc_mulmod(crc_x, xj);
+        }
+    }
+    // lanes 2o apart join their runs of o lanes: (r, x) <- (r * x' + r', x * x'); lane 0 ends up with the whole block
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t r2 = __shfl_down(crc_r, o), x2 = __shfl_down(crc_x, o);
+        crc_r = crc_chain(crc_r, r2, x2);
+        crc_x = crc_mulmod(crc_x, x2);
+    }
+    return crc_chain(0xFFFFFFFFu, (uint32_t)__builtin_amdgcn_readfirstlane((int)crc_r), (uint32_t)__builtin_amdgcn_readfirstlane((int)crc_x)) ^ 0xFFFFFFFFu;
+}
+
 // LDS of one wavefront.  The Huffman scratch of the second phase lies over the hash table of the first.
 struct WaveLds {
     union {
@@ -115,46 +164,8 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
         __builtin_amdgcn_wave_barrier();
 
         DFL_MARK(0);
-        // ---- CRC-32: 256 pieces of q bytes, four per lane (four independent table walks keep the LDS pipe busy), every
-        // piece's register started at 0; the pieces are joined below: running B behind A is  r_AB = r_A * x^(8|B|) + r_B
-        // in GF(2)[x] mod P (crc_chain), an associative rule, so a lane folds its four and the wave reduces in six steps
-        const int q = (len + 255) / 256;
-        uint32_t crc_r = 0, crc_x = 0x80000000u;      // the lane's four pieces as one: register from 0, x^(8 * its bytes)
-        {
-            if (q != xq_for) { xq = crc_xpow8((uint64_t)q); xq4 = crc_mulmod(xq, xq); xq4 = crc_mulmod(xq4, xq4); xq_for = q; }
-            int a[4], n[4];
-            uint32_t c[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { a[j] = min(len, (4 * lane + j) * q); n[j] = min(len, a[j] + q) - a[j]; }
-            int i = 0;
-            for (; i + 8 <= n[3]; i += 8) {      // (n[0] >= n[1] >= n[2] >= n[3])
-                uint64_t v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = load8(in + a[j] + i);
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { c[j] = S.crc_tab[(c[j] ^ (uint32_t)(v[j] >> (8 * k))) & 0xFFu] ^ (c[j] >> 8); }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                for (int t = i; t < n[j]; ++t) c[j] = S.crc_tab[(c[j] ^ in[a[j] + t]) & 0xFFu] ^ (c[j] >> 8);
-            // the lane's fold; only the block's last piece is shorter than q (and the ones behind it empty)
-            if (__ballot(n[3] != q) == 0) {
-                crc_r = crc_chain(crc_chain(crc_chain(c[0], c[1], xq), c[2], xq), c[3], xq);
-                crc_x = xq4;
-            } else {
-                crc_r = c[0];
-                crc_x = n[0] == q ? xq : crc_xpow8((uint64_t)n[0]);
-#pragma unroll
-                for (int j = 1; j < 4; ++j) {
-                    const uint32_t xj = n[j] == q ? xq : crc_xpow8((uint64_t)n[j]);
-                    crc_r = crc_chain(crc_r, c[j], xj);
-                    crc_x = crc_mulmod(crc_x, xj);
-                }
-            }
-        }
-
+        // ---- CRC-32 of the payload
+        const uint32_t crc = wave_crc32(in, len, S.crc_tab, lane, xq_for, xq, xq4);
         DFL_MARK(1);
         // ---- LZ77 in three sweeps over the block, 64 positions per step.  A sweep never waits for a load that depends on
         // another load of the same step's chain more than once, and what it needs next is already on its way: the text is
@@ -418,13 +429,6 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
         }
         DFL_MARK(6);
         // ---- CRC chain, framing
-        // lanes 2o apart join their runs of o lanes: (r, x) <- (r * x' + r', x * x'); lane 0 ends up with the whole block
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t r2 = __shfl_down(crc_r, o), x2 = __shfl_down(crc_x, o);
-            crc_r = crc_chain(crc_r, r2, x2);
-            crc_x = crc_mulmod(crc_x, x2);
-        }
-        const uint32_t reg = crc_chain(0xFFFFFFFFu, (uint32_t)__builtin_amdgcn_readfirstlane((int)crc_r), (uint32_t)__builtin_amdgcn_readfirstlane((int)crc_x));
         // (atomic / plain stores of this wave to its own slot: complete before the kernel ends, nobody else reads them earlier)
         if (lane == 0) {
             const uint32_t total = BGZF_HEAD + body_bytes + BGZF_TAIL;
@@ -433,7 +437,7 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
         }
         // (the trailer may share an 8-byte word with the last bits of the stream: a byte store and an atomic OR of zeros
         // into those bytes give the same word in either order)
-        if (lane == 0) bgzf_trailer(block + BGZF_HEAD + body_bytes, reg ^ 0xFFFFFFFFu, (uint32_t)len);
+        if (lane == 0) bgzf_trailer(block + BGZF_HEAD + body_bytes, crc, (uint32_t)len);
         DFL_MARK(7);
     }
 }

@@ -629,6 +629,9 @@ int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uin
         const unsigned grid = std::min<unsigned>(nb, r->inflate_grid);
         hipLaunchKernelGGL(k_inflate, dim3(grid), dim3(64 * INF_WAVES), 0, r->st, A);
         HIP_TRY(hipGetLastError());
+        // the blocks' checksums, as bgzf_read verifies them
+        hipLaunchKernelGGL(k_block_crc, dim3(std::min<unsigned>((nb + 3) / 4, 256 * 16)), dim3(256), 0, r->st, A);
+        HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemsetAsync((char *)r->text.p + text, 0, 64, r->st));
     HIP_TRY(hipEventRecord(r->t1, r->st));
@@ -648,8 +651,10 @@ int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uin
         if (nb) {
             std::vector<uint32_t> stt(nb);
             HIP_TRY(hipMemcpy(stt.data(), r->status.p, (size_t)nb * 4, hipMemcpyDeviceToHost));
-            for (uint32_t b = 0; b < nb; ++b)
+            for (uint32_t b = 0; b < nb; ++b) {
+                if (stt[b] == INF_BAD_CRC) return fail(KBBQ_EIO, "BGZF block %u of the chunk: CRC32 checksum mismatch", b);
                 if (stt[b] != INF_OK) return fail(KBBQ_EIO, "BGZF block %u of the chunk does not inflate (code %u)", b, stt[b]);
+            }
         }
     }
     const uint64_t n_rec = n_lines / 4;

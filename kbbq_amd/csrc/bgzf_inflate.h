@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bgzf_device.h"
 #include "deflate_common.h"
 
 namespace kbbq {
@@ -528,6 +529,26 @@ __global__ void __launch_bounds__(64 * INF_WAVES, 6) k_inflate(InflateArgs A) {
         }
         if (lane == 0) A.status[blk] = err;
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- the blocks' CRC-32 (what bgzf_read checks per block: "CRC32 checksum mismatch"): one wavefront per block over the
+// inflated bytes, against the value in the block's trailer; a block whose inflation already failed keeps that status
+enum : uint32_t { INF_BAD_CRC = 9 };
+__global__ void __launch_bounds__(256) k_block_crc(InflateArgs A) {
+    __shared__ uint32_t tab[256];
+    tab[threadIdx.x] = crc_table_entry(threadIdx.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    int xq_for = -1;
+    uint32_t xq = 0, xq4 = 0;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    for (uint32_t blk = wave; blk < A.n_blocks; blk += n_waves) {
+        if (A.status[blk] != INF_OK) continue;
+        const uint8_t *t = A.comp + A.c_off[blk] + A.c_len[blk];      // CRC32 then ISIZE, little-endian (RFC 1952)
+        const uint32_t want = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        const uint32_t got = wave_crc32(A.out + A.o_off[blk], (int)A.o_len[blk], tab, lane, xq_for, xq, xq4);
+        if (lane == 0 && got != want) A.status[blk] = INF_BAD_CRC;
     }
 }
 

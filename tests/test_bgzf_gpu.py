@@ -147,6 +147,84 @@ def test_inflate_on_the_device_every_block_type(level):
     r.close()
 
 
+def bgzf_member(body, raw):
+    import struct
+    return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(body) + 25) + body +
+            struct.pack("<II", zlib.crc32(raw), len(raw)))
+
+
+EOF_BLOCK = b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0\x1b\0\x03\0\0\0\0\0\0\0\0\0"
+
+
+def test_inflate_fixed_codes_and_several_deflate_blocks_in_one_member():
+    """Shapes bgzip does not write but RFC 1951 allows and htslib reads: fixed Huffman codes (Z_FIXED), a member whose stream is
+    several DEFLATE blocks of different kinds (full flushes between pieces compressed with different strategies: dynamic,
+    stored through an incompressible piece, fixed), an empty member in the middle of the file."""
+    recs, text = make_records(2500, seed=12)
+    members = []
+    for at in range(0, len(text), 30000):
+        raw = text[at:at + 30000]
+        kind = (at // 30000) % 3
+        if kind == 0:
+            co = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_FIXED)
+            body = co.compress(raw) + co.flush()
+        elif kind == 1:
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            body = co.compress(raw[:9000]) + co.flush(zlib.Z_FULL_FLUSH)      # dynamic block + an empty stored block
+            body += co.compress(raw[9000:20000]) + co.flush(zlib.Z_SYNC_FLUSH)
+            body += co.compress(raw[20000:]) + co.flush()
+        else:
+            co = zlib.compressobj(1, zlib.DEFLATED, -15, 8, zlib.Z_HUFFMAN_ONLY)
+            body = co.compress(raw) + co.flush()
+        members.append(bgzf_member(body, raw))
+        if kind == 1:
+            members.append(bgzf_member(zlib.compressobj(6, zlib.DEFLATED, -15).flush(), b""))      # an empty member
+    r = bgzf.FastqReader()
+    info = r.chunk(b"".join(members) + EOF_BLOCK, True)
+    assert info["flags"] == 0 and info["n_records"] == len(recs) and info["text_bytes"] == len(text)
+    d = r.batch()
+    got = download_batch(d)
+    want_q = np.frombuffer("".join(x[3] for x in recs).encode(), dtype=np.uint8) - 33
+    assert np.array_equal(got["qual"], want_q)
+    _lib.check(_lib.lib().kbbq_reads_free(None, ctypes.byref(d)))
+    r.close()
+
+
+def test_damaged_blocks_are_reported_not_followed():
+    """What bgzf_read answers with an error: a flipped bit in the DEFLATE stream (bad code, bad distance, wrong size, or --
+    when the stream still decodes to the right number of bytes -- the CRC-32), a wrong CRC in the trailer, a wrong ISIZE.
+    The reader must return an error for every one of them and stay usable."""
+    recs, text = make_records(1500, seed=3)
+    good = bgzip(text, 6, block=20000)
+    r = bgzf.FastqReader()
+    rng = np.random.RandomState(9)
+    n_err = 0
+    for trial in range(40):
+        bad = bytearray(good)
+        if trial < 30:
+            at = int(rng.randint(18, len(good) - 28 - 8))      # somewhere in the members (a header byte breaks the framing: flag or error)
+            bad[at] ^= 1 << int(rng.randint(0, 8))
+        elif trial < 35:
+            # the CRC of the first member
+            bsize = bad[16] | (bad[17] << 8)
+            bad[bsize + 1 - 8] ^= 0x40
+        else:
+            bsize = bad[16] | (bad[17] << 8)
+            bad[bsize + 1 - 4] ^= 0x01                          # ISIZE
+        try:
+            info = r.chunk(bytes(bad), True)
+            # a flip inside a header's fixed fields makes the file "not BGZF" (flag) or cuts the chunk short
+            assert info["flags"] != 0 or info["n_records"] != len(recs) or info["consumed"] != len(bad), trial
+        except Exception as ex:
+            n_err += 1
+            assert "BGZF" in str(ex) or "CRC" in str(ex) or "block" in str(ex), ex
+        r.rewind()
+    assert n_err >= 30
+    info = r.chunk(good, True)                                   # and the reader still works
+    assert info["flags"] == 0 and info["n_records"] == len(recs)
+    r.close()
+
+
 @pytest.mark.parametrize("uniform,lower", [(True, False), (False, False), (False, True)])
 def test_reader_batch_equals_the_host_packing(uniform, lower):
     """The device batch of a chunk (2-bit bases, N mask, qualities - 33, offsets, second-in-pair flags, off-case bits) equals
