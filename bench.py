@@ -581,6 +581,25 @@ def main():
     info = None
     for _ in range(args.warmup):
         info = run_step(e, xch, batches, ordinals, out_buf, hints)
+
+    def exclusive_step():
+        """One untimed step with every kernel in order on one stream: exclusive kernel durations (see below)."""
+        from kbbq_amd import _lib as _l
+        _l.check(e.L.kbbq_engine_tune(e.h, b"no_overlap", 1))
+        e.profile_reset()
+        keep = dict(xch.ms)
+        run_step(e, xch, batches, ordinals, out_buf, hints)
+        barrier()
+        p = e.profile()
+        xch.ms.clear()
+        xch.ms.update(keep)      # the exchange times quoted are the timed region's alone
+        _l.check(e.L.kbbq_engine_tune(e.h, b"no_overlap", 0))
+        return p
+
+    # (the card slows down under sustained load -- the same kernel measures 9.0 ms on a cold card and 9.8-10.3 ms a
+    # minute later -- so the exclusive step is taken on both sides of the timed region: the roofline quotes the one behind)
+    want_excl = not os.environ.get("KBBQ_NO_OVERLAP") and not args.no_exclusive_step
+    prof_excl_before = exclusive_step() if want_excl and args.warmup > 0 else None
     e.profile_reset()
     xch.reset_timers()
     barrier()
@@ -600,18 +619,7 @@ def main():
     # Untimed, same process, same resident reads: one more step with every kernel in order on one stream.  In the timed
     # region passes 1-3 keep two streams busy, so a kernel's event duration there includes time it shared the chip; the
     # roofline line of the dominant kernel is quoted on its EXCLUSIVE duration from this step (both are printed).
-    prof_excl = None
-    if not os.environ.get("KBBQ_NO_OVERLAP") and not args.no_exclusive_step:
-        from kbbq_amd import _lib as _l
-        _l.check(e.L.kbbq_engine_tune(e.h, b"no_overlap", 1))
-        e.profile_reset()
-        xch_ms_timed = dict(xch.ms)
-        run_step(e, xch, batches, ordinals, out_buf, hints)
-        barrier()
-        prof_excl = e.profile()
-        xch.ms.clear()
-        xch.ms.update(xch_ms_timed)      # the exchange times quoted are the timed region's alone
-        _l.check(e.L.kbbq_engine_tune(e.h, b"no_overlap", 0))
+    prof_excl = exclusive_step() if want_excl else None
     # untimed: digest of the recalibrated qualities (rank-count invariant)
     digest = 0
     for bt in batches:
@@ -656,7 +664,8 @@ def main():
                         kernels[name]["exclusive_GBps"] = round(kernels[name]["alg_bytes_per_launch"] / (ms / launches) / 1e6, 1)
             dom = max((k for k in kernels if "exclusive_GBps" in kernels[k]), key=lambda k: kernels[k]["exclusive_avg_ms"] * kernels[k]["launches"])
             dom_ms, dom_GBps = kernels[dom]["exclusive_avg_ms"], kernels[dom]["exclusive_GBps"]
-            dom_how = "exclusive: an untimed in-order step of this same run (kbbq_engine_tune no_overlap), HIP events on the engine's stream"
+            dom_how = ("exclusive: an untimed in-order step of this same run behind the timed region (kbbq_engine_tune no_overlap), HIP events on "
+                       "the engine's stream; avg_launch_ms_before_timed_region: the same step taken behind the warm-up, on a cooler card")
         else:
             dom = max((k for k in kernels if "achieved_GBps" in kernels[k] and not kernels[k].get("overlapped")),
                       key=lambda k: kernels[k]["total_ms"])
@@ -693,6 +702,8 @@ def main():
                     algorithmic_bytes_per_launch=kernels[dom]["alg_bytes_per_launch"], avg_launch_ms=dom_ms,
                     duration_measured_in=dom_how,
                     timed_region_avg_launch_ms=kernels[dom]["avg_ms"],
+                    avg_launch_ms_before_timed_region=(round(prof_excl_before[dom][1] / prof_excl_before[dom][0], 4)
+                                                       if prof_excl and prof_excl_before and prof_excl_before.get(dom, (0, 0))[0] else None),
                     timed_region_note="in the timed region the kernel shares the chip with the insert side of pass 2 on the side stream; "
                                       "its event duration there is not its own cost",
                     traffic_note=traffic_note,
