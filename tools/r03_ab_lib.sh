@@ -12,6 +12,6 @@ for i in 1 2; do
 import json
 d=json.loads(open('$R/gpurun_out/r03_${tag}_${which}_$i.json').read().strip().splitlines()[-1])
 k=d['kernels']
-print('$which $i', 'step', d['ms_per_step'], 'k_infer', k['k_infer']['avg_ms'], 'k_scan', k['k_scan_trusted']['avg_ms'], 'walk', k['k_correct_wave']['avg_ms'], 'digest', d['result']['recal_qual_sum'])"
+print('$which $i', 'step', d['ms_per_step'], 'k_infer', k['k_infer']['avg_ms'], 'k_scan', k['k_scan_trusted']['avg_ms'], 'walk', k['k_correct_wave']['avg_ms'], 'emit', k['k_emit_sampled']['avg_ms'], k['k_emit_trusted']['avg_ms'], 'split', k['k_split_trusted']['avg_ms'], 'apply', k['k_apply_trusted']['avg_ms'], 'digest', d['result']['recal_qual_sum'])"
   done
 done
