@@ -99,7 +99,8 @@ def run_cases(n_cases, seed0, verbose=True):
                 d = dict(d)
                 q = d["qual"].copy()
                 r2 = np.random.RandomState(case)
-                q = np.where(q <= 2, q, r2.randint(3, 45, size=len(q))).astype(np.uint8)
+                top = 45 if r2.randint(0, 3) else 256      # a third of these: qualities up to 255 (256 quality rows, round 3)
+                q = np.where(q <= 2, q, r2.randint(3, top, size=len(q))).astype(np.uint8)
                 d["qual"] = np.ascontiguousarray(q)
             t0 = time.time()
             ora = common.run_oracle(d, k=k, alpha=alpha, n_rg=n_rg)
