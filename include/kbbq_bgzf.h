@@ -105,6 +105,17 @@ int kbbq_fastq_reader_attach(kbbq_fastq_reader *r, const kbbq_reads *batch);
  * Every block's CRC-32 and ISIZE are checked as bgzf_read checks them; a block that does not inflate to them is
  * KBBQ_EIO ("CRC32 checksum mismatch" / "does not inflate"). */
 int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uint64_t n_bytes, int32_t last, kbbq_fastq_chunk *info);
+/* kbbq_reads_upload (kbbq_engine.h) for a batch whose bases are still text: host's bases / nmask / offcase are ignored,
+ * seq_text holds its n_bases sequence characters and is packed on the device (kbbq_pack_bases_case's table).  e may be
+ * NULL like there. */
+int kbbq_reads_upload_text(kbbq_engine *e, const kbbq_reads *host, const uint8_t *seq_text, kbbq_reads *dev);
+/* The inflater alone, for callers that parse on the host (BAM; FASTQ shapes the record kernels do not take): the whole
+ * BGZF blocks at the front of file_bytes[0, n_bytes) whose inflated bytes fit in `capacity` are inflated on the device,
+ * checked (CRC-32, ISIZE) and copied to host_out (page-locked memory makes the copy DMA).  *consumed: bytes of the input
+ * taken (feed the rest again in front of the next piece), *produced: bytes written.  What bgzf_read does under
+ * sam_read1 / kseq_read (htsiter.hh:64-66,101-126), at the device's rate instead of a thread pool's. */
+int kbbq_fastq_reader_inflate(kbbq_fastq_reader *r, const uint8_t *file_bytes, uint64_t n_bytes, uint8_t *host_out, uint64_t capacity,
+                              uint64_t *consumed, uint64_t *produced);
 /* The current chunk's records as a device batch (arrays owned by the library: kbbq_reads_free): bases, N mask, qualities,
  * offsets (NULL and read_len for equally long reads), second-in-pair flags, off-case bits when a base is not upper-case. */
 int kbbq_fastq_reader_batch(kbbq_fastq_reader *r, kbbq_reads *dev);

@@ -162,6 +162,9 @@ SYMBOLS = {
     "kbbq_fastq_reader_keep": (ctypes.c_int, [c_vp, ctypes.c_int32]),
     "kbbq_fastq_reader_kept": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "kbbq_fastq_reader_select": (ctypes.c_int, [c_vp, ctypes.c_uint64, ctypes.c_void_p]),
+    "kbbq_reads_upload_text": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads), ctypes.c_void_p, ctypes.POINTER(Reads)]),
+    "kbbq_fastq_reader_inflate": (ctypes.c_int, [c_vp, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
+                                                 ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "kbbq_fastq_reader_attach": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads)]),
     "kbbq_fastq_reader_kernel_ms": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }

@@ -196,8 +196,7 @@ void BamChunkParser::produce() {
     std::vector<unsigned char> carry;
     bool eof = false, bad = false, failed = false;
     while (!eof && !bad && !stopping()) {
-        auto chunk = std::make_shared<std::vector<unsigned char>>();
-        chunk->resize(carry.size() + kChunk);
+        auto chunk = chunk_buffer(carry.size() + kChunk);
         if (!carry.empty()) memcpy(chunk->data(), carry.data(), carry.size());
         size_t have = carry.size();
         carry.clear();
@@ -207,8 +206,7 @@ void BamChunkParser::produce() {
             if (got <= 0) { eof = true; break; }
             have += (size_t)got;
         }
-        chunk->resize(have);
-        if (have == 0 && !failed) break;
+        if (have == 0 && !failed) break;      // (the buffer keeps its size: `have` says how much of it is the stream's)
         const unsigned char *b = chunk->data();
         // whole records: [block_size u32][block]; a partial one waits for the next chunk, a malformed size or -- at the
         // end of the stream -- a partial record ends the stream after the piece before it

@@ -716,6 +716,101 @@ int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uin
     return KBBQ_OK;
 }
 
+int kbbq_fastq_reader_inflate(kbbq_fastq_reader *r, const uint8_t *file_bytes, uint64_t n_bytes, uint8_t *host_out, uint64_t capacity,
+                              uint64_t *consumed, uint64_t *produced) {
+    if (!r || !host_out || !consumed || !produced || (!file_bytes && n_bytes)) return fail(KBBQ_EINVAL, "bad argument");
+    KbbqDeviceGuard guard(r->device);
+    HIP_TRY(guard.err);
+    stash_current(r);
+    r->selected = -1;
+    r->have_chunk = false;
+    *consumed = *produced = 0;
+    // whole blocks while their inflated bytes fit
+    std::vector<uint64_t> c_off, o_off;
+    std::vector<uint32_t> c_len, o_len;
+    uint64_t at = 0, text = 0;
+    while (at + 18 <= n_bytes) {
+        const uint8_t *h = file_bytes + at;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return fail(KBBQ_EIO, "not a BGZF block at byte %llu of the piece", (unsigned long long)at);
+        const uint32_t xlen = h[10] | (h[11] << 8);
+        if (at + 12 + xlen > n_bytes) break;
+        uint32_t bsize = 0;
+        for (uint32_t x = 0; x + 4 <= xlen;) {
+            const uint8_t *sf = h + 12 + x;
+            const uint32_t slen = sf[2] | (sf[3] << 8);
+            if (sf[0] == 66 && sf[1] == 67 && slen == 2 && x + 6 <= xlen) bsize = (sf[4] | (sf[5] << 8)) + 1u;
+            x += 4 + slen;
+        }
+        if (!bsize || bsize < 12 + xlen + 8) return fail(KBBQ_EIO, "a BGZF header without its BC field at byte %llu of the piece", (unsigned long long)at);
+        if (at + bsize > n_bytes) break;
+        const uint8_t *tail = h + bsize - 8;
+        const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+        if (isize > 65536) return fail(KBBQ_EIO, "a BGZF block of %u bytes", isize);
+        if (text + isize > capacity) break;
+        if (isize) {
+            c_off.push_back(at + 12 + xlen);
+            c_len.push_back(bsize - (12 + xlen) - 8);
+            o_off.push_back(text);
+            o_len.push_back(isize);
+            text += isize;
+        }
+        at += bsize;
+    }
+    *consumed = at;
+    *produced = text;
+    const uint32_t nb = (uint32_t)c_off.size();
+    if (!nb) return KBBQ_OK;
+    int rc;
+    if ((rc = r->comp.reserve(at + 4096))) return rc;
+    if ((rc = r->text.reserve(text + 4096))) return rc;
+    if ((rc = r->status.reserve((size_t)nb * 4 + 64))) return rc;
+    const size_t meta_bytes = (size_t)nb * 24 + 64;
+    if ((rc = r->blk_meta.reserve(meta_bytes))) return rc;
+    if ((rc = r->h_meta.reserve(std::max<size_t>(meta_bytes, (size_t)nb * 4 + 64)))) return rc;
+    uint64_t *hm = (uint64_t *)r->h_meta.p;
+    memcpy(hm, c_off.data(), (size_t)nb * 8);
+    memcpy(hm + nb, o_off.data(), (size_t)nb * 8);
+    memcpy((uint32_t *)(hm + 2 * (size_t)nb), c_len.data(), (size_t)nb * 4);
+    memcpy((uint32_t *)(hm + 2 * (size_t)nb) + nb, o_len.data(), (size_t)nb * 4);
+    HIP_TRY(hipMemcpyAsync(r->comp.p, file_bytes, at, hipMemcpyHostToDevice, r->st));
+    HIP_TRY(hipMemsetAsync((char *)r->comp.p + at, 0, 4096, r->st));
+    HIP_TRY(hipMemcpyAsync(r->blk_meta.p, hm, (size_t)nb * 24, hipMemcpyHostToDevice, r->st));
+    HIP_TRY(hipEventRecord(r->t0, r->st));
+    InflateArgs A;
+    A.comp = (const uint8_t *)r->comp.p;
+    A.c_off = (const uint64_t *)r->blk_meta.p;
+    A.o_off = A.c_off + nb;
+    A.c_len = (const uint32_t *)(A.c_off + 2 * (size_t)nb);
+    A.o_len = A.c_len + nb;
+    A.out = (uint8_t *)r->text.p;
+    A.n_blocks = nb;
+    A.status = (uint32_t *)r->status.p;
+    if (!r->inflate_grid) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, r->device));
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate, 64 * INF_WAVES, 0));
+        r->inflate_grid = (unsigned)std::max(1, prop.multiProcessorCount) * (unsigned)std::max(1, per_cu);
+    }
+    hipLaunchKernelGGL(k_inflate, dim3(std::min<unsigned>(nb, r->inflate_grid)), dim3(64 * INF_WAVES), 0, r->st, A);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_block_crc, dim3(std::min<unsigned>((nb + 3) / 4, 256 * 16)), dim3(256), 0, r->st, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(r->t1, r->st));
+    HIP_TRY(hipMemcpyAsync(host_out, r->text.p, text, hipMemcpyDeviceToHost, r->st));
+    // (the status words travel through the page-locked meta buffer, which the block table no longer needs)
+    HIP_TRY(hipMemcpyAsync(r->h_meta.p, r->status.p, (size_t)nb * 4, hipMemcpyDeviceToHost, r->st));
+    HIP_TRY(hipStreamSynchronize(r->st));
+    const uint32_t *stt = (const uint32_t *)r->h_meta.p;
+    for (uint32_t b = 0; b < nb; ++b) {
+        if (stt[b] == INF_BAD_CRC) return fail(KBBQ_EIO, "BGZF block %u of the piece: CRC32 checksum mismatch", b);
+        if (stt[b] != INF_OK) return fail(KBBQ_EIO, "BGZF block %u of the piece does not inflate (code %u)", b, stt[b]);
+    }
+    float a = 0;
+    if (hipEventElapsedTime(&a, r->t0, r->t1) == hipSuccess) r->ms_inflate += a;
+    return KBBQ_OK;
+}
+
 int kbbq_fastq_reader_batch(kbbq_fastq_reader *r, kbbq_reads *dev) {
     if (!r || !dev) return fail(KBBQ_EINVAL, "null argument");
     if (!r->have_chunk || !r->n_records || r->selected >= 0) return fail(KBBQ_ESTATE, "no records in the current chunk");
@@ -819,6 +914,53 @@ int kbbq_fastq_reader_attach(kbbq_fastq_reader *r, const kbbq_reads *batch) {
     r->att_bases = batch->bases;
     r->att_nmask = batch->nmask;
     r->att_offcase = batch->offcase;
+    return KBBQ_OK;
+}
+
+// A host batch made resident with its bases packed ON the device: the sequence characters travel as they are (1 byte per
+// base) and k_pack_text makes the 2-bit words, the non-ACGT mask and the off-case bits there -- kbbq_pack_bases_case's
+// table, 40x its rate -- so the host thread that assembles the batches does not spend a third of its time packing.
+int kbbq_reads_upload_text(kbbq_engine *e, const kbbq_reads *host, const uint8_t *seq_text, kbbq_reads *dev) {
+    if (!host || !seq_text || !dev) return fail(KBBQ_EINVAL, "null argument");
+    if (host->on_device) return fail(KBBQ_EINVAL, "batch is already on the device");
+    kbbq_reads h2 = *host;
+    h2.bases = nullptr; h2.nmask = nullptr; h2.offcase = nullptr;
+    int rc = kbbq_reads_upload(e, &h2, dev);      // qualities, offsets, flags, read groups
+    if (rc) return rc;
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    const uint64_t nbases = host->n_bases, words = nbases / 64 + 1;
+    void *b = nullptr, *m = nullptr, *oc = nullptr, *text = nullptr, *cnt = nullptr;
+    auto give_up = [&](hipError_t he, const char *what) {
+        void *all[] = {b, m, oc, text, cnt};
+        for (void *x : all) (void)hipFree(x);
+        kbbq_reads_free(e, dev);
+        return fail(he == hipErrorOutOfMemory ? KBBQ_ENOMEM : KBBQ_EIO, "%s: %s", what, hipGetErrorString(he));
+    };
+    hipError_t he;
+    if ((he = hipMalloc(&b, (2 * words + 2) * 8)) != hipSuccess) return give_up(he, "bases");
+    if ((he = hipMalloc(&m, (words + 2) * 8)) != hipSuccess) return give_up(he, "mask");
+    if ((he = hipMalloc(&oc, (words + 2) * 8)) != hipSuccess) return give_up(he, "off-case bits");
+    if ((he = hipMalloc(&text, nbases + 64)) != hipSuccess) return give_up(he, "sequence text");
+    if ((he = hipMalloc(&cnt, 16)) != hipSuccess) return give_up(he, "counter");
+    hipStream_t st = nullptr;      // the null stream: ordered behind kbbq_reads_upload's copies, which it waited for
+    if ((he = hipMemsetAsync(cnt, 0, 16, st)) != hipSuccess) return give_up(he, "memset");
+    (void)hipMemsetAsync((char *)b + 2 * words * 8, 0, 16, st);
+    (void)hipMemsetAsync((char *)m + words * 8, 0, 16, st);
+    (void)hipMemsetAsync((char *)oc + words * 8, 0, 16, st);
+    if ((he = hipMemcpyAsync(text, seq_text, nbases, hipMemcpyHostToDevice, st)) != hipSuccess) return give_up(he, "upload of the sequence text");
+    hipLaunchKernelGGL(k_pack_text, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, (const uint8_t *)text, nbases, (uint64_t *)b, (uint64_t *)m,
+                       (uint64_t *)oc, (unsigned long long *)cnt);
+    if ((he = hipGetLastError()) != hipSuccess) return give_up(he, "k_pack_text");
+    unsigned long long counts[2] = {0, 0};
+    if ((he = hipMemcpyAsync(counts, cnt, 16, hipMemcpyDeviceToHost, st)) != hipSuccess) return give_up(he, "counts");
+    if ((he = hipStreamSynchronize(st)) != hipSuccess) return give_up(he, "packing");
+    (void)hipFree(text);
+    (void)hipFree(cnt);
+    if (!counts[0]) { (void)hipFree(oc); oc = nullptr; }
+    dev->bases = (const uint64_t *)b;
+    dev->nmask = (const uint64_t *)m;
+    dev->offcase = (const uint64_t *)oc;
     return KBBQ_OK;
 }
 

@@ -224,6 +224,9 @@ private:
 
 }  // namespace
 
+static BgzfSourceFactory g_bgzf_factory = nullptr;
+void set_bgzf_source_factory(BgzfSourceFactory f) { g_bgzf_factory = f; }
+
 std::unique_ptr<ByteSource> open_bytes(const std::string &path, int threads) {
     if (threads > 1 && path != "-") {
         FILE *f = fopen(path.c_str(), "rb");
@@ -231,6 +234,10 @@ std::unique_ptr<ByteSource> open_bytes(const std::string &path, int threads) {
         unsigned char head[18];
         const size_t got = fread(head, 1, sizeof head, f);
         if (bgzf_block_size(head, got)) {
+            if (g_bgzf_factory) {
+                std::unique_ptr<ByteSource> dev = g_bgzf_factory(path);
+                if (dev) { fclose(f); return dev; }
+            }
             rewind(f);
             return std::unique_ptr<ByteSource>(new BgzfSource(f, threads));
         }
@@ -349,6 +356,24 @@ int looks_like_record_start(const unsigned char *b, size_t p, size_t end) {
 // ---- the pipeline: reader thread -> pool -> consumer, in order ----
 ChunkPipeline::~ChunkPipeline() { stop(); }
 
+std::shared_ptr<std::vector<unsigned char>> ChunkPipeline::chunk_buffer(size_t bytes) {
+    std::vector<unsigned char> v;
+    {
+        std::lock_guard<std::mutex> lk(buffers_->mu);
+        if (!buffers_->free.empty()) { v = std::move(buffers_->free.back()); buffers_->free.pop_back(); }
+    }
+    if (v.size() < bytes) v.resize(bytes);
+    std::shared_ptr<BufferPool> pool = buffers_;      // (outlives the pipeline if a piece is still held somewhere)
+    auto *raw = new std::vector<unsigned char>(std::move(v));
+    return std::shared_ptr<std::vector<unsigned char>>(raw, [pool](std::vector<unsigned char> *p) {
+        {
+            std::lock_guard<std::mutex> lk(pool->mu);
+            if (pool->free.size() < 8) pool->free.push_back(std::move(*p));
+        }
+        delete p;
+    });
+}
+
 void ChunkPipeline::start() {
     max_in_flight_ = (size_t)parse_threads_ * 6 + 16;
     for (int i = 0; i < parse_threads_; ++i) pool_.emplace_back(&ChunkPipeline::worker, this);
@@ -441,8 +466,7 @@ void FastqChunkParser::produce() {
     std::vector<unsigned char> carry;
     bool eof = false;
     while (!eof && !stopping()) {
-        auto chunk = std::make_shared<std::vector<unsigned char>>();
-        chunk->resize(carry.size() + kChunkBytes);
+        auto chunk = chunk_buffer(carry.size() + kChunkBytes);
         if (!carry.empty()) memcpy(chunk->data(), carry.data(), carry.size());
         size_t have = carry.size();
         carry.clear();
@@ -453,8 +477,7 @@ void FastqChunkParser::produce() {
             if (got <= 0) { eof = true; break; }
             have += (size_t)got;
         }
-        chunk->resize(have);
-        if (have == 0) break;
+        if (have == 0) break;      // (the buffer keeps its size: `have` says how much of it is the stream's)
         const unsigned char *b = chunk->data();
         size_t cut = have;
         bool whole_complex = failed;      // (a read error: FastqReader decides what the passes see of such a file)

@@ -34,6 +34,10 @@ public:
     virtual int read(void *dst, unsigned n) = 0;   // bytes delivered (short only at the end), 0 at EOF, < 0 on error
 };
 std::unique_ptr<ByteSource> open_bytes(const std::string &path, int threads);
+// Another inflater for BGZF files (the command line installs the one on the GPU, kbbq_cli.cc: DeviceBgzfSource): called by
+// open_bytes for a regular BGZF file; a null result falls back to the thread pool.
+typedef std::unique_ptr<ByteSource> (*BgzfSourceFactory)(const std::string &path);
+void set_bgzf_source_factory(BgzfSourceFactory f);
 
 struct FastqRecord {
     std::string name, comment, seq, qual;
@@ -99,12 +103,21 @@ protected:
     void stop();
     bool stopping();
     void submit(std::shared_ptr<Job> job); // blocks while too many pieces are in flight
+    // A chunk buffer of at least `bytes` (its size is what it was left at: the caller tracks how much it filled).  Buffers
+    // come back when their last job is done and are handed out again -- a fresh 32 MB vector per chunk is zero-filled and
+    // faulted in page by page, which cost the reader thread more than reading the bytes.
+    std::shared_ptr<std::vector<unsigned char>> chunk_buffer(size_t bytes);
     virtual void produce() = 0;            // reader thread: cut the stream into jobs
     virtual void parse(Job &job) = 0;      // worker thread
 
 private:
     void run_reader();
     void worker();
+    struct BufferPool {
+        std::mutex mu;
+        std::vector<std::vector<unsigned char>> free;
+    };
+    std::shared_ptr<BufferPool> buffers_ = std::make_shared<BufferPool>();
     int parse_threads_;
     std::vector<std::thread> pool_;
     std::deque<std::shared_ptr<Job>> order_, todo_;      // guarded by mu_

@@ -26,6 +26,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -338,6 +339,133 @@ private:
     bool failed_ = false, closed_ = false;
 };
 
+// BGZF input for the host parsers (BAM; FASTQ that the device's record kernels do not take) inflated on the GPU
+// (kbbq_fastq_reader_inflate): a thread reads the file in 32 MB pieces, the device inflates and checks their blocks and
+// copies the bytes into one of two page-locked buffers, read() hands them on.  What bgzf_mt's thread pool does for the
+// reference (htsiter.hh:64-66,110-112) -- the pool's cores go to the parsers instead.  Installed as fastq_io's BGZF source;
+// KBBQ_DEVICE_INFLATE=0 (or KBBQ_HOST_DEFLATE=1) leaves the thread pool in place.
+class DeviceBgzfSource : public ByteSource {
+public:
+    static std::unique_ptr<ByteSource> open(const std::string &path) {
+        std::unique_ptr<DeviceBgzfSource> s(new DeviceBgzfSource);
+        if (!s->init(path)) return nullptr;
+        return std::unique_ptr<ByteSource>(s.release());
+    }
+    ~DeviceBgzfSource() override {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+        if (reader_) kbbq_fastq_reader_destroy(reader_);
+        for (int i = 0; i < 2; ++i) if (out_[i]) kbbq_host_free(out_[i]);
+        if (in_) kbbq_host_free(in_);
+        if (fd_ >= 0) ::close(fd_);
+    }
+    int read(void *dst, unsigned n) override {
+        unsigned char *to = (unsigned char *)dst;
+        unsigned done = 0;
+        while (done < n) {
+            if (have_ && pos_ < fill_[cur_]) {
+                const size_t take = std::min<size_t>(n - done, fill_[cur_] - pos_);
+                memcpy(to + done, out_[cur_] + pos_, take);
+                pos_ += take;
+                done += (unsigned)take;
+                continue;
+            }
+            std::unique_lock<std::mutex> lk(mu_);
+            if (have_) {          // the buffer is used up: give it back
+                ready_[cur_] = false;
+                have_ = false;
+                cur_ ^= 1;
+                cv_.notify_all();
+            }
+            cv_.wait(lk, [&] { return ready_[cur_] || eof_ || error_; });
+            if (error_) return -1;
+            if (!ready_[cur_]) break;      // end of file
+            have_ = true;
+            pos_ = 0;
+        }
+        return (int)done;
+    }
+
+private:
+    bool init(const std::string &path) {
+        fd_ = ::open(path.c_str(), O_RDONLY);
+        if (fd_ < 0) return false;
+        void *p = nullptr;
+        if (kbbq_host_alloc(kIn + kCarry, &p) < 0) return false;
+        in_ = (uint8_t *)p;
+        for (int i = 0; i < 2; ++i) {
+            if (kbbq_host_alloc(kOut, &p) < 0) return false;
+            out_[i] = (uint8_t *)p;
+        }
+        if (kbbq_fastq_reader_create(0, &reader_) < 0) return false;
+        th_ = std::thread([this] { run(); });
+        return true;
+    }
+    void run() {
+        uint64_t left = 0;      // unconsumed bytes at the front of in_ (the tail of the piece before)
+        int k = 0;
+        bool file_end = false;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return quit_ || !ready_[k]; });
+                if (quit_) return;
+            }
+            // top the input buffer up
+            while (!file_end && left < kIn) {
+                const ssize_t r = ::read(fd_, in_ + left, (size_t)(kIn + kCarry - left));
+                if (r < 0) { fail(); return; }
+                if (r == 0) { file_end = true; break; }
+                left += (uint64_t)r;
+            }
+            if (left == 0) break;
+            uint64_t consumed = 0, produced = 0;
+            if (kbbq_fastq_reader_inflate(reader_, in_, left, out_[k], kOut, &consumed, &produced) < 0) {
+                std::cerr << "BGZF input: " << kbbq_last_error() << std::endl;
+                fail();
+                return;
+            }
+            if (consumed == 0) {      // no whole block in what is left: a truncated file
+                if (file_end) { std::cerr << "BGZF input: the file ends inside a block." << std::endl; fail(); return; }
+                fail();
+                return;
+            }
+            memmove(in_, in_ + consumed, (size_t)(left - consumed));
+            left -= consumed;
+            if (produced) {
+                std::lock_guard<std::mutex> lk(mu_);
+                fill_[k] = produced;
+                ready_[k] = true;
+                k ^= 1;
+            }
+            cv_.notify_all();
+        }
+        std::lock_guard<std::mutex> lk(mu_);
+        eof_ = true;
+        cv_.notify_all();
+    }
+    void fail() {
+        std::lock_guard<std::mutex> lk(mu_);
+        error_ = true;
+        cv_.notify_all();
+    }
+    static constexpr uint64_t kIn = 32ull << 20, kCarry = 1ull << 17, kOut = 256ull << 20;
+    int fd_ = -1;
+    kbbq_fastq_reader *reader_ = nullptr;
+    uint8_t *in_ = nullptr, *out_[2] = {nullptr, nullptr};
+    uint64_t fill_[2] = {0, 0};
+    bool ready_[2] = {false, false}, have_ = false, eof_ = false, error_ = false, quit_ = false;
+    int cur_ = 0;
+    size_t pos_ = 0;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::thread th_;
+};
+
 // The input side on the GPU (include/kbbq_bgzf.h: kbbq_fastq_reader): a BGZF-compressed four-line FASTQ file goes to the
 // device as it is, chunk by chunk -- inflate, line index, record rules and packing are kernels -- and every chunk becomes one
 // resident batch.  Pass 4 feeds the same chunks again and the records' text is re-assembled there around the new qualities.
@@ -541,13 +669,25 @@ struct Batch {
         std::vector<int> rg_map;
         bool complex = false;
         int lens_per_record = 3;                    // RecordStore's layout: FASTQ 3 lengths per record, BAM 1
+        double wait_s = 0;                          // time spent waiting for the parsers' next piece
+    };
+    // The pieces' arrays are copied into the batch's by a few threads at once (the segments and their places are known
+    // first): one thread moved 580 bytes per BAM record -- sequence, qualities, the alignment block -- at 5 GB/s, which was
+    // most of the first scan's wall time behind 16 parsers.
+    struct Segment {
+        std::shared_ptr<ReadPiece> piece;
+        size_t a, b;                 // records [a, b) of the piece
+        std::vector<int> rg_map;
+        size_t read0, base0, blob0;  // where they go in the batch
     };
     bool fill_fast(Fast &f, ReadGroups &groups, size_t max_reads, RecordStore *store) {
         fq_recs.clear(); bam_recs.clear(); seq.clear(); qual.clear(); flags.clear(); rg.clear();
         off.assign(1, 0);
         saw_empty = false;
         longest = 0;
-        while (rg.size() < max_reads) {
+        std::vector<Segment> segs;
+        size_t n_reads = 0, n_bases = 0, n_blob = 0;
+        while (n_reads < max_reads) {
             if (f.cur && f.at == f.cur->n() && f.cur->fatal_at >= 0) {      // (the piece's parse stopped at that record)
                 if (!f.cur->fatal_msg.empty()) std::cerr << f.cur->fatal_msg << std::flush;
                 else std::cerr << put_now << " Error: read name '" << f.cur->fatal_name << "' is shorter than 2 characters before the first '_'." << std::endl;
@@ -555,7 +695,9 @@ struct Batch {
                 return false;
             }
             if (!f.cur || f.at == f.cur->n()) {
+                const auto tw = std::chrono::steady_clock::now();
                 f.cur = f.parser->next();
+                f.wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
                 f.at = 0;
                 if (!f.cur) break;
                 if (f.cur->complex) { f.complex = true; return false; }
@@ -564,44 +706,82 @@ struct Batch {
                 continue;
             }
             const FastqPiece &P = *f.cur;
-            const size_t take = std::min(P.n() - f.at, max_reads - rg.size());
-            const size_t a = f.at, b = f.at + take;
-            const uint64_t base = seq.size() - P.off[a];
-            seq.insert(seq.end(), P.seq.begin() + P.off[a], P.seq.begin() + P.off[b]);
-            qual.insert(qual.end(), P.qual.begin() + P.off[a], P.qual.begin() + P.off[b]);
-            for (size_t r = a; r < b; ++r) {
-                off.push_back(base + P.off[r + 1]);
-                longest = std::max<size_t>(longest, P.off[r + 1] - P.off[r]);
-                if (P.off[r + 1] == P.off[r]) saw_empty = true;
-                rg.push_back((uint16_t)f.rg_map[P.rg[r]]);
-            }
-            flags.insert(flags.end(), P.second.begin() + a, P.second.begin() + b);
-            if (store) {
-                store->blob.append(P.blob, P.blob_off[a], P.blob_off[b] - P.blob_off[a]);
-                store->lens.insert(store->lens.end(), P.lens.begin() + f.lens_per_record * a, P.lens.begin() + f.lens_per_record * b);
-            }
-            f.at = b;
+            const size_t take = std::min(P.n() - f.at, max_reads - n_reads);
+            Segment g;
+            g.piece = f.cur; g.a = f.at; g.b = f.at + take; g.rg_map = f.rg_map;
+            g.read0 = n_reads; g.base0 = n_bases; g.blob0 = n_blob;
+            n_reads += take;
+            n_bases += (size_t)(P.off[g.b] - P.off[g.a]);
+            if (store) n_blob += (size_t)(P.blob_off[g.b] - P.blob_off[g.a]);
+            segs.push_back(std::move(g));
+            f.at += take;
         }
+        if (!n_reads) return finish();
+        seq.resize(n_bases); qual.resize(n_bases); flags.resize(n_reads); rg.resize(n_reads); off.resize(n_reads + 1);
+        const size_t blob_base = store ? store->blob.size() : 0, lens_base = store ? store->lens.size() : 0;
+        if (store) { store->blob.resize(blob_base + n_blob); store->lens.resize(lens_base + (size_t)f.lens_per_record * n_reads); }
+        std::vector<size_t> seg_longest(segs.size(), 0);
+        std::vector<char> seg_empty(segs.size(), 0);
+        auto copy_segment = [&](size_t i) {
+            const Segment &g = segs[i];
+            const ReadPiece &P = *g.piece;
+            const uint64_t p0 = P.off[g.a];
+            memcpy(seq.data() + g.base0, P.seq.data() + p0, (size_t)(P.off[g.b] - p0));
+            memcpy(qual.data() + g.base0, P.qual.data() + p0, (size_t)(P.off[g.b] - p0));
+            memcpy(flags.data() + g.read0, P.second.data() + g.a, g.b - g.a);
+            size_t lg = 0;
+            bool empty = false;
+            for (size_t r = g.a; r < g.b; ++r) {
+                const uint64_t l = P.off[r + 1] - P.off[r];
+                off[g.read0 + (r - g.a) + 1] = g.base0 + (P.off[r + 1] - p0);
+                lg = std::max<size_t>(lg, (size_t)l);
+                empty = empty || l == 0;
+                rg[g.read0 + (r - g.a)] = (uint16_t)g.rg_map[P.rg[r]];
+            }
+            seg_longest[i] = lg;
+            seg_empty[i] = empty;
+            if (store) {
+                memcpy(&store->blob[blob_base + g.blob0], P.blob.data() + P.blob_off[g.a], (size_t)(P.blob_off[g.b] - P.blob_off[g.a]));
+                memcpy(store->lens.data() + lens_base + (size_t)f.lens_per_record * g.read0, P.lens.data() + (size_t)f.lens_per_record * g.a,
+                       (size_t)f.lens_per_record * (g.b - g.a) * sizeof(uint32_t));
+            }
+        };
+        const size_t n_threads = std::min<size_t>(segs.size(), (size_t)std::max(1, std::min(g_io_threads, 8)));
+        if (n_threads <= 1) {
+            for (size_t i = 0; i < segs.size(); ++i) copy_segment(i);
+        } else {
+            std::atomic<size_t> next_seg{0};
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < n_threads; ++t)
+                th.emplace_back([&] { for (size_t i; (i = next_seg.fetch_add(1)) < segs.size();) copy_segment(i); });
+            for (auto &x : th) x.join();
+        }
+        for (size_t i = 0; i < segs.size(); ++i) { longest = std::max(longest, seg_longest[i]); saw_empty = saw_empty || seg_empty[i]; }
         return finish();
     }
 
+    // false: the batch is only going to be made resident with kbbq_reads_upload_text, which packs the bases on the device
+    // (the first scan: packing 1.6e8 bases took this thread as long as everything else it does for a batch)
+    bool pack_on_host = true;
     bool finish() {
         if (rg.empty()) return false;
-        bases.assign(seq.size() / 32 + 2, 0);
-        nmask.assign(seq.size() / 64 + 2, 0);
         qual.resize(seq.size() + 16, 0);
-        // FASTQ text may be soft-masked: the raw case of a base matters to three comparisons of the reference
-        // (include/kbbq_engine.h: kbbq_reads.offcase); the bit array only travels when some base is off-case.
-        // BAM sequences come out of bam_seq_str upper-case (readutils.hh:30-42).
-        offcase.assign(seq.size() / 64 + 2, 0);
         uint64_t n_offcase = 0;
-        kbbq_pack_bases_case(seq.data(), seq.size(), bases.data(), nmask.data(), offcase.data(), &n_offcase);
+        if (pack_on_host) {
+            bases.assign(seq.size() / 32 + 2, 0);
+            nmask.assign(seq.size() / 64 + 2, 0);
+            // FASTQ text may be soft-masked: the raw case of a base matters to three comparisons of the reference
+            // (include/kbbq_engine.h: kbbq_reads.offcase); the bit array only travels when some base is off-case.
+            // BAM sequences come out of bam_seq_str upper-case (readutils.hh:30-42).
+            offcase.assign(seq.size() / 64 + 2, 0);
+            kbbq_pack_bases_case(seq.data(), seq.size(), bases.data(), nmask.data(), offcase.data(), &n_offcase);
+        }
         memset(&c, 0, sizeof c);
         c.offcase = n_offcase ? offcase.data() : nullptr;
         c.n_reads = rg.size();
         c.n_bases = seq.size();
-        c.bases = bases.data();
-        c.nmask = nmask.data();
+        c.bases = pack_on_host ? bases.data() : nullptr;
+        c.nmask = pack_on_host ? nmask.data() : nullptr;
         c.qual = qual.data();
         c.offsets = off.data();
         c.flags = flags.data();
@@ -694,6 +874,34 @@ static int io_test(int argc, char *argv[]) {
                    it.seq.c_str(), q.c_str());
         }
         printf("#end %d\n", rc);
+        return 0;
+    }
+    if (what == "bam-scan" && argc > 3) {     // the first scan's host side alone, timed: --io-test bam-scan FILE [parse threads] [keep records 0/1]
+        const int pt = argc > 4 ? atoi(argv[4]) : 4;
+        const bool keep = argc > 5 ? atoi(argv[5]) != 0 : true;
+        g_io_threads = io_threads;
+        const auto t0 = std::chrono::steady_clock::now();
+        Batch::Fast ff;
+        auto *bp = new BamChunkParser(argv[3], false, std::max(2, io_threads), pt, keep);
+        ff.parser.reset(bp);
+        ff.lens_per_record = 1;
+        if (!bp->ok()) return 2;
+        Batch batch;
+        batch.pack_on_host = false;
+        ReadGroups groups;
+        uint64_t reads = 0, bases = 0;
+        double fill_s = 0;
+        for (;;) {
+            RecordStore st;
+            const auto a = std::chrono::steady_clock::now();
+            if (!batch.fill_fast(ff, groups, (size_t)1 << 20, keep ? &st : nullptr)) break;
+            fill_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
+            reads += batch.c.n_reads;
+            bases += batch.c.n_bases;
+        }
+        const double all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("reads %llu bases %llu wall %.3f s (in fill_fast %.3f s, of it waiting for pieces %.3f s) %.2f Gbases/s\n", (unsigned long long)reads,
+               (unsigned long long)bases, all, fill_s, ff.wait_s, bases / all / 1e9);
         return 0;
     }
     if (what == "bam-fast" && argc > 3) {     // the same lines from the block-parallel BAM parser: --io-test bam-fast FILE [use-oq] [threads]
@@ -810,6 +1018,9 @@ int main(int argc, char *argv[]) {
         return 1;
     }
     const bool is_bam = fmt == Format::bam;
+    // BGZF input that the host parsers read (BAM always) is inflated on the GPU as well
+    if (!(getenv("KBBQ_HOST_DEFLATE") && atoi(getenv("KBBQ_HOST_DEFLATE")) != 0) && !(getenv("KBBQ_DEVICE_INFLATE") && atoi(getenv("KBBQ_DEVICE_INFLATE")) == 0))
+        set_bgzf_source_factory(&DeviceBgzfSource::open);
 
     // One scan before the engine exists: total length (the reference's coverage pass, kbbq.cc:229-250),
     // read groups, longest read.  The packed batches of this scan are uploaded as they are made and stay
@@ -915,6 +1126,7 @@ int main(int argc, char *argv[]) {
             dev_in.close();
         }
     }
+    batch.pack_on_host = false;      // (the scan's batches only ever go to the device: packed there)
     for (int attempt = 0; attempt < 2 && !dev_in.active; ++attempt) {
         const bool fast = attempt == 0 && g_io_threads > 1 && !(getenv("KBBQ_SERIAL_PARSE") && atoi(getenv("KBBQ_SERIAL_PARSE")));
         if (attempt == 1) {
@@ -966,7 +1178,8 @@ int main(int argc, char *argv[]) {
                 // qualities 1 B + bases 1/4 + N mask 1/8 + two hint arrays 1/4 per base; offsets, flags, read groups per read
                 const uint64_t need = batch.c.n_bases * 13 / 8 + batch.c.n_reads * 16 + (1 << 16);
                 kbbq_reads d;
-                if (resident.bytes + need > resident.budget || kbbq_reads_upload(nullptr, &batch.c, &d) < 0) {
+                if (resident.bytes + need > resident.budget ||
+                    (batch.pack_on_host ? kbbq_reads_upload(nullptr, &batch.c, &d) : kbbq_reads_upload_text(nullptr, &batch.c, batch.seq.data(), &d)) < 0) {
                     resident.drop();
                 } else if (kbbq_reads_alloc_hints(&d) < 0) {
                     kbbq_reads_free(nullptr, &d);
@@ -991,6 +1204,7 @@ int main(int argc, char *argv[]) {
         if (fast && ff.complex) continue;
         break;
     }
+    batch.pack_on_host = true;       // (streaming passes hand host batches to the engine)
     if (longest > KBBQ_MAX_READ_LEN) {
         std::cerr << put_now << " Error: reads longer than " << KBBQ_MAX_READ_LEN << " bases are not supported by the GPU engine." << std::endl;
         return 1;
