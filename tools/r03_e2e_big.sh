@@ -19,7 +19,10 @@ echo "files ready"
 # reads and inflates the input again (KBBQ_KEEP_TEXT=0: the text of the first scan is not kept in HBM)
 for name in ${2:-first second file rescan}; do
     s=$(date +%s%N)
-    if [ $name = file ]; then
+    if [[ $name =~ ^file([0-9]+)$ ]]; then      # fileN: into a file with N writer threads
+        KBBQ_WRITE_THREADS=${BASH_REMATCH[1]} KBBQ_TIMING=1 KBBQ_SEED=777 $R/kbbq_amd/kbbq -g 1000000000 $D/big.fq.gz 2> $D/err_$name.txt > $D/out.fq.gz || { echo "$name failed"; tail -3 $D/err_$name.txt; exit 1; }
+        stat -c %s $D/out.fq.gz > $D/out_$name.bytes; rm -f $D/out.fq.gz
+    elif [ $name = file ]; then
         KBBQ_TIMING=1 KBBQ_SEED=777 $R/kbbq_amd/kbbq -g 1000000000 $D/big.fq.gz 2> $D/err_$name.txt > $D/out.fq.gz || { echo "$name failed"; tail -3 $D/err_$name.txt; exit 1; }
         stat -c %s $D/out.fq.gz > $D/out_$name.bytes; rm -f $D/out.fq.gz
     elif [ $name = rescan ]; then
