@@ -408,16 +408,25 @@ __global__ void __launch_bounds__(64 * INF_WAVES, 6) k_inflate(InflateArgs A) {
             const uint32_t dd_info = (uint32_t)lane < n_dd ? distance_info(S.sorted_small[lane]) : 0u;
             // ---- the block's symbols
             for (;;) {
-                B.refill();
-                uint32_t bits = B.bits();
-                uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.ll[bits & ((1u << INF_TBITS) - 1)]);
-                if (ent & 0x30u) {
-                    // one to three literals: lane i writes byte i (the lanes behind them write bytes that the following symbols
-                    // overwrite: what lies up to 63 bytes ahead of the output position is nobody's yet)
+                // Runs of literals stay in a loop of their own (lookup, store, advance; nothing else is live across it):
+                // one to three literals per turn, lane i writes byte i -- the lanes behind them write bytes that the
+                // following symbols overwrite (what lies up to 63 bytes ahead of the output position is nobody's yet).
+                uint32_t bits, ent;
+                bool line_done = false;
+                for (;;) {
+                    B.refill();
+                    bits = B.bits();
+                    ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.ll[bits & ((1u << INF_TBITS) - 1)]);
+                    if (!(ent & 0x30u)) break;
                     S.ring[(sp + (uint32_t)lane) & MASK] = (uint8_t)(ent >> lit_shift);
                     B.drop((int)(ent & 15u));
                     sp += (ent >> 4) & 3u;
-                    if (sp >= next_line) { __builtin_amdgcn_wave_barrier(); flush_lines(); if (err != INF_OK) break; }
+                    if (sp >= next_line) { line_done = true; break; }
+                }
+                if (line_done) {
+                    __builtin_amdgcn_wave_barrier();
+                    flush_lines();
+                    if (err != INF_OK) break;
                     continue;
                 }
                 int len;
