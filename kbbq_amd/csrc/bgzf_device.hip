@@ -356,6 +356,9 @@ struct kbbq_fastq_reader {
     bool packed_is_exact = false;              // the current chunk's batch gives its sequence text back (set by batch())
     const uint64_t *att_bases = nullptr, *att_nmask = nullptr, *att_offcase = nullptr;      // kbbq_fastq_reader_attach
     std::vector<Kept> kept;
+    // the short form's arrays are carved from slabs of 2 GB (four hipMalloc per chunk were four trips to the driver)
+    std::vector<Buf> slabs;
+    size_t slab_used = 0;
     bool keeping = false;
     int64_t selected = -1;      // the kept chunk that is the current one (pass 4), or -1: the live buffers
     uint64_t kept_bytes = 0;
@@ -391,10 +394,34 @@ FastqIndex index_of(kbbq_fastq_reader *r, uint64_t cap) {
 }
 
 void release_kept(kbbq_fastq_reader *r) {
-    for (auto &k : r->kept) { k.text.release(); k.idx_u32.release(); k.base_sz.release(); k.text_sz.release(); k.names.release(); k.lens.release(); }
+    for (auto &k : r->kept) {
+        if (k.short_form) continue;      // (its arrays are pieces of the slabs)
+        k.text.release(); k.idx_u32.release(); k.base_sz.release(); k.text_sz.release();
+    }
+    for (auto &b : r->slabs) b.release();
+    r->slabs.clear();
+    r->slab_used = 0;
     r->kept.clear();
     r->kept_bytes = 0;
     r->selected = -1;
+}
+
+// a piece of a slab (256-byte aligned); null when the device is full
+void *slab_piece(kbbq_fastq_reader *r, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (r->slabs.empty() || r->slab_used + bytes > r->slabs.back().bytes) {
+        // slabs grow from 64 MB to 2 GB (a small file keeps little)
+        const size_t next = r->slabs.empty() ? ((size_t)64 << 20) : std::min<size_t>(r->slabs.back().bytes * 2, (size_t)2 << 30);
+        Buf b;
+        b.exact = true;
+        if (b.reserve(std::max(next, bytes))) { (void)hipGetLastError(); return nullptr; }
+        r->slabs.push_back(b);
+        r->slab_used = 0;
+    }
+    void *p = (char *)r->slabs.back().p + r->slab_used;
+    r->slab_used += bytes;
+    r->kept_bytes += bytes;
+    return p;
 }
 
 // The live chunk moves into the kept list (its buffers with it: the next chunk allocates its own).
@@ -408,11 +435,13 @@ void stash_current(kbbq_fastq_reader *r) {
     const uint64_t names_bytes = r->out_text_bytes - 2 * r->n_bases - 6 * n;      // sum of name + comment lengths
     bool short_form = r->packed_is_exact;
     if (short_form) {
-        // names, lengths and the two scans into buffers of exactly their size; the working buffers stay the reader's
-        k.names.exact = k.lens.exact = k.base_sz.exact = k.text_sz.exact = true;
-        if (k.names.reserve(names_bytes + 64) || k.lens.reserve(n * 8) || k.base_sz.reserve((n + 1) * 8) || k.text_sz.reserve((n + 1) * 8)) {
-            (void)hipGetLastError();
-            k.names.release(); k.lens.release(); k.base_sz.release(); k.text_sz.release();
+        // names, lengths and the two scans into pieces of exactly their size; the working buffers stay the reader's
+        k.names.p = slab_piece(r, names_bytes + 64);
+        k.lens.p = k.names.p ? slab_piece(r, n * 8) : nullptr;
+        k.base_sz.p = k.lens.p ? slab_piece(r, (n + 1) * 8) : nullptr;
+        k.text_sz.p = k.base_sz.p ? slab_piece(r, (n + 1) * 8) : nullptr;
+        if (!k.text_sz.p) {
+            k.names.p = k.lens.p = k.base_sz.p = k.text_sz.p = nullptr;
             short_form = false;      // (the long form below takes the buffers that exist already)
         } else {
             const FastqIndex X = index_of(r, n);
@@ -422,7 +451,6 @@ void stash_current(kbbq_fastq_reader *r) {
             (void)hipMemcpyAsync(k.text_sz.p, X.text_sz, (n + 1) * 8, hipMemcpyDeviceToDevice, r->st);
             // (the reader's next chunk is queued on the same stream: it overwrites the working buffers behind these)
             k.short_form = true;
-            r->kept_bytes += k.names.bytes + k.lens.bytes + k.base_sz.bytes + k.text_sz.bytes;
         }
     }
     if (!short_form) {
