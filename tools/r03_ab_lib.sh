@@ -4,7 +4,7 @@
 set -o pipefail
 V=$1; tag=${2:-ab}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-for i in 1 2; do
+for i in ${ROUNDS:-1 2}; do
   for which in base variant; do
     if [ $which = variant ]; then export KBBQ_LIB=$R/$V; else unset KBBQ_LIB; fi
     KBBQ_NO_OVERLAP=1 timeout -k 10 300 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-exclusive-step > $R/gpurun_out/r03_${tag}_${which}_$i.json 2> $R/gpurun_out/r03_${tag}_${which}_$i.log || { tail -3 $R/gpurun_out/r03_${tag}_${which}_$i.log; exit 1; }
