@@ -340,27 +340,45 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply(FiltDev F, BucketDev B)
     if (n == 0) return;
     const uint64_t b0 = (uint64_t)sub << SUB_BITS;
     const uint32_t nblk = (uint32_t)min((uint64_t)SUB_BLOCKS, F.n_blocks - b0);
+    const uint32_t *src = B.l2 + (size_t)sub * B.cap2;
+    // Record -> pattern (L2) -> LDS is a chain of two loads per record, and a subslice has only ~20 records per lane: the
+    // chain is kept two rounds deep -- the records of round r + 2 and the patterns of round r + 1 travel while round r is
+    // applied; the first of them go out before the subslice itself is loaded.  The loads are unconditional (clamped
+    // index: a lane past the end fetches the last record again and applies nothing), so that nothing waits for them early.
+    const uint32_t last = n - 1;
+    // three register sets take turns (round r uses set r mod 3; no register is copied: a copy of a loaded register waits
+    // for the load): behind round r its set receives the records of round r + 3; in round r the set of round r + 1,
+    // whose records were sent for two rounds ago, sends for its patterns
+    uint32_t v[3][4];
+    ulonglong2 p[3][4];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[s][j] = src[min(threadIdx.x + (4 * s + j) * APPLY_THREADS, last)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[0][j] = F.patterns[v[0][j] & 0xFFFFu];
     for (uint32_t i = threadIdx.x; i < nblk; i += APPLY_THREADS) blk_l[i] = F.table[b0 + i];
     __syncthreads();
-    const uint32_t *src = B.l2 + (size_t)sub * B.cap2;
     unsigned long long *w = reinterpret_cast<unsigned long long *>(blk_l);
-    // four records per lane in flight: record -> pattern (L2) -> LDS is a chain of two loads per record
-    for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 4 * APPLY_THREADS) {
-        uint32_t v[4];
-        ulonglong2 p[4];
+    for (uint32_t i1 = threadIdx.x; i1 < n; i1 += 12 * APPLY_THREADS) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const uint32_t i = i0 + j * APPLY_THREADS; v[j] = i < n ? src[i] : 0xFFFFFFFFu; }
+        for (int s = 0; s < 3; ++s) {
+            const uint32_t i0 = i1 + 4 * s * APPLY_THREADS;      // (rounds past the end apply nothing)
+            const int s2 = (s + 1) % 3;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) p[j] = F.patterns[v[j] & 0xFFFFu];
+            for (int j = 0; j < 4; ++j) p[s2][j] = F.patterns[v[s2][j] & 0xFFFFu];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (i0 + j * APPLY_THREADS < n) {
-                const uint32_t bi = v[j] >> 16;
-                const ulonglong2 t = blk_l[bi];
-                const unsigned long long mx = p[j].x & ~t.x, my = p[j].y & ~t.y;
-                if (mx) atomicOr(&w[2 * bi], mx);
-                if (my) atomicOr(&w[2 * bi + 1], my);
+            for (int j = 0; j < 4; ++j) {
+                if (i0 + j * APPLY_THREADS < n) {
+                    const uint32_t bi = v[s][j] >> 16;
+                    const ulonglong2 t = blk_l[bi];
+                    const unsigned long long mx = p[s][j].x & ~t.x, my = p[s][j].y & ~t.y;
+                    if (mx) atomicOr(&w[2 * bi], mx);
+                    if (my) atomicOr(&w[2 * bi + 1], my);
+                }
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[s][j] = src[min(i0 + (12 + j) * APPLY_THREADS, last)];
         }
     }
     __syncthreads();
