@@ -1131,6 +1131,7 @@ int main(int argc, char *argv[]) {
         }
     }
     batch.pack_on_host = false;      // (the scan's batches only ever go to the device: packed there)
+    bool scan_fast = false, any_empty = false;
     for (int attempt = 0; attempt < 2 && !dev_in.active; ++attempt) {
         const bool fast = attempt == 0 && g_io_threads > 1 && !(getenv("KBBQ_SERIAL_PARSE") && atoi(getenv("KBBQ_SERIAL_PARSE")));
         if (attempt == 1) {
@@ -1167,6 +1168,7 @@ int main(int argc, char *argv[]) {
             if (is_bam) bam_header = static_cast<BamSource *>(in.get())->header();
         }
         bool counting = true;    // the coverage pass stops at the first empty read; the other passes do not
+        scan_fast = fast;
         for (;;) {
             const bool keep = resident.on && resident.keep_recs;
             RecordStore st;
@@ -1177,6 +1179,7 @@ int main(int argc, char *argv[]) {
             }
             longest = std::max(longest, batch.longest);
             n_reads += batch.c.n_reads;
+            if (batch.saw_empty) any_empty = true;
             if (batch.saw_empty && resident.on) resident.drop();
             if (resident.on && batch.longest <= KBBQ_MAX_READ_LEN) {
                 // qualities 1 B + bases 1/4 + N mask 1/8 + two hint arrays 1/4 per base; offsets, flags, read groups per read
@@ -1205,9 +1208,32 @@ int main(int argc, char *argv[]) {
             }
         }
         if (batch.fatal) return 1;
-        if (fast && ff.complex) continue;
+        if (fast && ff.complex) { scan_fast = false; continue; }
         break;
     }
+    // Passes 1-3 of the streaming mode (the reads did not stay in HBM) read the file through the block-parallel parser as
+    // well when the first scan found the stream of its shape and no empty read in it (an empty read ends the reference's
+    // sampling loop: the serial reader's case); the serial reader otherwise.
+    struct PassInput {
+        std::unique_ptr<Source> serial;
+        Batch::Fast fast;
+        bool use_fast = false;
+        bool next(Batch &b, ReadGroups &g, size_t max_reads) {
+            return use_fast ? b.fill_fast(fast, g, max_reads, nullptr) : b.fill(*serial, g, max_reads, false);
+        }
+    };
+    const bool passes_fast = scan_fast && !any_empty && !dev_in.active;
+    auto open_pass = [&]() -> std::unique_ptr<PassInput> {
+        std::unique_ptr<PassInput> in(new PassInput);
+        if (passes_fast) {
+            in->use_fast = true;
+            if (is_bam) { in->fast.parser.reset(new BamChunkParser(filename, use_oq, g_io_threads, out_threads, false)); in->fast.lens_per_record = 1; }
+            else in->fast.parser.reset(new FastqChunkParser(filename, g_io_threads, out_threads, false));
+        } else {
+            in->serial = open_source(filename, is_bam, use_oq);
+        }
+        return in;
+    };
     batch.pack_on_host = true;       // (streaming passes hand host batches to the engine)
     if (longest > KBBQ_MAX_READ_LEN) {
         std::cerr << put_now << " Error: reads longer than " << KBBQ_MAX_READ_LEN << " bases are not supported by the GPU engine." << std::endl;
@@ -1288,9 +1314,9 @@ int main(int argc, char *argv[]) {
                     ordinal += nk;
                 }
             } else {
-                std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
+                std::unique_ptr<PassInput> in = open_pass();
                 batch.stop_at_empty = true;
-                while (batch.fill(*in, groups, batch_reads, false)) {
+                while (in->next(batch, groups, batch_reads)) {
                     if (kbbq_sample_batch(e, &batch.c, ordinal) < 0) return fail_engine("sampling");
                     if (kbbq_count_kmer_positions(e, &batch.c, &nk) < 0) return fail_engine("sampling");
                     ordinal += nk;
@@ -1331,8 +1357,8 @@ int main(int argc, char *argv[]) {
                 for (auto &d : resident.dev)
                     if (kbbq_trusted_batch(e, &d, nullptr) < 0) return fail_engine("finding trusted kmers");
             } else {
-                std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
-                while (batch.fill(*in, groups, batch_reads, false))
+                std::unique_ptr<PassInput> in = open_pass();
+                while (in->next(batch, groups, batch_reads))
                     if (kbbq_trusted_batch(e, &batch.c, nullptr) < 0) return fail_engine("finding trusted kmers");
                 if (batch.fatal) return 1;
             }
@@ -1346,8 +1372,8 @@ int main(int argc, char *argv[]) {
                 for (auto &d : resident.dev)
                     if (kbbq_errors_batch(e, &d, nullptr) < 0) return fail_engine("finding errors");
             } else {
-                std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
-                while (batch.fill(*in, groups, batch_reads, false))
+                std::unique_ptr<PassInput> in = open_pass();
+                while (in->next(batch, groups, batch_reads))
                     if (kbbq_errors_batch(e, &batch.c, nullptr) < 0) return fail_engine("finding errors");
                 if (batch.fatal) return 1;
             }
