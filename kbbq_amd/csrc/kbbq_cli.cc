@@ -1642,6 +1642,55 @@ int main(int argc, char *argv[]) {
                     }
                 }
             }
+        } else if (passes_fast && !is_bam && dev_out) {
+            // FASTQ whose records were not kept (streaming mode, or the host cache was too small): the parsers decode the
+            // file once more, and every batch goes the way of a resident one -- on the device (the resident copy, or
+            // uploaded now with its bases packed there), pass 4 into a device array, the text assembled and deflated there.
+            PassInput in;
+            in.use_fast = true;
+            in.fast.parser.reset(new FastqChunkParser(filename, g_io_threads, out_threads, true));
+            void *d_q[2] = {nullptr, nullptr};
+            size_t d_q_bytes[2] = {0, 0};
+            kbbq_reads up[2];
+            bool up_live[2] = {false, false};
+            struct FreeAll {
+                kbbq_engine *e; void **q; kbbq_reads *up; bool *live;
+                ~FreeAll() { for (int i = 0; i < 2; ++i) { if (q[i]) kbbq_device_free(e, q[i]); if (live[i]) kbbq_reads_free(e, &up[i]); } }
+            } free_all{e, d_q, up, up_live};
+            batch.pack_on_host = false;
+            size_t bi = 0;
+            for (size_t n = 0;; ++n) {
+                RecordStore st;
+                if (!batch.fill_fast(in.fast, groups, batch_reads, &st)) break;
+                const int t = (int)(n & 1);
+                // the arrays of slot t were read by the submission two batches ago: that one must be through
+                while (dev_out->in_flight() >= 2) if (!dev_out->drain()) return 1;
+                if (up_live[t]) { kbbq_reads_free(e, &up[t]); up_live[t] = false; }
+                const kbbq_reads *d = nullptr;
+                if (resident.on) {
+                    if (bi >= resident.dev.size() || resident.dev[bi].n_bases != batch.c.n_bases || resident.dev[bi].n_reads != batch.c.n_reads) {
+                        std::cerr << put_now << " Error: the input changed between the passes." << std::endl;
+                        return 1;
+                    }
+                    d = &resident.dev[bi++];
+                } else {
+                    if (kbbq_reads_upload_text(e, &batch.c, batch.seq.data(), &up[t]) < 0) return fail_engine("recalibrating");
+                    up_live[t] = true;
+                    d = &up[t];
+                }
+                if (d_q_bytes[t] < d->n_bases + 16) {
+                    if (d_q[t] && kbbq_device_free(e, d_q[t]) < 0) return fail_engine("recalibrating");
+                    d_q[t] = nullptr;
+                    d_q_bytes[t] = d->n_bases + d->n_bases / 8 + 4096;
+                    if (kbbq_device_alloc(e, d_q_bytes[t], &d_q[t]) < 0) return fail_engine("recalibrating");
+                }
+                if (kbbq_recalibrate_batch(e, d, (uint8_t *)d_q[t]) < 0) return fail_engine("recalibrating");
+                if (!dev_out->fastq_batch(st.blob.data(), st.lens.data(), d->n_reads, (const uint8_t *)d_q[t], d->offsets, d->read_len, kbbq_engine_stream(e)))
+                    return 1;
+            }
+            batch.pack_on_host = true;
+            if (batch.fatal) return 1;
+            if (!dev_out->drain()) return 1;
         } else {
             std::unique_ptr<Source> in = open_source(filename, is_bam, use_oq);
             size_t bi = 0;
