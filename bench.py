@@ -370,8 +370,9 @@ def pcie_inclusive(genome_len, coverage, local_rank):
     def bound(bytes_per_pass, duplex=False):
         # a pass cannot be faster than its transfers or than its resident time; `duplex`: the two directions of pass 4 fully
         # overlapped (the link carries both at once; the engine pipelines a host batch's pass 4 in pieces), otherwise summed
-        # (duplex: both directions at once, each at the rate measured WITH the other one running)
-        return sum(max(max(nb * u / (h2d_dx if dwn else h2d), nb * dwn / d2h_dx) if duplex else nb * u / h2d + nb * dwn / d2h, c)
+        # (duplex: both directions at once, each at the rate measured WITH the other one running; a pass that moves bytes
+        # in one direction only is priced at that direction's rate alone)
+        return sum(max(max(nb * u / (h2d_dx if dwn else h2d), nb * dwn / (d2h_dx if u else d2h)) if duplex else nb * u / h2d + nb * dwn / d2h, c)
                    for (u, dwn), c in zip(bytes_per_pass, t_res))
 
     def mode(t, bytes_per_pass, text):
@@ -745,6 +746,9 @@ def main():
             shard.free()      # the leg needs HBM for its own resident copy
             shard = None
             line["pcie_inclusive"] = pcie_inclusive(args.pcie_genome_len, cov, local_rank)
+            # the product's other shape beside `value` (reads resident): host batches uploaded once over the pinned link
+            line["ingest_inclusive_value"] = line["pcie_inclusive"]["upload_once"]["value"]
+            line["ingest_inclusive_unit"] = "Gbases/s"
         print(json.dumps(line), flush=True)
     if shard is not None:
         shard.free()

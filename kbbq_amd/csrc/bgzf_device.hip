@@ -505,6 +505,8 @@ void kbbq_fastq_reader_destroy(kbbq_fastq_reader *r) {
 
 int kbbq_fastq_reader_rewind(kbbq_fastq_reader *r) {
     if (!r) return fail(KBBQ_EINVAL, "null argument");
+    KbbqDeviceGuard guard(r->device);      // stash_current launches kernels and may allocate
+    HIP_TRY(guard.err);
     stash_current(r);
     r->keeping = false;      // what was kept stays; a second scan keeps nothing more
     r->selected = -1;
@@ -538,6 +540,8 @@ int kbbq_fastq_reader_kept(kbbq_fastq_reader *r, uint64_t *n_chunks, uint64_t *n
 
 int kbbq_fastq_reader_select(kbbq_fastq_reader *r, uint64_t i, kbbq_fastq_chunk *info) {
     if (!r) return fail(KBBQ_EINVAL, "null argument");
+    KbbqDeviceGuard guard(r->device);
+    HIP_TRY(guard.err);
     stash_current(r);
     if (i >= r->kept.size()) return fail(KBBQ_EINVAL, "kept chunk %llu of %llu", (unsigned long long)i, (unsigned long long)r->kept.size());
     const kbbq_fastq_reader::Kept &k = r->kept[i];
@@ -645,7 +649,7 @@ int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uin
         A.out = (uint8_t *)r->text.p;
         A.n_blocks = nb;
         A.status = (uint32_t *)r->status.p;
-        // as many wavefronts as stay resident (13 KB of LDS each): blocks are handed out round-robin, a second round of
+        // as many wavefronts as stay resident (5.6 KB of LDS each: 2 KB ring + 9-bit table): blocks are handed out round-robin, a second round of
         // workgroups would only queue behind the first
         if (!r->inflate_grid) {
             hipDeviceProp_t prop;

@@ -10,9 +10,11 @@
 //                        it in uniform control flow (everything it decides lives in scalar registers) and uses its lanes
 //                        as storage and for the copies: the canonical-code tables sit in vector registers (lane l holds
 //                        the bound of the codes of length l: one compare + ballot finds a code's length, v_readlane
-//                        fetches its symbol), 256 bytes of the compressed stream per vector register, and the
-//                        32 KB window in LDS, where a match is copied by up to 64 lanes at once and from where finished
-//                        4 KB pieces leave for HBM as coalesced 16-byte stores.  No per-symbol memory latency anywhere.
+//                        fetches its symbol), 256 bytes of the compressed stream per vector register, a 512-entry
+//                        literal/length table in LDS, and the most recent 2 KB of output in an LDS ring laid out at
+//                        (HBM address) mod 2 KB: a match inside the ring is an LDS-to-LDS copy by up to 64 lanes, a
+//                        finished 256-byte line leaves for HBM as 64 coalesced dword stores, and a match that reaches
+//                        further back (DEFLATE allows 32 KB) is read back from HBM behind a wait for the wave's own stores.
 //   k_count_newlines / k_newline_positions   where the lines of the inflated text start
 //   k_fastq_records      per record (four lines): name / comment / sequence / quality fields, kseq's rules
 //                        (htsiter.cc:52-59, kseq.h) and the read-name rules of readutils.cc:74-97 that need no dictionary
@@ -40,7 +42,6 @@ constexpr int INF_NEAR = INF_RING - 512;     // a match at most this far back st
                                              // bytes ahead of the output position, see the literal and match copies)
 constexpr int INF_TBITS = 9;                 // the literal/length table is indexed by the next 9 bits of the stream
 constexpr int INF_WAVES = 1;                 // one wavefront per workgroup
-constexpr int INF_LDS_PER_WAVE = INF_RING + (4 << INF_TBITS) + 1536;
 
 // status codes of a block
 enum : uint32_t { INF_OK = 0, INF_BAD_BLOCK_TYPE = 1, INF_BAD_STORED = 2, INF_BAD_CODE = 3, INF_OVERRUN_IN = 4, INF_OVERRUN_OUT = 5,
@@ -54,7 +55,11 @@ struct InflateArgs {
     const uint32_t *o_len;      //            ISIZE
     uint8_t *out;               // (+ 4 KB writable behind the last block: a block that overruns its size is caught a line late)
     uint32_t n_blocks;
-    uint32_t *status;           // per block
+    uint32_t *status;           // per block.  ANY status other than INF_OK invalidates the whole chunk, not only that block's
+                                // bytes: a block whose stream overruns its ISIZE stores one full 256-byte line behind its
+                                // region -- the head of its neighbour's -- before INF_OVERRUN_OUT is raised, and the first
+                                // line of a block is shared with the block before it.  Every caller rejects the chunk
+                                // (kbbq_fastq_reader_chunk / _inflate return an error); never keep "the good blocks".
 };
 
 // The canonical decoder of one alphabet: lane l (1..15) of `lim` holds the exclusive upper bound of the codes of length

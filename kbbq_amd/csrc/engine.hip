@@ -86,6 +86,7 @@ struct Options {
     bool no_pass4_pipeline = false;   // KBBQ_F_NO_PASS4_PIPELINE / KBBQ_NO_PASS4_PIPELINE: pass 4 of a host batch in one piece
     bool pass2_side = true;           // KBBQ_F_PASS2_INORDER / KBBQ_PASS2_SIDE=0 clear it: the insert side of pass 2 beside k_infer
     bool tally_general = false;       // KBBQ_TALLY_GENERAL: the general tally kernel for every batch shape (A/B)
+    bool infer_subset = false;        // KBBQ_INFER_SUBSET=1 / kbbq_engine_tune("infer_subset"): k_infer decides from three of four lookups first
     bool debug_bucket = false;        // KBBQ_DEBUG_BUCKET: one stderr line per flush of the bucketed inserts
     int bucket = -1;                  // KBBQ_F_BUCKET_ON / _OFF, KBBQ_BUCKET=1/0: bucketed / direct inserts; -1: by filter size
     uint64_t bucket_records = 0;      // KBBQ_BUCKET_RECORDS: records gathered per flush (0: a share of the free HBM)
@@ -218,15 +219,18 @@ int ensure_scratch(kbbq_engine *e, int idx, size_t bytes) {
 // quality -> slot map of the tally from the presence bits (256: a quality is any uint8_t).  At most `max_slots`
 // values get a slot (what the LDS tables hold, and never more than 255: 255 means "none"); the rest -- more distinct
 // qualities than any real instrument writes -- are counted through global atomics by the kernels.
-static void plan_tally_slots(TallyPlan &P, const uint32_t mask[8], int max_slots) {
+static void plan_tally_slots(TallyPlan &P, const uint32_t mask[8], int max_slots, int n_rg) {
     memset(P.qslot, 255, sizeof P.qslot);
     memset(P.qof, 0, sizeof P.qof);
     P.n_slots = 0;
     max_slots = std::max(1, std::min(max_slots, 255));
-    int top = -1;
+    int top = -1, distinct = 0;
     for (int q = 0; q < KBBQ_NQ; ++q)
-        if ((mask[q >> 5] >> (q & 31)) & 1) top = q;
-    if (top >= 0 && top + 1 <= max_slots) {
+        if ((mask[q >> 5] >> (q & 31)) & 1) { top = q; ++distinct; }
+    // With several read groups every unused slot is LDS that another read group's tables could have had (binned
+    // qualities {2,11,25,37}: 38 identity slots against 4), and fewer read groups per launch means more passes over
+    // the batch: the identity layout only when it wastes less than half of its slots, or there is one read group.
+    if (top >= 0 && top + 1 <= max_slots && (n_rg <= 1 || 2 * distinct >= top + 1)) {
         // few, small values (the usual FASTQ range): slot = quality, no lookup in the kernels
         for (int q = 0; q <= top; ++q) { P.qof[q] = (uint8_t)q; P.qslot[q] = (uint8_t)q; }
         P.n_slots = top + 1;
@@ -758,6 +762,7 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
         o.no_pass4_pipeline = (fl & KBBQ_F_NO_PASS4_PIPELINE) || env_set("KBBQ_NO_PASS4_PIPELINE");      // (no_overlap implies it, where it is used)
         o.pass2_side = !(fl & KBBQ_F_PASS2_INORDER) && env_int("KBBQ_PASS2_SIDE", 1) != 0;                // (no_overlap switches it off, where it is used)
         o.tally_general = env_set("KBBQ_TALLY_GENERAL");
+        o.infer_subset = env_set("KBBQ_INFER_SUBSET");
         o.debug_bucket = env_set("KBBQ_DEBUG_BUCKET");
         o.bucket = (fl & KBBQ_F_BUCKET_ON) ? 1 : (fl & KBBQ_F_BUCKET_OFF) ? 0 : env_set("KBBQ_BUCKET") ? (env_int("KBBQ_BUCKET", 0) != 0 ? 1 : 0) : -1;
         o.bucket_records = env_u64("KBBQ_BUCKET_RECORDS", 0);
@@ -940,6 +945,8 @@ int kbbq_engine_tune(kbbq_engine *e, const char *name, uint64_t value) {
         e->opt.bucket_records = value;
     } else if (!strcmp(name, "pass4_piece")) {
         e->opt.pass4_piece = value;
+    } else if (!strcmp(name, "infer_subset")) {
+        e->opt.infer_subset = value != 0;      // (same results either way: an A/B switch between two runs)
     } else if (!strcmp(name, "no_overlap")) {
         // between two runs: every kernel in order on one stream (exclusive kernel durations for a profile) or back
         ENGINE_DEVICE(e);
@@ -1541,6 +1548,27 @@ int kbbq_set_thresholds(kbbq_engine *e, const int32_t *thresholds, int32_t n) {
 }  // extern "C"
 
 
+// k_infer<SUB>: how far from the read ends phase 1 may start skipping every fourth lookup (kernels.h), or -1 when the
+// thresholds leave no room for it.  A window of n starts whose k-mers are all present must still be decided without its
+// skipped lookups: skipped <= n - thr[n] - 1.  Inside the read a window of k starts holds at most ceil(k/4) skipped ones;
+// at the ends the windows are the prefixes [0, i] (and, mirrored, the suffixes), which hold the starts s % 4 == 3 from
+// `edge` on -- at the right end up to one more, the residues there depend on the read's length: counted as the worst case.
+// Only speed depends on this choice; every base still gets its exact decision (phase 2).
+static int infer_subset_edge(const std::vector<int> &thr, int k) {
+    if (k < 8 || (int)thr.size() < k + 1) return -1;
+    if ((k + 3) / 4 > k - thr[k] - 1) return -1;
+    for (int edge = 0; edge < k; ++edge) {
+        bool ok = true;
+        for (int n = edge + 1; n <= k && ok; ++n) {      // the window of the first (last) n starts
+            const int beyond = n - edge;                  // starts of it that may be skipped
+            const int skipped = (beyond + 3) / 4;         // worst case over the residues
+            ok = skipped <= n - thr[n] - 1;
+        }
+        if (ok) return edge;
+    }
+    return -1;
+}
+
 template <int NW> struct LaunchTrusted {
     static int go(kbbq_engine *e, ReadsDev R, uint32_t *take_bits, uint32_t *err_out, int max_len) {
         Thresholds thr;
@@ -1549,13 +1577,15 @@ template <int NW> struct LaunchTrusted {
         HIP_TRY(hipMemsetAsync(e->d_tickets, 0, 4, e->stream));      // the kernel's chunk counter (ReadChunks)
         {
             Timed t(e, "k_infer");
+            const int edge = e->opt.infer_subset ? infer_subset_edge(e->thresholds, e->p.k) : -1;
             // NK: chunks of 64 lanes that can hold a k-mer start (150-base reads, k = 32: 119 starts, two of the three chunks)
-            if (std::max(1, max_len - e->p.k + 1) <= (NW - 1) * 64)
-                hipLaunchKernelGGL((k_infer<NW, NW - 1>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
-                                   e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3, e->d_tickets);
-            else
-                hipLaunchKernelGGL((k_infer<NW, NW>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K,
-                                   e->filt[0].dev(), thr, take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3, e->d_tickets);
+            const bool short_nk = std::max(1, max_len - e->p.k + 1) <= (NW - 1) * 64;
+#define KBBQ_LAUNCH_INFER(NK_, SUB_)                                                                                              \
+    hipLaunchKernelGGL((k_infer<NW, NK_, 1, SUB_>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K, e->filt[0].dev(), thr, \
+                       take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3, e->d_tickets, edge)
+            if (edge >= 0) { if (short_nk) KBBQ_LAUNCH_INFER(NW - 1, true); else KBBQ_LAUNCH_INFER(NW, true); }
+            else { if (short_nk) KBBQ_LAUNCH_INFER(NW - 1, false); else KBBQ_LAUNCH_INFER(NW, false); }
+#undef KBBQ_LAUNCH_INFER
             HIP_TRY(hipGetLastError());
         }
         if (bucket_on(e, 1)) {
@@ -1794,7 +1824,7 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
     // per quality slot: totals and errors of 2 x ccap cycles as 16-bit counters + 2 x 16 dinucleotide words
     const size_t per_slot = (size_t)8 * ccap + 128;
     TallyPlan P;
-    plan_tally_slots(P, e->qpresent, (int)((152 * 1024 - 512) / per_slot));
+    plan_tally_slots(P, e->qpresent, (int)((152 * 1024 - 512) / per_slot), n_rg);
     const size_t per_rg = (size_t)P.n_slots * per_slot;
     // (half of the LDS if everything fits in it: two blocks per CU)
     const size_t budget = (size_t)n_rg * per_rg <= 70 * 1024 ? 70 * 1024 : 140 * 1024;
@@ -2175,8 +2205,20 @@ static int recalibrate_impl(kbbq_engine *e, const kbbq_reads *reads, uint8_t *qu
 namespace {
 struct AsyncCall {
     kbbq_engine *e;
-    explicit AsyncCall(kbbq_engine *e_) : e(e_) { e->async_call = true; }
+    explicit AsyncCall(kbbq_engine *e_) : e(e_) { e->async_call = true; e->last_ticket = 0; }
     ~AsyncCall() { e->async_call = false; }
+    // What the caller gets: the ticket of THIS call, or 0 when the call failed -- a failure before HostBatchDone's
+    // constructor would otherwise hand back the previous call's ticket.  A failed call may have queued copies out of
+    // or into the caller's memory (pass 4 in pieces: copies back without their event): they are drained here, so that
+    // after an error nothing of the engine touches the caller's batch any more.
+    uint64_t finish(int rc) {
+        if (rc == KBBQ_OK) return e->last_ticket;
+        (void)hipStreamSynchronize(e->copy);
+        (void)hipStreamSynchronize(e->stream);
+        (void)hipStreamSynchronize(e->stream2);
+        e->last_ticket = 0;
+        return 0;
+    }
 };
 }  // namespace
 
@@ -2184,7 +2226,7 @@ int kbbq_sample_batch_submit(kbbq_engine *e, const kbbq_reads *reads, uint64_t f
     if (!e || !ticket) return fail(KBBQ_EINVAL, "null argument");
     AsyncCall a(e);
     const int rc = kbbq_sample_batch(e, reads, first_kmer_ordinal);
-    *ticket = e->last_ticket;
+    *ticket = a.finish(rc);
     return rc;
 }
 
@@ -2192,7 +2234,7 @@ int kbbq_trusted_batch_submit(kbbq_engine *e, const kbbq_reads *reads, kbbq_tick
     if (!e || !ticket) return fail(KBBQ_EINVAL, "null argument");
     AsyncCall a(e);
     const int rc = kbbq_trusted_batch(e, reads, nullptr);
-    *ticket = e->last_ticket;
+    *ticket = a.finish(rc);
     return rc;
 }
 
@@ -2200,7 +2242,7 @@ int kbbq_errors_batch_submit(kbbq_engine *e, const kbbq_reads *reads, kbbq_ticke
     if (!e || !ticket) return fail(KBBQ_EINVAL, "null argument");
     AsyncCall a(e);
     const int rc = kbbq_errors_batch(e, reads, nullptr);
-    *ticket = e->last_ticket;
+    *ticket = a.finish(rc);
     return rc;
 }
 
@@ -2208,7 +2250,7 @@ int kbbq_recalibrate_batch_submit(kbbq_engine *e, const kbbq_reads *reads, uint8
     if (!e || !ticket) return fail(KBBQ_EINVAL, "null argument");
     AsyncCall a(e);
     const int rc = kbbq_recalibrate_batch(e, reads, qual_out);
-    *ticket = e->last_ticket;
+    *ticket = a.finish(rc);
     return rc;
 }
 

@@ -253,12 +253,24 @@ struct Thresholds { int v[KBBQ_MAX_KMER + 1]; };
 // quarters of the time: more resident waves keep more lookups in flight)
 // NK: 64-lane chunks that can hold k-mer starts (the batch's longest read has at most NK * 64 of them; NK <= NW): their
 // loads are unconditional, so that they sit in one basic block and all go out together.
-template <int NW, int NK, int MINW = 1>
+//
+// SUB (round 4): decide from a SUBSET of the lookups first.  err[i] only asks whether in[i] exceeds thr[possible[i]], and
+// the k-mers known to be present -- hint bits plus the lookups made so far -- bound in[i] from below, the skipped ones
+// from above: a base with lower bound > thr is clean, one with lower + skipped <= thr is flagged, whatever the skipped
+// lookups would say.  Phase 1 skips every fourth k-mer start (s % 4 == 3) at least `edge` starts away from both read
+// ends (near the ends thr[possible] leaves no room: the host derives `edge` from the thresholds, infer_subset_edge);
+// phase 2 makes the skipped lookups whose k bases hold an undecided base -- around real errors, where in[i] crosses
+// the threshold -- and only if the read has any.  Every base ends up with the exact decision: for a decided base the
+// final count moves inside the bounds that decided it, for an undecided one every start in its window has been looked
+// up.  take_bits, err_out, qpresent and the insert count are bit-identical to the plain form (tests/test_parity_gpu.py
+// runs both); `lookups` counts the lines really fetched.
+template <int NW, int NK, int MINW = 1, bool SUB = false>
 __global__ void __launch_bounds__(256, MINW) k_infer(ReadsDev R, KParams K, FiltDev S, Thresholds thr, uint32_t *take_bits,
                                                 unsigned long long *inserted, uint32_t *err_out, uint32_t *qpresent,
-                                                unsigned long long *lookups, unsigned int *ticket) {
+                                                unsigned long long *lookups, unsigned int *ticket, int edge) {
     using St = Stage<NW>;
     __shared__ uint32_t lds[4][St::LDS_U32];
+    __shared__ uint32_t lds_sub[SUB ? 4 : 1][SUB ? 2 * St::RES : 1];      // skipped starts, undecided bases (same shape as PW)
     __shared__ int thr_lds[KBBQ_MAX_KMER + 1];
     __shared__ uint32_t qseen[8];                  // quality values this block has met (256 bits), flushed once at the end
     const int lane = threadIdx.x & 63;
@@ -272,6 +284,9 @@ __global__ void __launch_bounds__(256, MINW) k_infer(ReadsDev R, KParams K, Filt
     const int k = K.k;
     unsigned long long mine = 0, looked = 0;
     if (lane < St::RES) { PW[lane] = 0; EW[lane] = 0; }
+    uint32_t *SW = lds_sub[SUB ? (threadIdx.x >> 6) : 0];      // SUB: the starts phase 1 skipped
+    uint32_t *UW = SW + (SUB ? St::RES : 0);                    //      the bases phase 1 left undecided
+    if (SUB && lane < St::RES) { SW[lane] = 0; UW[lane] = 0; }
     uint64_t off = 0, word = 0;
     uint32_t len = 0;
     ReadChunks<32> Q;      // reads in chunks of 32 from a global counter: no idle last round (device_common.h)
@@ -292,24 +307,36 @@ __global__ void __launch_bounds__(256, MINW) k_infer(ReadsDev R, KParams K, Filt
             read_span(R, r_next, off, len);
             word = stage_fetch<NW>(R, hint, nullptr, 0, 0, off, lane);
         }
-        if (nk <= 0) continue;           // engine-defined: the reference underflows size_t here
+        if (nk <= 0) {
+            // engine-defined: the reference underflows size_t here.  The read is still tallied and recalibrated, so its
+            // quality values belong to the set pass 3 sizes its tables by
+            for (int i = lane; i < Lr; i += 64) qseen_note(qseen, R.qual[cur + i]);
+            continue;
+        }
         // Step A (ALU and LDS only): which block and pattern every lane wants.  A lane with nothing to look up -- past the
         // last k-mer, a k-mer with a non-ACGT base, one this read put into the sampled filter itself in pass 1 (hint
         // bit) -- points at block 0 / pattern 0: one shared, cache-resident line per instruction, no branch around the load.
-        bool valid[NK], known[NK];
+        bool valid[NK], known[NK], skip[NK];
         uint32_t blk[NK], pat[NK];
+        uint32_t blk2[SUB ? NK : 1], pat2[SUB ? NK : 1];      // SUB: where the skipped starts would look (phase 2)
 #pragma unroll
         for (int c = 0; c < NK; ++c) {
             valid[c] = false;
             known[c] = false;
+            skip[c] = false;
             blk[c] = 0;
             pat[c] = 0;
+            if (SUB) { blk2[c] = 0; pat2[c] = 0; }
             const int s = c * 64 + lane;
             if (s < nk) {
                 valid[c] = (lds_window32(L32 + 2 * St::M, o63 + s) & K.nmask_bits) == 0;
                 known[c] = hint && lds_bit(L32 + 2 * St::H, o63 + s);
                 const uint64_t key = canon_key(lds_window64(L32 + 2 * St::B, 2 * (o31 + s)), K);
-                if (valid[c] && !known[c]) { blk[c] = block_of(S, key); pat[c] = pattern_of(S, key); }
+                if (valid[c] && !known[c]) {
+                    const uint32_t b = block_of(S, key), pt = pattern_of(S, key);
+                    skip[c] = SUB && (s & 3) == 3 && s >= edge && s < nk - edge;
+                    if (skip[c]) { blk2[c] = b; pat2[c] = pt; } else { blk[c] = b; pat[c] = pt; }
+                }
             }
         }
         // Step B: every load of the read goes out back to back -- quality bytes (streamed), blocks (one random HBM line
@@ -328,25 +355,79 @@ __global__ void __launch_bounds__(256, MINW) k_infer(ReadsDev R, KParams K, Filt
 #pragma unroll
         for (int c = 0; c < NK; ++c) p[c] = S.patterns[pat[c]];
         __builtin_amdgcn_sched_barrier(0);
-        uint64_t V[NK];
+        uint64_t V[NK], P[NK];
+        uint64_t any_skip = 0;
 #pragma unroll
         for (int c = 0; c < NK; ++c) {
-            const bool need = valid[c] && !known[c];
+            const bool need = valid[c] && !known[c] && !skip[c];
             const bool present = known[c] || (need && ((p[c].x & ~t[c].x) | (p[c].y & ~t[c].y)) == 0);
-            const uint64_t P = __ballot(present);
+            P[c] = __ballot(present);
             V[c] = __ballot(valid[c]);
             looked += __popcll(__ballot(need));      // blocks actually wanted (reported, not used)
-            if (lane < 2) PW[1 + 2 * c + lane] = (uint32_t)(P >> (32 * lane));
+            if (lane < 2) PW[1 + 2 * c + lane] = (uint32_t)(P[c] >> (32 * lane));
+            if (SUB) {
+                const uint64_t SKb = __ballot(skip[c]);
+                any_skip |= SKb;
+                if (lane < 2) SW[1 + 2 * c + lane] = (uint32_t)(SKb >> (32 * lane));
+            }
         }
 #pragma unroll
         for (int c = NK; c < NW; ++c)
-            if (lane < 2) PW[1 + 2 * c + lane] = 0;
+            if (lane < 2) { PW[1 + 2 * c + lane] = 0; if (SUB) SW[1 + 2 * c + lane] = 0; }
         // which quality values occur at all (the tally of pass 3 sizes its LDS tables by them): a look at the block's
         // 256-bit set in LDS, an LDS atomic the first time
 #pragma unroll
         for (int c = 0; c < NW; ++c)
             if (c * 64 < Lr && c * 64 + lane < Lr) qseen_note(qseen, q[c]);
         __builtin_amdgcn_wave_barrier();
+        if (SUB && any_skip) {
+            // Phase 1's verdict per base: lower bound (PW) and skipped starts (SW) of its window against the threshold
+            uint64_t any_und = 0;
+#pragma unroll
+            for (int c = 0; c < NW; ++c) {
+                if (c * 64 < Lr) {
+                    const int i = c * 64 + lane;
+                    bool und = false;
+                    if (i < Lr && q[c] > 2) {
+                        const int possible = min(i, nk - 1) - max(0, i - k + 1) + 1;
+                        const int lb = __popc(lds_window32(PW, i - k + 1 + 32) & K.nmask_bits);
+                        const int nsk = __popc(lds_window32(SW, i - k + 1 + 32) & K.nmask_bits);
+                        const int th = thr_lds[possible];
+                        und = lb <= th && lb + nsk > th;
+                    }
+                    const uint64_t U = __ballot(und);
+                    any_und |= U;
+                    if (lane < 2) UW[1 + 2 * c + lane] = (uint32_t)(U >> (32 * lane));
+                } else if (lane < 2) {
+                    UW[1 + 2 * c + lane] = 0;
+                }
+            }
+            if (any_und) {
+                // Phase 2: the skipped starts whose k bases hold an undecided base (a second round of line fetches, only
+                // around the places where in[i] crosses its threshold)
+                __builtin_amdgcn_wave_barrier();
+                bool need2[NK];
+#pragma unroll
+                for (int c = 0; c < NK; ++c) {
+                    const int s = c * 64 + lane;
+                    need2[c] = skip[c] && (lds_window32(UW, s + 32) & K.nmask_bits) != 0;
+                    if (!need2[c]) { blk2[c] = 0; pat2[c] = 0; }
+                }
+#pragma unroll
+                for (int c = 0; c < NK; ++c) t[c] = S.table[blk2[c]];
+#pragma unroll
+                for (int c = 0; c < NK; ++c) p[c] = S.patterns[pat2[c]];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < NK; ++c) {
+                    const bool present2 = need2[c] && ((p[c].x & ~t[c].x) | (p[c].y & ~t[c].y)) == 0;
+                    P[c] |= __ballot(present2);
+                    looked += __popcll(__ballot(need2[c]));
+                    if (lane < 2) PW[1 + 2 * c + lane] = (uint32_t)(P[c] >> (32 * lane));
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
         // in[i] = present k-mers among the starts max(0,i-k+1)..min(i,nk-1): the k bits of the present
         // stream that end at bit i (bits before 0 and from nk on are zero)
 #pragma unroll

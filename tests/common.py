@@ -227,12 +227,12 @@ def run_oracle(d, k=32, seed=777, alpha=None, n_rg=1):
     return out
 
 
-def run_engine(d, k=32, seed=777, alpha=None, n_rg=1, uniform=False, n_batches=1, max_read_len=None):
+def run_engine(d, k=32, seed=777, alpha=None, n_rg=1, uniform=False, n_batches=1, max_read_len=None, tune=None):
     alpha_ld, cov, approx = plan_parameters(d["genome_len"], d["coverage"], alpha)
     lens = np.diff(d["off"].astype(np.int64))
     if max_read_len is None:
         max_read_len = int(lens.max())
-    e = Engine(k, alpha_ld, seed, approx, n_rg=n_rg, max_read_len=max_read_len)
+    e = Engine(k, alpha_ld, seed, approx, n_rg=n_rg, max_read_len=max_read_len, tune=tune)
     full = ReadBatch(d["seq"], d["qual"], d["off"], d["rg"], d["second"], uniform=uniform)
     n = full.n_reads
     cuts = [n * i // n_batches for i in range(n_batches + 1)]

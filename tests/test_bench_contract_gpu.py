@@ -42,6 +42,9 @@ def test_bench_prints_one_contract_line():
     assert p["host_link"]["h2d_GBps"] > 1 and p["host_link"]["d2h_GBps"] > 1
     for mode in ("resubmit", "upload_once"):
         assert 0 < p[mode]["value"] <= p[mode]["bound_Gbases_per_s"] * 1.05 and len(p[mode]["pass_seconds"]) == 4
+        # a bound that is beaten is not a bound: the duplex form prices a one-directional pass at that direction's own rate
+        assert p[mode]["fraction_of_duplex_bound"] <= 1.02, (mode, p[mode])
+    assert d["ingest_inclusive_value"] == p["upload_once"]["value"] and d["ingest_inclusive_unit"] == "Gbases/s"
     assert r["useful_bytes"] is None or r["useful_bytes"] < r["algorithmic_bytes_per_launch"]
 
 
