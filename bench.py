@@ -497,6 +497,10 @@ def main():
                     help="diagnostic (N = 1): a one-rank RCCL group and every exchange step at full size -- all_to_all, OR "
                          "kernel and all_gather over the whole 6.3 + 10.4 GB of filters in 512 MB slabs, histogram sum, delta-Q "
                          "broadcast -- beside the record buffers of the bucketed inserts; adds an `exchange_one_rank` object")
+    ap.add_argument("--ab-tune", default=None, metavar="KNOB[,ROUNDS]",
+                    help="diagnostic (N = 1): A/B of one kbbq_engine_tune switch inside ONE process on the same resident reads -- "
+                         "KNOB=0 / KNOB=1 alternated ROUNDS times (default 4), each an overlapped step (wall time) and an in-order "
+                         "step (exclusive kernel durations); prints one JSON object and exits")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -597,6 +601,36 @@ def main():
         _l.check(e.L.kbbq_engine_tune(e.h, b"no_overlap", 0))
         return p
 
+    if args.ab_tune:
+        # the card's clock moves a kernel by +-7 % between boxes and within minutes: both settings alternate in one job
+        knob, _, rounds = args.ab_tune.partition(",")
+        rounds = int(rounds or 4)
+        from kbbq_amd import _lib as _l
+        rows = []
+        for i in range(rounds):
+            for v in (0, 1):
+                _l.check(e.L.kbbq_engine_tune(e.h, knob.encode(), v))
+                barrier()
+                t0 = time.perf_counter()
+                info = run_step(e, xch, batches, ordinals, out_buf, hints)
+                barrier()
+                wall = (time.perf_counter() - t0) * 1e3
+                p = exclusive_step()
+                st = e.stats()
+                rows.append(dict(round=i, value=v, step_ms=round(wall, 1), lookups=st["infer_lookups"],
+                                 trusted_inserted=info["trusted_inserted"],
+                                 exclusive_avg_ms={k: round(ms / n, 4) for k, (n, ms) in p.items() if n}))
+                log("[ab] %s=%d round %d: step %.0f ms, k_infer %.3f ms, lookups %d" % (knob, v, i, wall, rows[-1]["exclusive_avg_ms"].get("k_infer", 0), st["infer_lookups"]))
+        _l.check(e.L.kbbq_engine_tune(e.h, knob.encode(), 0))
+        digest = 0
+        for bt in batches:
+            e.recalibrate(bt, out_buf.data_ptr())
+            e.sync()
+            digest += int(out_buf[:bt.n_bases].to(torch.int64).sum().item())
+        print(json.dumps(dict(ab_tune=knob, genome_len=G, coverage=cov, recal_qual_sum=digest, rows=rows)), flush=True)
+        shard.free()
+        e.close()
+        return
     # (the card slows down under sustained load -- the same kernel measures 9.0 ms on a cold card and 9.8-10.3 ms a
     # minute later -- so the exclusive step is taken on both sides of the timed region: the roofline quotes the one behind)
     want_excl = not os.environ.get("KBBQ_NO_OVERLAP") and not args.no_exclusive_step

@@ -126,6 +126,47 @@ int kbbq_fastq_reader_write(kbbq_fastq_reader *r, kbbq_bgzf *z, const uint8_t *d
 /* Milliseconds the device spent inflating / indexing + packing since creation. */
 int kbbq_fastq_reader_kernel_ms(kbbq_fastq_reader *r, double *inflate_ms, double *index_ms);
 
+/* ---- the input side: a BAM file read on the device (round 4) ----------------------------------------------------------
+ * What it replaces: sam_read1 (BamFile::next, htsiter.cc:5), the BAM constructor of CReadData (readutils.cc:13-61, with
+ * bam_seq_str, readutils.hh:30-42) and -- pass 4 -- BamFile::recalibrate + sam_write1 (htsiter.cc:11-45), once per chunk of
+ * the file instead of once per record and pass.  The caller parses the BAM header itself (it needs the reference lengths,
+ * kbbq.cc:196-216) and feeds the file's bytes in chunks, as for kbbq_fastq_reader; the device inflates every BGZF block,
+ * finds the alignment records (a length-prefixed chain: segments of the stream are walked in parallel from guessed starts
+ * and accepted only where each segment starts exactly where the one before it lands, csrc/bam_device.h), decodes them --
+ * 4-bit bases to the engine's 2-bit layout + N mask, reverse-strand records reverse-complemented with their qualities
+ * reversed, qualities from OQ:Z with use_oq, second-in-pair from FLAG 0x80, RG:Z looked up in the header's @RG ids -- and
+ * pass 4 rewrites them in place around the new qualities (with set_oq the old ones become OQ:Z, replaced or appended as
+ * bam_aux_update_str does) for a kbbq_bgzf to deflate.  Shapes this path does not take are reported in flags and left to
+ * the caller's host parser (bam_io.cc), which stays the definition:
+ *   bit 0  not BGZF; a malformed alignment block; a record without a usable RG:Z tag, or one the header has no @RG line
+ *          for; with use_oq a missing / corrupt OQ tag or one whose length is not l_seq; more than 4096 misjudged segments
+ *   bit 2  the stream ended inside a record
+ *   bit 3  some record's OQ tag could not be updated by bam_aux_update_str (other type, or malformed tags in front of the
+ *          place it would be appended): the caller must not use kbbq_bam_reader_write with set_oq on this file
+ * Read groups get dense indices in the order of their first record, as rg_to_int does (readutils.cc:53-57). */
+typedef struct kbbq_bam_reader kbbq_bam_reader;
+typedef struct kbbq_fastq_chunk kbbq_bam_chunk;      /* same fields; text_bytes = inflated bytes, flags as above */
+/* header_bytes: size of the BAM header in the inflated stream (magic, l_text, text, n_ref, references);
+ * n_ref: number of references (refID must be in [-1, n_ref)); rg_ids: the ID fields of the header's @RG lines. */
+int kbbq_bam_reader_create(int32_t device, int32_t use_oq, int32_t n_ref, uint64_t header_bytes, const char *const *rg_ids, uint32_t n_rg_ids,
+                           kbbq_bam_reader **out);
+void kbbq_bam_reader_destroy(kbbq_bam_reader *r);
+int kbbq_bam_reader_rewind(kbbq_bam_reader *r);
+/* Keep the COMPRESSED bytes of every chunk with records in device memory (about a third of the stream's size), so that
+ * pass 4 inflates and indexes them again there (kbbq_bam_reader_select) instead of reading the file a second time. */
+int kbbq_bam_reader_keep(kbbq_bam_reader *r, int32_t on);
+int kbbq_bam_reader_kept(kbbq_bam_reader *r, uint64_t *n_chunks, uint64_t *n_bytes);
+int kbbq_bam_reader_select(kbbq_bam_reader *r, uint64_t i, kbbq_bam_chunk *info);
+int kbbq_bam_reader_chunk(kbbq_bam_reader *r, const uint8_t *file_bytes, uint64_t n_bytes, int32_t last, kbbq_bam_chunk *info);
+/* The read groups met so far in dense-index order: table_index[d] = index into rg_ids of the group with dense index d. */
+int kbbq_bam_reader_read_groups(kbbq_bam_reader *r, uint32_t *table_index, uint32_t capacity, uint32_t *n);
+/* The current chunk's records as a device batch (arrays owned by the library: kbbq_reads_free), rg = dense indices. */
+int kbbq_bam_reader_batch(kbbq_bam_reader *r, kbbq_reads *dev);
+/* Pass 4: the current chunk's records with d_qual (device: the batch's new qualities in the batch's base order) in their
+ * quality fields, submitted to writer z (kbbq_bgzf_collect returns the blocks).  after_stream as in kbbq_bgzf_submit. */
+int kbbq_bam_reader_write(kbbq_bam_reader *r, kbbq_bgzf *z, const uint8_t *d_qual, int32_t set_oq, void *after_stream);
+int kbbq_bam_reader_kernel_ms(kbbq_bam_reader *r, double *inflate_ms, double *index_ms);
+
 /* ---- host-only twin (no GPU touched): the same scalar pieces (Huffman lengths, header, token bits, CRC chaining,
  * framing) around a serial match finder; lets the CPU test-suite inflate what those pieces produce. */
 int kbbq_host_bgzf_compress(const uint8_t *payload, uint64_t n, uint8_t *out, uint64_t out_capacity, uint64_t *out_bytes);

@@ -167,6 +167,18 @@ SYMBOLS = {
                                                  ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "kbbq_fastq_reader_attach": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads)]),
     "kbbq_fastq_reader_kernel_ms": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "kbbq_bam_reader_create": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_char_p),
+                                              ctypes.c_uint32, ctypes.POINTER(c_vp)]),
+    "kbbq_bam_reader_destroy": (None, [c_vp]),
+    "kbbq_bam_reader_rewind": (ctypes.c_int, [c_vp]),
+    "kbbq_bam_reader_keep": (ctypes.c_int, [c_vp, ctypes.c_int32]),
+    "kbbq_bam_reader_kept": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    "kbbq_bam_reader_select": (ctypes.c_int, [c_vp, ctypes.c_uint64, ctypes.c_void_p]),
+    "kbbq_bam_reader_chunk": (ctypes.c_int, [c_vp, c_vp, c_u64, ctypes.c_int32, ctypes.POINTER(FastqChunk)]),
+    "kbbq_bam_reader_read_groups": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]),
+    "kbbq_bam_reader_batch": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads)]),
+    "kbbq_bam_reader_write": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int32, c_vp]),
+    "kbbq_bam_reader_kernel_ms": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }
 
 _LIB = None

@@ -120,3 +120,66 @@ class FastqReader:
 
     def attach(self, batch):
         _lib.check(self.L.kbbq_fastq_reader_attach(self.h, ctypes.byref(batch)))
+
+
+class BamReader:
+    """A BAM file read on the device (include/kbbq_bgzf.h: kbbq_bam_reader): inflate, record chain, field decode, and --
+    pass 4 -- the records rewritten around the new qualities.  header_bytes / n_ref / rg_ids come from the caller's own
+    parse of the BAM header."""
+
+    def __init__(self, header_bytes, n_ref, rg_ids, use_oq=False, device=0):
+        self.L = _lib.lib()
+        self.h = _lib.c_vp()
+        ids = (ctypes.c_char_p * max(1, len(rg_ids)))(*[i.encode() if isinstance(i, str) else i for i in rg_ids])
+        _lib.check(self.L.kbbq_bam_reader_create(device, 1 if use_oq else 0, n_ref, header_bytes, ids, len(rg_ids), ctypes.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.kbbq_bam_reader_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def rewind(self):
+        _lib.check(self.L.kbbq_bam_reader_rewind(self.h))
+
+    def keep(self, on=True):
+        _lib.check(self.L.kbbq_bam_reader_keep(self.h, 1 if on else 0))
+
+    def kept(self):
+        n, b = ctypes.c_uint64(), ctypes.c_uint64()
+        _lib.check(self.L.kbbq_bam_reader_kept(self.h, ctypes.byref(n), ctypes.byref(b)))
+        return n.value, b.value
+
+    def chunk(self, data, last):
+        a = np.frombuffer(data, dtype=np.uint8)
+        info = _lib.FastqChunk()
+        _lib.check(self.L.kbbq_bam_reader_chunk(self.h, a.ctypes.data if a.size else None, a.size, 1 if last else 0, ctypes.byref(info)))
+        return {k: getattr(info, k) for k, _ in _lib.FastqChunk._fields_}
+
+    def select(self, i):
+        info = _lib.FastqChunk()
+        _lib.check(self.L.kbbq_bam_reader_select(self.h, i, ctypes.byref(info)))
+        return {k: getattr(info, k) for k, _ in _lib.FastqChunk._fields_}
+
+    def read_groups(self):
+        """Table indices (into rg_ids) of the read groups met so far, in dense-index order."""
+        n = ctypes.c_uint32()
+        _lib.check(self.L.kbbq_bam_reader_read_groups(self.h, None, 0, ctypes.byref(n)))
+        out = (ctypes.c_uint32 * max(1, n.value))()
+        _lib.check(self.L.kbbq_bam_reader_read_groups(self.h, out, n.value, ctypes.byref(n)))
+        return list(out[:n.value])
+
+    def batch(self):
+        d = _lib.Reads()
+        _lib.check(self.L.kbbq_bam_reader_batch(self.h, ctypes.byref(d)))
+        return d
+
+    def write(self, writer, d_qual, set_oq=False, after_stream=None):
+        _lib.check(self.L.kbbq_bam_reader_write(self.h, writer.h, d_qual, 1 if set_oq else 0, after_stream))
+
+    def kernel_ms(self):
+        a, b = ctypes.c_double(), ctypes.c_double()
+        _lib.check(self.L.kbbq_bam_reader_kernel_ms(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return dict(inflate=a.value, index=b.value)

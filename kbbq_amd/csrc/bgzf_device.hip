@@ -12,6 +12,7 @@
 #include "abi_internal.h"
 #include "bgzf_device.h"
 #include "bgzf_inflate.h"
+#include "bam_device.h"
 
 using namespace kbbq::dfl;
 
@@ -366,16 +367,20 @@ struct kbbq_fastq_reader {
 
 namespace {
 
-int device_scan(kbbq_fastq_reader *r, uint64_t *d, uint64_t n, uint64_t *d_total /* device */) {
+// exclusive scan of d[0, n) in place, the total to *d_total (device); tile_sums: the caller's scratch
+int device_scan_on(Buf &tile_sums, hipStream_t st, uint64_t *d, uint64_t n, uint64_t *d_total /* device */) {
     const uint64_t n_tiles = (n + DSCAN_TILE - 1) / DSCAN_TILE;
-    int rc = r->tile_sums.reserve((n_tiles + 1) * 8);
+    int rc = tile_sums.reserve((n_tiles + 1) * 8);
     if (rc) return rc;
-    uint64_t *ts = (uint64_t *)r->tile_sums.p;
-    hipLaunchKernelGGL(k_dscan_tiles, dim3((unsigned)n_tiles), dim3(256), 0, r->st, d, n, ts);
-    hipLaunchKernelGGL(k_dscan_sums, dim3(1), dim3(1024), 0, r->st, ts, n_tiles, d_total);
-    hipLaunchKernelGGL(k_dscan_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, r->st, d, n, (const uint64_t *)ts);
+    uint64_t *ts = (uint64_t *)tile_sums.p;
+    hipLaunchKernelGGL(k_dscan_tiles, dim3((unsigned)n_tiles), dim3(256), 0, st, d, n, ts);
+    hipLaunchKernelGGL(k_dscan_sums, dim3(1), dim3(1024), 0, st, ts, n_tiles, d_total);
+    hipLaunchKernelGGL(k_dscan_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, n, (const uint64_t *)ts);
     HIP_TRY(hipGetLastError());
     return KBBQ_OK;
+}
+int device_scan(kbbq_fastq_reader *r, uint64_t *d, uint64_t n, uint64_t *d_total /* device */) {
+    return device_scan_on(r->tile_sums, r->st, d, n, d_total);
 }
 
 FastqIndex index_from(void *idx_u32, void *second, void *base_sz, void *text_sz, void *flags, uint64_t cap) {
@@ -1004,3 +1009,6 @@ int kbbq_fastq_reader_kernel_ms(kbbq_fastq_reader *r, double *inflate_ms, double
 }
 
 }  // extern "C"
+
+// ============================================================ the input side: BAM read on the device
+#include "bam_reader.h"

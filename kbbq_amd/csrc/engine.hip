@@ -86,7 +86,7 @@ struct Options {
     bool no_pass4_pipeline = false;   // KBBQ_F_NO_PASS4_PIPELINE / KBBQ_NO_PASS4_PIPELINE: pass 4 of a host batch in one piece
     bool pass2_side = true;           // KBBQ_F_PASS2_INORDER / KBBQ_PASS2_SIDE=0 clear it: the insert side of pass 2 beside k_infer
     bool tally_general = false;       // KBBQ_TALLY_GENERAL: the general tally kernel for every batch shape (A/B)
-    bool infer_subset = false;        // KBBQ_INFER_SUBSET=1 / kbbq_engine_tune("infer_subset"): k_infer decides from three of four lookups first
+    bool infer_subset = true;         // KBBQ_INFER_SUBSET=0 / kbbq_engine_tune("infer_subset", 0): k_infer makes every lookup at once (round 3's form)
     bool debug_bucket = false;        // KBBQ_DEBUG_BUCKET: one stderr line per flush of the bucketed inserts
     int bucket = -1;                  // KBBQ_F_BUCKET_ON / _OFF, KBBQ_BUCKET=1/0: bucketed / direct inserts; -1: by filter size
     uint64_t bucket_records = 0;      // KBBQ_BUCKET_RECORDS: records gathered per flush (0: a share of the free HBM)
@@ -762,7 +762,7 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
         o.no_pass4_pipeline = (fl & KBBQ_F_NO_PASS4_PIPELINE) || env_set("KBBQ_NO_PASS4_PIPELINE");      // (no_overlap implies it, where it is used)
         o.pass2_side = !(fl & KBBQ_F_PASS2_INORDER) && env_int("KBBQ_PASS2_SIDE", 1) != 0;                // (no_overlap switches it off, where it is used)
         o.tally_general = env_set("KBBQ_TALLY_GENERAL");
-        o.infer_subset = env_set("KBBQ_INFER_SUBSET");
+        o.infer_subset = env_int("KBBQ_INFER_SUBSET", 1) != 0;
         o.debug_bucket = env_set("KBBQ_DEBUG_BUCKET");
         o.bucket = (fl & KBBQ_F_BUCKET_ON) ? 1 : (fl & KBBQ_F_BUCKET_OFF) ? 0 : env_set("KBBQ_BUCKET") ? (env_int("KBBQ_BUCKET", 0) != 0 ? 1 : 0) : -1;
         o.bucket_records = env_u64("KBBQ_BUCKET_RECORDS", 0);
@@ -1548,25 +1548,24 @@ int kbbq_set_thresholds(kbbq_engine *e, const int32_t *thresholds, int32_t n) {
 }  // extern "C"
 
 
-// k_infer<SUB>: how far from the read ends phase 1 may start skipping every fourth lookup (kernels.h), or -1 when the
-// thresholds leave no room for it.  A window of n starts whose k-mers are all present must still be decided without its
-// skipped lookups: skipped <= n - thr[n] - 1.  Inside the read a window of k starts holds at most ceil(k/4) skipped ones;
-// at the ends the windows are the prefixes [0, i] (and, mirrored, the suffixes), which hold the starts s % 4 == 3 from
-// `edge` on -- at the right end up to one more, the residues there depend on the read's length: counted as the worst case.
-// Only speed depends on this choice; every base still gets its exact decision (phase 2).
-static int infer_subset_edge(const std::vector<int> &thr, int k) {
-    if (k < 8 || (int)thr.size() < k + 1) return -1;
-    if ((k + 3) / 4 > k - thr[k] - 1) return -1;
-    for (int edge = 0; edge < k; ++edge) {
-        bool ok = true;
-        for (int n = edge + 1; n <= k && ok; ++n) {      // the window of the first (last) n starts
-            const int beyond = n - edge;                  // starts of it that may be skipped
-            const int skipped = (beyond + 3) / 4;         // worst case over the residues
-            ok = skipped <= n - thr[n] - 1;
+// k_infer<SUB>: every how many k-mer starts phase 1 may skip a lookup (4, 8 or 16) and how far from the read ends it
+// starts doing so (kernels.h); false when the thresholds leave no room for it.  A window of n starts whose k-mers are all
+// present must still be decided without its skipped lookups: skipped <= n - thr[n] - 1.  Inside the read a window of k
+// starts holds at most ceil(k / period) skipped ones; at the ends the windows are the prefixes [0, i] (and, mirrored, the
+// suffixes), which hold the skipped starts from `edge` on -- counted as the worst case over the residues.  Only speed
+// depends on this choice; every base still gets its exact decision (phase 2).
+static bool infer_subset_plan(const std::vector<int> &thr, int k, int *edge_out, int *pmask_out) {
+    if (k < 8 || (int)thr.size() < k + 1) return false;
+    for (int period = 4; period <= 16; period *= 2) {
+        if ((k + period - 1) / period > k - thr[k] - 1) continue;
+        for (int edge = 0; edge < k; ++edge) {
+            bool ok = true;
+            for (int n = edge + 1; n <= k && ok; ++n)      // the window of the first (last) n starts
+                ok = (n - edge + period - 1) / period <= n - thr[n] - 1;
+            if (ok) { *edge_out = edge; *pmask_out = period - 1; return true; }
         }
-        if (ok) return edge;
     }
-    return -1;
+    return false;
 }
 
 template <int NW> struct LaunchTrusted {
@@ -1577,12 +1576,15 @@ template <int NW> struct LaunchTrusted {
         HIP_TRY(hipMemsetAsync(e->d_tickets, 0, 4, e->stream));      // the kernel's chunk counter (ReadChunks)
         {
             Timed t(e, "k_infer");
-            const int edge = e->opt.infer_subset ? infer_subset_edge(e->thresholds, e->p.k) : -1;
+            int edge = -1, pmask = 3;
+            if (e->opt.infer_subset && !infer_subset_plan(e->thresholds, e->p.k, &edge, &pmask)) edge = -1;
+            if (edge >= 0 && getenv("KBBQ_SUBSET_EDGE")) edge = atoi(getenv("KBBQ_SUBSET_EDGE"));        // (diagnostic overrides: results
+            if (edge >= 0 && getenv("KBBQ_SUBSET_PMASK")) pmask = atoi(getenv("KBBQ_SUBSET_PMASK"));     //  never depend on either)
             // NK: chunks of 64 lanes that can hold a k-mer start (150-base reads, k = 32: 119 starts, two of the three chunks)
             const bool short_nk = std::max(1, max_len - e->p.k + 1) <= (NW - 1) * 64;
 #define KBBQ_LAUNCH_INFER(NK_, SUB_)                                                                                              \
     hipLaunchKernelGGL((k_infer<NW, NK_, 1, SUB_>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K, e->filt[0].dev(), thr, \
-                       take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3, e->d_tickets, edge)
+                       take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3, e->d_tickets, edge, pmask)
             if (edge >= 0) { if (short_nk) KBBQ_LAUNCH_INFER(NW - 1, true); else KBBQ_LAUNCH_INFER(NW, true); }
             else { if (short_nk) KBBQ_LAUNCH_INFER(NW - 1, false); else KBBQ_LAUNCH_INFER(NW, false); }
 #undef KBBQ_LAUNCH_INFER

@@ -255,6 +255,15 @@ public:
         ++in_flight_;
         return true;
     }
+    // The current chunk of a device BAM reader with new qualities (kbbq_bam_reader_write): BamFile::recalibrate + write of
+    // every record on the device.
+    bool bam_chunk(kbbq_bam_reader *reader, const uint8_t *d_qual, bool set_oq, void *after_stream) {
+        if (!flush_host()) return false;
+        if (!make_room()) return false;
+        if (kbbq_bam_reader_write(reader, z_, d_qual, set_oq ? 1 : 0, after_stream) < 0) return fail_here();
+        ++in_flight_;
+        return true;
+    }
     // every submission so far has been written out (a caller may then reuse device memory the submissions read)
     bool drain() {
         while (in_flight_ > 0) if (!collect_one()) return false;
@@ -483,9 +492,28 @@ public:
     uint64_t kept_bytes = 0;
     std::vector<uint64_t> chunk_records;      // records of every chunk of the first scan (pass 4 must meet the same)
     kbbq_fastq_reader *reader = nullptr;
+    // BAM mode (open_bam): the same file feeding, the chunks go to a kbbq_bam_reader -- inflate, record chain, field decode and,
+    // in pass 4, the records rewritten around the new qualities are kernels (sam_read1, the BAM
+    // constructor of CReadData and BamFile::recalibrate / write, htsiter.cc:5-45, readutils.cc:13-61)
+    kbbq_bam_reader *bam = nullptr;
+    bool oq_unwritable = false;               // some record's OQ tag bam_aux_update_str could not update (--set-oq: host path)
     double wait_s = 0, device_s = 0, batch_s = 0;
 
+    bool open_bam(const std::string &path, bool use_oq, int32_t n_ref, uint64_t header_bytes, const std::vector<std::string> &rg_ids) {
+        if (!open_file(path)) return false;
+        std::vector<const char *> ids;
+        for (auto &id : rg_ids) ids.push_back(id.c_str());
+        if (kbbq_bam_reader_create(0, use_oq ? 1 : 0, n_ref, header_bytes, ids.data(), (uint32_t)ids.size(), &bam) < 0) return false;
+        start_pass();
+        return true;
+    }
     bool open(const std::string &path) {
+        if (!open_file(path)) return false;
+        if (kbbq_fastq_reader_create(0, &reader) < 0) return false;
+        start_pass();
+        return true;
+    }
+    bool open_file(const std::string &path) {
         fd_ = ::open(path.c_str(), O_RDONLY);
         if (fd_ < 0) return false;
         struct stat st;
@@ -498,14 +526,14 @@ public:
             if (kbbq_host_alloc(kFront + kPiece, &p) < 0) return false;
             buf_[i] = (uint8_t *)p;
         }
-        if (kbbq_fastq_reader_create(0, &reader) < 0) return false;
-        start_pass();
         return true;
     }
     void close() {
         stop_io();
         if (reader) kbbq_fastq_reader_destroy(reader);
         reader = nullptr;
+        if (bam) kbbq_bam_reader_destroy(bam);
+        bam = nullptr;
         for (int i = 0; i < 2; ++i) { if (buf_[i]) kbbq_host_free(buf_[i]); buf_[i] = nullptr; }
         if (fd_ >= 0) ::close(fd_);
         fd_ = -1;
@@ -568,8 +596,9 @@ public:
         uint8_t *data = buf_[b] + kFront - left_;
         if (left_) memcpy(data, carry_, left_);
         const auto t1 = std::chrono::steady_clock::now();
-        if (kbbq_fastq_reader_chunk(reader, data, left_ + n, last, &info) < 0) return -1;
+        if ((bam ? kbbq_bam_reader_chunk(bam, data, left_ + n, last, &info) : kbbq_fastq_reader_chunk(reader, data, left_ + n, last, &info)) < 0) return -1;
         device_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        if (bam && (info.flags & 8)) oq_unwritable = true;
         if (info.flags & 7) return -2;      // (a read name that is too short included: the host path reports it)
         const uint64_t rest = left_ + n - info.consumed;
         if (rest > kFront || (rest && last)) return -2;      // a block that does not end: not a file this path reads
@@ -593,7 +622,9 @@ private:
         cv_.notify_all();
         if (io_.joinable()) io_.join();
     }
-    static constexpr uint64_t kPiece = 256ull << 20, kFront = 1ull << 16;
+    static constexpr uint64_t kFront = 1ull << 16;
+    // bytes of the file per chunk; KBBQ_READER_PIECE_KB shrinks it so that tests cross many chunk boundaries with small files
+    const uint64_t kPiece = getenv("KBBQ_READER_PIECE_KB") ? std::max<uint64_t>(64, strtoull(getenv("KBBQ_READER_PIECE_KB"), nullptr, 10)) << 10 : 256ull << 20;
     int fd_ = -1;
     uint64_t size_ = 0, next_piece_ = 0, taken_piece_ = 0, left_ = 0, piece_bytes_[2] = {0, 0};
     uint8_t *buf_[2] = {nullptr, nullptr};
@@ -1130,6 +1161,92 @@ int main(int argc, char *argv[]) {
             dev_in.close();
         }
     }
+    // A BAM file takes the same road (DeviceFastqInput::open_bam; include/kbbq_bgzf.h: kbbq_bam_reader): the header is
+    // parsed here (its reference lengths are the genome length, kbbq.cc:196-216; its @RG ids are the table the record
+    // kernel looks read groups up in), everything behind it on the device.  The compressed bytes of every chunk stay in HBM
+    // for pass 4 while they fit; otherwise pass 4 reads the file again.  A shape that path does not take -- a read group
+    // without an @RG line, a record the host codec would report or end the stream on -- starts over with BamChunkParser.
+    if (is_bam && !fixed_mode && !host_io && resident.on && filename != "-" && !(getenv("KBBQ_DEVICE_READER") && atoi(getenv("KBBQ_DEVICE_READER")) == 0) &&
+        !(getenv("KBBQ_SERIAL_PARSE") && atoi(getenv("KBBQ_SERIAL_PARSE")))) {
+        BamReader head(filename, 1);
+        bool ok = head.ok();
+        if (ok) {
+            bam_header = head.header();
+            uint64_t header_bytes = 12 + bam_header.text.size();
+            for (auto &r : bam_header.refs) header_bytes += 8 + r.first.size() + 1;
+            // the ID fields of the @RG lines (SAMv1 1.3: tab-separated TAG:VALUE fields)
+            std::vector<std::string> rg_ids;
+            {
+                const std::string &t = bam_header.text;
+                for (size_t at = 0; at < t.size();) {
+                    size_t eol = t.find('\n', at);
+                    if (eol == std::string::npos) eol = t.size();
+                    if (eol - at >= 3 && t.compare(at, 3, "@RG") == 0) {
+                        for (size_t f = at; f < eol;) {
+                            size_t tab = t.find('\t', f);
+                            if (tab == std::string::npos || tab > eol) tab = eol;
+                            if (tab - f >= 3 && t.compare(f, 3, "ID:") == 0) { rg_ids.push_back(t.substr(f + 3, tab - f - 3)); break; }
+                            f = tab + 1;
+                        }
+                    }
+                    at = eol + 1;
+                }
+            }
+            ok = !rg_ids.empty() && rg_ids.size() < 65535 && dev_in.open_bam(filename, use_oq, (int32_t)bam_header.refs.size(), header_bytes, rg_ids);
+            bool keeping = ok && !(getenv("KBBQ_KEEP_TEXT") && atoi(getenv("KBBQ_KEEP_TEXT")) == 0) && kbbq_bam_reader_keep(dev_in.bam, 1) == 0;
+            const uint64_t text_budget = resident.budget / 4 * 5;
+            while (ok) {
+                kbbq_bam_chunk info;
+                const int rc = dev_in.next_chunk(info);
+                if (rc == 0) break;
+                if (rc < 0) { ok = false; break; }
+                dev_in.chunk_records.push_back(info.n_records);
+                if (!info.n_records) continue;
+                const uint64_t need = info.n_bases * 13 / 8 + info.n_records * 18 + (1 << 16);
+                if (keeping) {
+                    uint64_t kept_chunks = 0, kept_bytes = 0;
+                    if (kbbq_bam_reader_kept(dev_in.bam, &kept_chunks, &kept_bytes) < 0 || resident.bytes + need + kept_bytes > text_budget) {
+                        kbbq_bam_reader_keep(dev_in.bam, 0);
+                        keeping = false;
+                    }
+                }
+                kbbq_reads d;
+                const auto tb = std::chrono::steady_clock::now();
+                if (info.longest > KBBQ_MAX_READ_LEN || resident.bytes + need > resident.budget || kbbq_bam_reader_batch(dev_in.bam, &d) < 0) { ok = false; break; }
+                if (kbbq_reads_alloc_hints(&d) < 0) { kbbq_reads_free(nullptr, &d); ok = false; break; }
+                dev_in.batch_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tb).count();
+                resident.dev.push_back(d);
+                resident.bytes += need;
+                seqlen += info.n_bases;
+                n_reads += info.n_records;
+                longest = std::max<size_t>(longest, info.longest);
+                if (info.shortest == 0) ok = false;      // an empty read ends the reference's coverage and sampling loops: the host path's case
+            }
+            if (ok && set_oq && dev_in.oq_unwritable) ok = false;      // bam_aux_update_str would fail on some record: the host path reports it
+            if (ok && n_reads) {
+                // read groups in the order of their first records, as rg_to_int numbers them (readutils.cc:53-57)
+                std::vector<uint32_t> order(rg_ids.size());
+                uint32_t n_groups = 0;
+                if (kbbq_bam_reader_read_groups(dev_in.bam, order.data(), (uint32_t)order.size(), &n_groups) < 0) ok = false;
+                for (uint32_t g = 0; ok && g < n_groups; ++g) groups.index_of(rg_ids[order[g]]);
+            }
+        }
+        if (ok && n_reads) {
+            dev_in.active = true;
+            uint64_t kept_chunks = 0;
+            if (kbbq_bam_reader_rewind(dev_in.bam) == 0 && kbbq_bam_reader_kept(dev_in.bam, &kept_chunks, &dev_in.kept_bytes) == 0)
+                dev_in.text_kept = kept_chunks == resident.dev.size();
+            if (!dev_in.text_kept) { kbbq_bam_reader_keep(dev_in.bam, 0); dev_in.kept_bytes = 0; }
+            resident.keep_recs = false;      // the records come from the device's own copy of the input in pass 4
+        } else {
+            groups = ReadGroups();
+            seqlen = n_reads = 0;
+            longest = 0;
+            resident.drop();
+            init_resident();
+            dev_in.close();
+        }
+    }
     batch.pack_on_host = false;      // (the scan's batches only ever go to the device: packed there)
     bool scan_fast = false, any_empty = false;
     for (int attempt = 0; attempt < 2 && !dev_in.active; ++attempt) {
@@ -1476,11 +1593,15 @@ int main(int argc, char *argv[]) {
             size_t bi = 0;
             if (!dev_in.text_kept) {
                 dev_in.start_pass();
-                if (kbbq_fastq_reader_rewind(dev_in.reader) < 0) return fail_engine("recalibrating");
+                if ((dev_in.bam ? kbbq_bam_reader_rewind(dev_in.bam) : kbbq_fastq_reader_rewind(dev_in.reader)) < 0) return fail_engine("recalibrating");
             }
             for (size_t ci = 0; ci < dev_in.chunk_records.size(); ++ci) {
                 kbbq_fastq_chunk info;
-                if (dev_in.text_kept) {
+                if (dev_in.text_kept && dev_in.bam) {
+                    // the chunk's compressed bytes are still on the device: inflated and indexed again there
+                    if (!dev_in.chunk_records[ci]) continue;
+                    if (kbbq_bam_reader_select(dev_in.bam, bi, &info) < 0 || info.n_records != dev_in.chunk_records[ci]) return fail_engine("recalibrating");
+                } else if (dev_in.text_kept) {
                     // the chunk's text and index are still on the device
                     if (!dev_in.chunk_records[ci]) continue;
                     if (kbbq_fastq_reader_select(dev_in.reader, bi, &info) < 0 || info.n_records != dev_in.chunk_records[ci] ||
@@ -1502,7 +1623,9 @@ int main(int argc, char *argv[]) {
                     if (kbbq_device_alloc(e, d_q_bytes[t], &d_q[t]) < 0) return fail_engine("recalibrating");
                 }
                 if (kbbq_recalibrate_batch(e, &d, (uint8_t *)d_q[t]) < 0) return fail_engine("recalibrating");
-                if (!dev_out->reader_chunk(dev_in.reader, (const uint8_t *)d_q[t], kbbq_engine_stream(e))) return 1;
+                if (dev_in.bam ? !dev_out->bam_chunk(dev_in.bam, (const uint8_t *)d_q[t], set_oq, kbbq_engine_stream(e))
+                               : !dev_out->reader_chunk(dev_in.reader, (const uint8_t *)d_q[t], kbbq_engine_stream(e)))
+                    return 1;
             }
             if (!dev_out->drain()) return 1;
         } else if (resident.on && resident.keep_recs && !is_bam && dev_out) {
@@ -1727,8 +1850,8 @@ int main(int argc, char *argv[]) {
     clock.mark("pass4+format+deflate+write");
     if (clock.on && dev_in.active) {
         double inf = 0, idx = 0;
-        kbbq_fastq_reader_kernel_ms(dev_in.reader, &inf, &idx);
-        std::cerr << "[timing] FASTQ reader on the GPU (" << (dev_in.text_kept ? "one scan, the text kept in HBM: " : "both scans: ")
+        if (dev_in.bam) kbbq_bam_reader_kernel_ms(dev_in.bam, &inf, &idx); else kbbq_fastq_reader_kernel_ms(dev_in.reader, &inf, &idx);
+        std::cerr << "[timing] " << (dev_in.bam ? "BAM" : "FASTQ") << " reader on the GPU (" << (dev_in.text_kept ? "one scan, the text kept in HBM: " : "both scans: ")
                   << (dev_in.text_kept ? std::to_string(dev_in.kept_bytes) + " bytes; " : std::string()) << "waiting for file reads " << dev_in.wait_s
                   << " s, device calls " << dev_in.device_s << " s, packing + batch arrays " << dev_in.batch_s << " s; kernels: inflate " << inf << " ms, index + pack " << idx << " ms" << std::endl;
     }

@@ -257,8 +257,9 @@ struct Thresholds { int v[KBBQ_MAX_KMER + 1]; };
 // SUB (round 4): decide from a SUBSET of the lookups first.  err[i] only asks whether in[i] exceeds thr[possible[i]], and
 // the k-mers known to be present -- hint bits plus the lookups made so far -- bound in[i] from below, the skipped ones
 // from above: a base with lower bound > thr is clean, one with lower + skipped <= thr is flagged, whatever the skipped
-// lookups would say.  Phase 1 skips every fourth k-mer start (s % 4 == 3) at least `edge` starts away from both read
-// ends (near the ends thr[possible] leaves no room: the host derives `edge` from the thresholds, infer_subset_edge);
+// lookups would say.  Phase 1 skips every fourth k-mer start ((s & pmask) == pmask; every 8th or 16th when the
+// thresholds sit closer to k) at least `edge` starts away from both read ends (near the ends thr[possible] leaves no
+// room: the host derives period and `edge` from the thresholds, infer_subset_plan);
 // phase 2 makes the skipped lookups whose k bases hold an undecided base -- around real errors, where in[i] crosses
 // the threshold -- and only if the read has any.  Every base ends up with the exact decision: for a decided base the
 // final count moves inside the bounds that decided it, for an undecided one every start in its window has been looked
@@ -267,7 +268,7 @@ struct Thresholds { int v[KBBQ_MAX_KMER + 1]; };
 template <int NW, int NK, int MINW = 1, bool SUB = false>
 __global__ void __launch_bounds__(256, MINW) k_infer(ReadsDev R, KParams K, FiltDev S, Thresholds thr, uint32_t *take_bits,
                                                 unsigned long long *inserted, uint32_t *err_out, uint32_t *qpresent,
-                                                unsigned long long *lookups, unsigned int *ticket, int edge) {
+                                                unsigned long long *lookups, unsigned int *ticket, int edge, int pmask) {
     using St = Stage<NW>;
     __shared__ uint32_t lds[4][St::LDS_U32];
     __shared__ uint32_t lds_sub[SUB ? 4 : 1][SUB ? 2 * St::RES : 1];      // skipped starts, undecided bases (same shape as PW)
@@ -334,8 +335,13 @@ __global__ void __launch_bounds__(256, MINW) k_infer(ReadsDev R, KParams K, Filt
                 const uint64_t key = canon_key(lds_window64(L32 + 2 * St::B, 2 * (o31 + s)), K);
                 if (valid[c] && !known[c]) {
                     const uint32_t b = block_of(S, key), pt = pattern_of(S, key);
-                    skip[c] = SUB && (s & 3) == 3 && s >= edge && s < nk - edge;
-                    if (skip[c]) { blk2[c] = b; pat2[c] = pt; } else { blk[c] = b; pat[c] = pt; }
+                    // (selects, not branches: with `if (skip) .. else ..` hipcc 7.2 left blk[c] unassigned on the lanes
+                    // whose first two terms hold and whose last does not -- found by the parity test, seen in the ISA)
+                    const bool sk = SUB & ((s & pmask) == pmask) & (s >= edge) & (s < nk - edge);
+                    skip[c] = sk;
+                    blk[c] = sk ? 0u : b;
+                    pat[c] = sk ? 0u : pt;
+                    if (SUB) { blk2[c] = sk ? b : 0u; pat2[c] = sk ? pt : 0u; }
                 }
             }
         }

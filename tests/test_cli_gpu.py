@@ -201,7 +201,10 @@ def test_cli_error_paths(tmp_path):
 import bamutil  # noqa: E402
 
 
-def bam_dataset(tmp_path, use_oq=False, **kw):
+RG_HEADER = "@HD\tVN:1.6\tSO:unsorted\n@RG\tID:lane2\tSM:s\n@RG\tID:unused\n@RG\tSM:s\tID:lane:3\n@RG\tID:lane1\n@PG\tID:x\n"
+
+
+def bam_dataset(tmp_path, use_oq=False, rg_header=False, **kw):
     """Unaligned BAM with RG:Z (and OQ:Z) tags, about half of the records reverse-flagged: those store the
     reverse complement of what was sequenced, qualities reversed (readutils.cc:36-39, htsiter.cc:27-31)."""
     d = common.make_dataset(**kw)
@@ -230,7 +233,7 @@ def bam_dataset(tmp_path, use_oq=False, **kw):
     d["rg"] = np.array(rg_index, dtype=np.int32)
     d["second"] = (np.arange(n) & 1).astype(np.uint8)
     refs = [("chr1", d["genome_len"] - 1000), ("chr2", 1000)]
-    stream = bamutil.header("@HD\tVN:1.6\tSO:unsorted\n", refs) + b"".join(
+    stream = bamutil.header(RG_HEADER if rg_header else "@HD\tVN:1.6\tSO:unsorted\n", refs) + b"".join(
         bamutil.record(r["name"], r["flag"], r["seq"], r["qual"], r["tags"]) for r in recs)
     path = tmp_path / "in.bam"
     path.write_bytes(bamutil.bgzf_compress(stream, ragged_seed=5))
@@ -451,3 +454,55 @@ def test_cli_block_parallel_and_serial_bam_parse_agree(tmp_path, use_oq):
         rc, out, err = run_cli(args, dict(env, KBBQ_SEED="21"))
         assert rc == 0, err
         assert bamutil.bgzf_decompress(out) == want, env
+
+
+@pytest.mark.parametrize("use_oq,set_oq", [(False, False), (False, True), (True, True), (True, False)])
+def test_cli_bam_on_the_device_equals_the_host_parsers(tmp_path, use_oq, set_oq):
+    """A BAM whose header names its read groups is read on the GPU (kbbq_bam_reader: inflate, record chain, field decode) and
+    pass 4 rewrites the records there; the decompressed output must be the host path's (bam_io.cc: BamChunkParser + the host
+    rewrite, KBBQ_DEVICE_READER=0) byte for byte -- with the chunks kept in HBM, with the file read a second time
+    (KBBQ_KEEP_TEXT=0), and with chunks of 64 KB of file that cut BGZF blocks and records everywhere."""
+    db, recs, path, n_rg = bam_dataset(tmp_path, use_oq=use_oq, rg_header=True, seed=919, genome_len=30000, coverage=24, n_per_million=2000, ragged=True,
+                                       extra_errors=60)
+    args = (["--use-oq"] if use_oq else []) + (["--set-oq"] if set_oq else []) + [path]
+    rc, want, err = run_cli(args, {"KBBQ_SEED": "33", "KBBQ_DEVICE_READER": "0", "KBBQ_TIMING": "1"})
+    assert rc == 0, err
+    assert "reader on the GPU" not in err
+    want = bamutil.bgzf_decompress(want)
+    text, refs, got = bamutil.parse(want)
+    assert text == RG_HEADER and len(got) == len(recs)
+    for env in ({}, {"KBBQ_KEEP_TEXT": "0"}, {"KBBQ_READER_PIECE_KB": "64"}, {"KBBQ_READER_PIECE_KB": "64", "KBBQ_KEEP_TEXT": "0"}):
+        rc, out, err = run_cli(args, dict(env, KBBQ_SEED="33", KBBQ_TIMING="1"))
+        assert rc == 0, err
+        assert "BAM reader on the GPU" in err, err[-2000:]
+        assert ("one scan" in err) == ("KBBQ_KEEP_TEXT" not in env)
+        assert bamutil.bgzf_decompress(out) == want, env
+    # and the oracle on the same reads: the qualities are the reference pipeline's
+    total = int(db["off"][-1])
+    ora = common.run_oracle(dict(db, coverage=total // db["genome_len"]), seed=33, n_rg=n_rg)
+    off = db["off"].astype(np.int64)
+    for r, (src, g) in enumerate(zip(recs, got)):
+        w = ora["recal"][off[r]:off[r + 1]]
+        assert np.array_equal(g["qual"], w[::-1] if src["flag"] & 16 else w), "read %d" % r
+
+
+def test_cli_bam_shapes_the_device_path_hands_back(tmp_path):
+    """A read group the header does not name, and a record without RG: the device reader flags the chunk, the command line
+    starts over with the host parsers and behaves as before (output / the reference's message)."""
+    db, recs, path, n_rg = bam_dataset(tmp_path, rg_header=True, seed=920, genome_len=12000, coverage=20, read_len=100)
+    recs2 = [dict(r, tags=[("RG", "Z", "lane9") if t[0] == "RG" else t for t in r["tags"]]) if i % 50 == 7 else r for i, r in enumerate(recs)]
+    refs = [("chr1", db["genome_len"] - 1000), ("chr2", 1000)]
+    p2 = tmp_path / "unnamed.bam"
+    p2.write_bytes(bamutil.bgzf_compress(bamutil.header(RG_HEADER, refs) + b"".join(
+        bamutil.record(r["name"], r["flag"], r["seq"], r["qual"], r["tags"]) for r in recs2), ragged_seed=3))
+    rc, out, err = run_cli([p2], {"KBBQ_SEED": "5", "KBBQ_TIMING": "1"})
+    assert rc == 0, err
+    assert "reader on the GPU" not in err
+    rc, want, err = run_cli([p2], {"KBBQ_SEED": "5", "KBBQ_DEVICE_READER": "0"})
+    assert rc == 0 and bamutil.bgzf_decompress(out) == bamutil.bgzf_decompress(want)
+    recs3 = [dict(r, tags=[t for t in r["tags"] if t[0] != "RG"]) if i == 31 else r for i, r in enumerate(recs)]
+    p3 = tmp_path / "norg.bam"
+    p3.write_bytes(bamutil.bgzf_compress(bamutil.header(RG_HEADER, refs) + b"".join(
+        bamutil.record(r["name"], r["flag"], r["seq"], r["qual"], r["tags"]) for r in recs3)))
+    rc, out, err = run_cli([p3], {"KBBQ_SEED": "5"})
+    assert rc != 0 and "Unable to read RG tag on read " + recs3[31]["name"] in err
