@@ -167,6 +167,14 @@ int kbbq_bam_reader_batch(kbbq_bam_reader *r, kbbq_reads *dev);
 int kbbq_bam_reader_write(kbbq_bam_reader *r, kbbq_bgzf *z, const uint8_t *d_qual, int32_t set_oq, void *after_stream);
 int kbbq_bam_reader_kernel_ms(kbbq_bam_reader *r, double *inflate_ms, double *index_ms);
 
+/* ---- test and bench data as files: reads [first_read, first_read + n) of the synthetic data set (kbbq_synth_params: the
+ * generator bench.py measures on) formatted on the device and submitted to z like any payload.  format 0: four-line FASTQ,
+ * names "r%010llu"; 1: unaligned BAM records with RG:Z:grp0, about half of them reverse-flagged (stored reverse-complemented,
+ * qualities reversed); 2: the same with the true qualities in OQ:Z and 11s in the quality field (BASELINE configs[3]:
+ * --use-oq).  Every record has the same size.  The caller writes the BAM header itself.  `kbbq --io-test synth-fastq|synth-bam`. */
+int kbbq_bgzf_submit_synth(kbbq_bgzf *z, kbbq_engine *e, const kbbq_synth_params *sp, uint64_t first_read, uint64_t n, int32_t format,
+                           uint64_t *payload_bytes);
+
 /* ---- host-only twin (no GPU touched): the same scalar pieces (Huffman lengths, header, token bits, CRC chaining,
  * framing) around a serial match finder; lets the CPU test-suite inflate what those pieces produce. */
 int kbbq_host_bgzf_compress(const uint8_t *payload, uint64_t n, uint8_t *out, uint64_t out_capacity, uint64_t *out_bytes);

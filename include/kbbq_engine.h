@@ -183,6 +183,11 @@ int kbbq_device_or(kbbq_engine *e, void *dst_device, const void *src_device, uin
 int kbbq_device_or_pieces(kbbq_engine *e, void *dst_device, const void *src_device, uint64_t piece_words,
                           int32_t n_pieces, int32_t skip);
 int kbbq_filter_set_inserted(kbbq_engine *e, int which, uint64_t inserted);
+/* A running byte sum on the engine's stream: the digest of recalibrated qualities that never leave the device uncompressed
+ * (`kbbq` with KBBQ_QUAL_DIGEST=1 prints it; bench.py's recal_qual_sum is the same number).  add: queued behind the
+ * kernels that produce device_bytes; get: waits, returns the sum since the last reset. */
+int kbbq_digest_add(kbbq_engine *e, const uint8_t *device_bytes, uint64_t n);
+int kbbq_digest_get(kbbq_engine *e, uint64_t *sum, int32_t reset);
 
 /* ---- read staging ------------------------------------------------------ */
 

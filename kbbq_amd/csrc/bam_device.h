@@ -332,7 +332,10 @@ __global__ void __launch_bounds__(256) k_bam_records(const uint8_t *text, uint64
             if (same) rg = i;
         }
         if (rg == 0xFFFF) fl |= BAMF_FALLBACK;      // a read group without an @RG line: the host path's dictionary handles it
-        else atomicMin(&first_seen[rg], (unsigned long long)r);
+        // first appearance: a look first -- after the first wavefronts of a chunk nearly every record finds a smaller
+        // ordinal there already (with an atomic per record, 2.5e6 of them on one address were 25 of the kernel's 28 ms)
+        else if (__hip_atomic_load(&first_seen[rg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (unsigned long long)r)
+            atomicMin(&first_seen[rg], (unsigned long long)r);
     }
     // OQ (readutils.cc:16-31; htsiter.cc:13-26)
     uint32_t oq_vlen = 0;
@@ -356,8 +359,8 @@ __global__ void __launch_bounds__(256) k_bam_records(const uint8_t *text, uint64
     X.rg[r] = (uint16_t)rg;
     X.base_sz[r] = l_seq;
     if (fl) atomicOr(&out[0], fl);
-    atomicMax(&out[1], l_seq);
-    atomicMin(&out[2], l_seq);
+    if (__hip_atomic_load(&out[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < l_seq) atomicMax(&out[1], l_seq);
+    if (__hip_atomic_load(&out[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > l_seq) atomicMin(&out[2], l_seq);
 }
 
 // second-in-pair flags (readutils.cc:59) and the dense read-group index of every record
@@ -445,6 +448,98 @@ __global__ void __launch_bounds__(256) k_bam_rewrite(const uint8_t *text, BamInd
                 b = src[tail + (j - (v0 + n + 1))];
             }
             dst[j] = b;
+        }
+    }
+}
+
+// ---- the synthetic data set as files (tools: `kbbq --io-test synth-fastq / synth-bam`): the bench's own reads
+// (kbbq_synth_reads, engine.hip: k_synth) formatted on the device, so that a true 30x WGS-size FASTQ or BAM can be fed
+// to the command line and its digest compared with bench.py's.  Fixed-width names: every record has the same size.
+struct SynthBatch {
+    const uint64_t *bases, *nmask;
+    const uint8_t *qual;
+    uint64_t first, n;      // global index of the batch's first read, reads
+    uint32_t read_len;
+};
+__device__ __forceinline__ void synth_base(const SynthBatch &B, uint64_t g, uint32_t &code, bool &is_n) {
+    code = (uint32_t)(B.bases[g >> 5] >> (2 * (g & 31))) & 3;
+    is_n = (B.nmask[g >> 6] >> (g & 63)) & 1;
+}
+__device__ __forceinline__ void synth_name(uint8_t *dst, uint64_t idx) {      // 'r' + 10 decimal digits
+    dst[0] = 'r';
+    for (int j = 10; j >= 1; --j) { dst[j] = (uint8_t)('0' + idx % 10); idx /= 10; }
+}
+constexpr uint32_t synth_fastq_record(uint32_t L) { return 2 * L + 17; }      // "@" name "\n" seq "\n+\n" qual "\n"
+constexpr uint32_t synth_bam_record(uint32_t L, bool oq) { return 4 + 32 + 12 + (L + 1) / 2 + L + 8 + (oq ? L + 4 : 0); }
+
+__global__ void __launch_bounds__(256) k_synth_fastq(SynthBatch B, uint8_t *out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * 4;
+    const uint32_t L = B.read_len, W = synth_fastq_record(L);
+    for (uint64_t r = wave; r < B.n; r += n_waves) {
+        uint8_t *d = out + r * W;
+        if (lane == 0) {
+            d[0] = '@';
+            synth_name(d + 1, B.first + r);
+            d[12] = '\n';
+            d[13 + L] = '\n'; d[14 + L] = '+'; d[15 + L] = '\n';
+            d[16 + 2 * L] = '\n';
+        }
+        for (uint32_t i = lane; i < L; i += 64) {
+            uint32_t c; bool nn;
+            synth_base(B, r * L + i, c, nn);
+            d[13 + i] = nn ? 'N' : (uint8_t)"ACGT"[c];
+            d[16 + L + i] = (uint8_t)(B.qual[r * L + i] + 33);
+        }
+    }
+}
+
+// unaligned BAM records: RG:Z:grp0, FLAG 4 (+16 for about half: those store the reverse complement with the qualities
+// reversed, as an aligner would); oq: the true qualities travel in OQ:Z, the quality field holds 11s (configs[3])
+__global__ void __launch_bounds__(256) k_synth_bam(SynthBatch B, int oq, uint8_t *out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * 4;
+    const uint32_t L = B.read_len, W = synth_bam_record(L, oq != 0), half = (L + 1) / 2;
+    for (uint64_t r = wave; r < B.n; r += n_waves) {
+        uint8_t *d = out + r * W;
+        const uint64_t idx = B.first + r;
+        const bool rev = ((idx * 2654435761ull) >> 7) & 1;
+        if (lane < 36) {
+            const uint32_t bs = W - 4, flag = 4u | (rev ? 16u : 0u);
+            uint8_t v = 0;
+            if (lane < 4) v = (uint8_t)(bs >> (8 * lane));
+            else if (lane < 12) v = 0xFF;                                    // refID, pos = -1
+            else if (lane == 12) v = 12;                                     // l_read_name
+            else if (lane == 14) v = 4680 & 0xFF;                            // bin
+            else if (lane == 15) v = 4680 >> 8;
+            else if (lane == 18) v = (uint8_t)flag;
+            else if (lane >= 20 && lane < 24) v = (uint8_t)(L >> (8 * (lane - 20)));
+            else if (lane >= 24 && lane < 32) v = 0xFF;                      // next refID, next pos = -1
+            d[lane] = v;
+        }
+        if (lane == 36) { synth_name(d + 36, idx); d[47] = 0; }
+        uint8_t *sq = d + 48, *ql = sq + half, *aux = ql + L;
+        if (lane == 37) { aux[0] = 'R'; aux[1] = 'G'; aux[2] = 'Z'; aux[3] = 'g'; aux[4] = 'r'; aux[5] = 'p'; aux[6] = '0'; aux[7] = 0; }
+        if (oq && lane == 38) { aux[8] = 'O'; aux[9] = 'Q'; aux[10] = 'Z'; aux[11 + L] = 0; }
+        for (uint32_t j = lane; j < half; j += 64) {                        // two stored bases per byte
+            uint8_t byte = 0;
+            for (uint32_t h = 0; h < 2; ++h) {
+                const uint32_t i = 2 * j + h;
+                uint32_t code = 0;
+                if (i < L) {
+                    uint32_t c; bool nn;
+                    synth_base(B, r * L + (rev ? L - 1 - i : i), c, nn);
+                    if (rev) c = 3 - c;
+                    code = nn ? 15u : (1u << c);
+                }
+                byte |= (uint8_t)(code << (h ? 0 : 4));
+            }
+            sq[j] = byte;
+        }
+        for (uint32_t i = lane; i < L; i += 64) {
+            const uint8_t q = B.qual[r * L + (rev ? L - 1 - i : i)];
+            ql[i] = oq ? (uint8_t)11 : q;
+            if (oq) aux[11 + i] = (uint8_t)(q + 33);
         }
     }
 }

@@ -557,6 +557,37 @@ int kbbq_bam_reader_write(kbbq_bam_reader *r, kbbq_bgzf *z, const uint8_t *d_qua
     return KBBQ_OK;
 }
 
+int kbbq_bgzf_submit_synth(kbbq_bgzf *z, kbbq_engine *e, const kbbq_synth_params *sp, uint64_t first_read, uint64_t n, int32_t format,
+                           uint64_t *payload_bytes) {
+    if (!z || !e || !sp || !n || format < 0 || format > 2) return fail(KBBQ_EINVAL, "bad argument");
+    KbbqDeviceGuard guard(z->device);
+    HIP_TRY(guard.err);
+    kbbq_reads dev;
+    int rc = kbbq_synth_reads(e, sp, first_read, n, &dev);
+    if (rc) return rc;
+    struct FreeBatch { kbbq_engine *e; kbbq_reads *d; ~FreeBatch() { kbbq_reads_free(e, d); } } free_batch{e, &dev};
+    const uint32_t W = format == 0 ? synth_fastq_record(sp->read_len) : synth_bam_record(sp->read_len, format == 2);
+    const uint64_t t = n * (uint64_t)W;
+    Submission *sp2;
+    if ((rc = begin_submission(z, kbbq_engine_stream(e), &sp2))) return rc;
+    Submission &s = *sp2;
+    s.n = t;
+    s.formatted = true;
+    if ((rc = s.payload.reserve(t + 16))) return rc;
+    HIP_TRY(hipMemsetAsync((char *)s.payload.p + t, 0, 16, z->st));
+    HIP_TRY(hipEventRecord(s.t0, z->st));
+    SynthBatch B;
+    B.bases = dev.bases; B.nmask = dev.nmask; B.qual = dev.qual; B.first = first_read; B.n = n; B.read_len = sp->read_len;
+    const unsigned grid = (unsigned)std::min<uint64_t>((n + 3) / 4, 256 * 32);
+    if (format == 0) hipLaunchKernelGGL(k_synth_fastq, dim3(grid), dim3(256), 0, z->st, B, (uint8_t *)s.payload.p);
+    else hipLaunchKernelGGL(k_synth_bam, dim3(grid), dim3(256), 0, z->st, B, format == 2 ? 1 : 0, (uint8_t *)s.payload.p);
+    HIP_TRY(hipGetLastError());
+    if ((rc = launch_deflate(z, s))) return rc;
+    HIP_TRY(hipEventSynchronize(s.t1));      // the batch is freed on return: the formatting kernel must be through with it
+    if (payload_bytes) *payload_bytes = t;
+    return KBBQ_OK;
+}
+
 int kbbq_bam_reader_kernel_ms(kbbq_bam_reader *r, double *inflate_ms, double *index_ms) {
     if (!r) return fail(KBBQ_EINVAL, "null argument");
     if (inflate_ms) *inflate_ms = r->ms_inflate;

@@ -814,8 +814,8 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
     CREATE_TRY(hipMemset(e->d_counters, 0, 64));
     CREATE_TRY(hipMalloc(&e->d_tickets, 64));
     CREATE_TRY(hipMemset(e->d_tickets, 0, 64));
-    CREATE_TRY(hipMalloc(&e->d_totals, 16));
-    CREATE_TRY(hipMemset(e->d_totals, 0, 16));
+    CREATE_TRY(hipMalloc(&e->d_totals, 32));
+    CREATE_TRY(hipMemset(e->d_totals, 0, 32));      // ([2]: the running byte sum of kbbq_digest_add)
     e->cur_cnt = e->d_counters;
     CREATE_TRY(hipMalloc(&e->d_dq_qslot, KBBQ_NQ));
     CREATE_TRY(hipMalloc(&e->d_qpresent, 32));
@@ -1040,6 +1040,42 @@ int kbbq_device_or(kbbq_engine *e, void *dst_device, const void *src_device, uin
     hipLaunchKernelGGL(k_or_words, dim3((unsigned)((n_words / 2 + 256) / 256)), dim3(256), 0, e->stream,
                        (uint64_t *)dst_device, (const uint64_t *)src_device, n_words);
     HIP_TRY(hipGetLastError());
+    return KBBQ_OK;
+}
+
+// sum of n bytes, added to *total (one 64-bit atomic per wavefront)
+__global__ void __launch_bounds__(256) k_sum_bytes(const uint8_t *d, uint64_t n, unsigned long long *total) {
+    unsigned long long mine = 0;
+    for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n; i += (uint64_t)gridDim.x * blockDim.x * 16) {
+        if (i + 16 <= n && !(((uintptr_t)d + i) & 15)) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(d + i);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            for (int j = 0; j < 4; ++j) mine += (w[j] & 0xFF) + ((w[j] >> 8) & 0xFF) + ((w[j] >> 16) & 0xFF) + (w[j] >> 24);
+        } else {
+            for (uint64_t j = i; j < n && j < i + 16; ++j) mine += d[j];
+        }
+    }
+    for (int o = 32; o; o >>= 1) mine += __shfl_down(mine, o);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(total, mine);
+}
+
+int kbbq_digest_add(kbbq_engine *e, const uint8_t *device_bytes, uint64_t n) {
+    ENGINE_DEVICE(e);
+    if (!e || (!device_bytes && n)) return fail(KBBQ_EINVAL, "bad argument");
+    if (!n) return KBBQ_OK;
+    hipLaunchKernelGGL(k_sum_bytes, dim3((unsigned)std::min<uint64_t>((n / 16 + 256) / 256, 4096)), dim3(256), 0, e->stream, device_bytes, n, e->d_totals + 2);
+    HIP_TRY(hipGetLastError());
+    return KBBQ_OK;
+}
+
+int kbbq_digest_get(kbbq_engine *e, uint64_t *sum, int32_t reset) {
+    ENGINE_DEVICE(e);
+    if (!e || !sum) return fail(KBBQ_EINVAL, "bad argument");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpy(&v, e->d_totals + 2, 8, hipMemcpyDeviceToHost));
+    *sum = v;
+    if (reset) HIP_TRY(hipMemset(e->d_totals + 2, 0, 8));
     return KBBQ_OK;
 }
 

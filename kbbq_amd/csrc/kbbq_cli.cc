@@ -264,6 +264,14 @@ public:
         ++in_flight_;
         return true;
     }
+    // reads of the synthetic data set formatted on the device (kbbq_bgzf_submit_synth)
+    bool synth_batch(kbbq_engine *e, const kbbq_synth_params *sp, uint64_t first, uint64_t n, int format) {
+        if (!flush_host()) return false;
+        if (!make_room()) return false;
+        if (kbbq_bgzf_submit_synth(z_, e, sp, first, n, format, nullptr) < 0) return fail_here();
+        ++in_flight_;
+        return true;
+    }
     // every submission so far has been written out (a caller may then reuse device memory the submissions read)
     bool drain() {
         while (in_flight_ > 0) if (!collect_one()) return false;
@@ -985,6 +993,37 @@ static int io_test(int argc, char *argv[]) {
         }
         return out.close() ? 0 : 1;
     }
+    if ((what == "synth-fastq" || what == "synth-bam") && argc > 4) {
+        // The bench's own reads as a file on stdout: --io-test synth-fastq GENOME_LEN COVERAGE / synth-bam GENOME_LEN COVERAGE [oq]
+        // (bench.py: seed 12345, 150-base reads, 100 N per million): k_synth -> record text / BAM records -> k_deflate, all on
+        // the device.  The command line run on this file must log the bench's insert counts and write the bench's digest.
+        const uint64_t G = strtoull(argv[3], nullptr, 10), cov = strtoull(argv[4], nullptr, 10);
+        const bool bam = what == "synth-bam", oq = bam && argc > 5 && std::string(argv[5]) == "oq";
+        kbbq_synth_params sp;
+        memset(&sp, 0, sizeof sp);
+        sp.seed = 12345; sp.genome_len = G; sp.read_len = 150; sp.n_reads = G * cov / 150; sp.n_rg = 1; sp.paired = 0; sp.n_per_million = 100;
+        if (G < 150 || !sp.n_reads) return 2;
+        kbbq_params prm;
+        memset(&prm, 0, sizeof prm);
+        prm.k = 32; prm.alpha = 0.1; prm.seed = 1; prm.n_rg = 1; prm.approx_kmers = 1000; prm.max_read_len = 150; prm.fpr_sampled = 0.01; prm.fpr_trusted = 0.0005;
+        prm.bloom_seed = 0xA5A5A5A55A5A5A5AULL;
+        kbbq_engine *e = nullptr;
+        if (kbbq_engine_create(&prm, &e) < 0) { std::cerr << kbbq_last_error() << std::endl; return 1; }
+        struct FreeEngine { kbbq_engine *e; ~FreeEngine() { kbbq_engine_destroy(e); } } free_engine{e};
+        DeviceBgzfWriter out(stdout, 0);
+        if (!out.ok()) return 1;
+        if (bam) {
+            BamHeader h;
+            h.text = "@HD\tVN:1.6\tSO:unsorted\n@RG\tID:grp0\tSM:synth\n";
+            h.refs.emplace_back("chr1", (uint32_t)std::min<uint64_t>(G, 0xFFFFFFFFull));
+            BamWriter w(out);
+            if (!w.write_header(h)) return 1;
+        }
+        const uint64_t step = (uint64_t)1 << 22;
+        for (uint64_t first = 0; first < sp.n_reads; first += step)
+            if (!out.synth_batch(e, &sp, first, std::min(step, sp.n_reads - first), bam ? (oq ? 2 : 1) : 0)) return 1;
+        return out.close() ? 0 : 1;
+    }
     if (what == "bgzf") {   // stdin -> BGZF on stdout: --io-test bgzf [threads]
         BgzfWriter out(stdout, argc > 3 ? atoi(argv[3]) : 1);
         std::vector<char> buf(1 << 16);
@@ -1479,7 +1518,10 @@ int main(int argc, char *argv[]) {
                     if (kbbq_trusted_batch(e, &batch.c, nullptr) < 0) return fail_engine("finding trusted kmers");
                 if (batch.fatal) return 1;
             }
-            if (kbbq_trusted_finish(e, nullptr) < 0) return fail_engine("finding trusted kmers");
+            uint64_t trusted_inserted = 0;
+            if (kbbq_trusted_finish(e, &trusted_inserted) < 0) return fail_engine("finding trusted kmers");
+            if (getenv("KBBQ_QUAL_DIGEST") && atoi(getenv("KBBQ_QUAL_DIGEST")))      // (the reference prints no count here; bench.py's result.trusted_inserted)
+                std::cerr << "[digest] trusted_inserted " << trusted_inserted << std::endl;
         }
         // pass 3, kbbq.cc:363-366
         clock.mark("pass2");
@@ -1591,6 +1633,9 @@ int main(int argc, char *argv[]) {
             size_t d_q_bytes[2] = {0, 0};
             struct FreeQ { kbbq_engine *e; void **p; ~FreeQ() { for (int i = 0; i < 2; ++i) if (p[i]) kbbq_device_free(e, p[i]); } } free_q{e, d_q};
             size_t bi = 0;
+            // KBBQ_QUAL_DIGEST=1: the sum of every recalibrated quality, taken on the device from the array the writer reads
+            // (the number bench.py prints as recal_qual_sum for the same reads)
+            const bool want_digest = getenv("KBBQ_QUAL_DIGEST") && atoi(getenv("KBBQ_QUAL_DIGEST"));
             if (!dev_in.text_kept) {
                 dev_in.start_pass();
                 if ((dev_in.bam ? kbbq_bam_reader_rewind(dev_in.bam) : kbbq_fastq_reader_rewind(dev_in.reader)) < 0) return fail_engine("recalibrating");
@@ -1623,11 +1668,17 @@ int main(int argc, char *argv[]) {
                     if (kbbq_device_alloc(e, d_q_bytes[t], &d_q[t]) < 0) return fail_engine("recalibrating");
                 }
                 if (kbbq_recalibrate_batch(e, &d, (uint8_t *)d_q[t]) < 0) return fail_engine("recalibrating");
+                if (want_digest && kbbq_digest_add(e, (const uint8_t *)d_q[t], d.n_bases) < 0) return fail_engine("recalibrating");
                 if (dev_in.bam ? !dev_out->bam_chunk(dev_in.bam, (const uint8_t *)d_q[t], set_oq, kbbq_engine_stream(e))
                                : !dev_out->reader_chunk(dev_in.reader, (const uint8_t *)d_q[t], kbbq_engine_stream(e)))
                     return 1;
             }
             if (!dev_out->drain()) return 1;
+            if (want_digest) {
+                uint64_t sum = 0;
+                if (kbbq_digest_get(e, &sum, 1) < 0) return fail_engine("recalibrating");
+                std::cerr << "[digest] recal_qual_sum " << sum << " reads " << n_reads << " bases " << seqlen << std::endl;
+            }
         } else if (resident.on && resident.keep_recs && !is_bam && dev_out) {
             // FASTQ, every batch in HBM, its record text in host memory: the new qualities never leave the GPU.  Pass 4
             // writes them to a device array, the writer assembles "@name\nseq\n+comment\nqual\n" there (FastqFile::write,
