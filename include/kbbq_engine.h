@@ -156,6 +156,8 @@ int kbbq_engine_sync(kbbq_engine *e);
 int kbbq_engine_tune(kbbq_engine *e, const char *name, uint64_t value);
 /* hipStream_t of the engine, as void*. */
 void *kbbq_engine_stream(kbbq_engine *e);
+/* First and last dimension of the histograms and delta-Q tables: read groups, cycles (kbbq_params.n_rg / max_read_len). */
+int kbbq_engine_dims(kbbq_engine *e, uint64_t *n_rg, uint64_t *n_cycle);
 const char *kbbq_last_error(void);
 
 int kbbq_filter_info_get(kbbq_engine *e, int which, kbbq_filter_info *out);

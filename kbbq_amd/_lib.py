@@ -167,6 +167,17 @@ SYMBOLS = {
                                                  ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "kbbq_fastq_reader_attach": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads)]),
     "kbbq_fastq_reader_kernel_ms": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "kbbq_engine_dims": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    "kbbq_group_rccl_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "kbbq_group_rccl_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(c_vp)]),
+    "kbbq_group_from_nccl_comm": (ctypes.c_int, [c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(c_vp)]),
+    "kbbq_group_local_create": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(c_vp)]),
+    "kbbq_group_destroy": (None, [c_vp]),
+    "kbbq_group_rank": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    "kbbq_exchange_filter": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
+    "kbbq_exchange_histograms": (ctypes.c_int, [c_vp, c_vp]),
+    "kbbq_exchange_dq": (ctypes.c_int, [c_vp, c_vp]),
+    "kbbq_exchange_ms": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double)]),
     "kbbq_digest_add": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint64]),
     "kbbq_digest_get": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int32]),
     "kbbq_bgzf_submit_synth": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint64)]),

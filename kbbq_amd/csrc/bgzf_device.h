@@ -22,8 +22,22 @@
 namespace kbbq {
 namespace dfl {
 
-constexpr int HASH_BITS = 12;                       // 4096 most-recent positions per wave: 8 KB of LDS (8192: 0.5 % smaller output, 15 % slower;
-                                                    // 2048 with five waves per SIMD: 7 % faster, 0.5 % larger: profiles/r03_deflate_variants.txt)
+// The match finder's table: HASH_SIZE buckets of HASH_WAYS positions (u16), the most recent position of a hash in way 0 and
+// -- with two ways -- the one it displaced in way 1: every position then has two candidates, the nearer one preferred on
+// equal length.  One way of 4096 (the default): 8 KB of LDS (8192: 0.5 % smaller output, 15 % slower; 2048 with five waves
+// per SIMD: 7 % faster, 0.5 % larger: profiles/r03_deflate_variants.txt).  Two ways were built and measured in round 4
+// (profiles/r04_deflate_variants.txt, the same 503 MB of FASTQ text, zlib level 6 = 181 MB): one way 194 MB at 40 GB/s, two
+// ways of 4096 191 MB at 34.6 GB/s -- 1.5 % of size for 14 % of the rate; on that text zlib itself goes from 1.098x (level 1,
+// chains of 4) over 1.067x (level 2, chains of 8) to 1.037x (level 3, chains of 32): the gap to level 6 is chain depth, and
+// every way costs a sweep-2 compare per position.  -DKBBQ_DFL_WAYS=2 / -DKBBQ_DFL_HASH_BITS build the variants.
+#ifndef KBBQ_DFL_WAYS
+#define KBBQ_DFL_WAYS 1
+#endif
+#ifndef KBBQ_DFL_HASH_BITS
+#define KBBQ_DFL_HASH_BITS 12
+#endif
+constexpr int HASH_WAYS = KBBQ_DFL_WAYS;
+constexpr int HASH_BITS = KBBQ_DFL_HASH_BITS;
 constexpr int HASH_SIZE = 1 << HASH_BITS;
 constexpr int DFL_WAVES = 1;                        // wavefronts per workgroup: each works alone (no workgroup barrier anywhere), 18 KB of LDS
 constexpr int MIN_TAKE = 4;                         // shortest match the 4-byte hash can find
@@ -120,7 +134,7 @@ __device__ __forceinline__ uint32_t wave_crc32(const uint8_t *in, int len, const
 // LDS of one wavefront.  The Huffman scratch of the second phase lies over the hash table of the first.
 struct WaveLds {
     union {
-        uint16_t htab[HASH_SIZE];
+        uint16_t htab[HASH_WAYS * HASH_SIZE];      // way 0, then way 1
         struct {
             uint8_t head[HEAD_BYTES];
             uint16_t order[N_LL];
@@ -158,7 +172,7 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
         unsigned long long prof_t = __builtin_readcyclecounter();
 #endif
         // ---- reset
-        for (int i = lane; i < HASH_SIZE; i += 64) S.u.htab[i] = 0xFFFFu;
+        for (int i = lane; i < HASH_WAYS * HASH_SIZE; i += 64) S.u.htab[i] = 0xFFFFu;
         for (int i = lane; i < N_LL; i += 64) S.ll_freq[i] = 0;
         if (lane < N_D) S.d_freq[lane] = 0;
         __builtin_amdgcn_wave_barrier();
@@ -188,8 +202,13 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
                     ahead[u] = load8(in + min(p + 64 * PF, len));
                     const bool hashed = p + 4 <= len;
                     const uint32_t h = hash4((uint32_t)cur);
-                    uint32_t cand = 0xFFFFu;
-                    if (hashed) { cand = S.u.htab[h]; S.u.htab[h] = (uint16_t)p; }
+                    uint32_t cand = 0xFFFFu, cand2 = 0xFFFFu;
+                    if (hashed) {
+                        // (every lane of the step reads before any writes: LDS instructions of a wave run in order)
+                        cand = S.u.htab[h];
+                        if (HASH_WAYS > 1) { cand2 = S.u.htab[HASH_SIZE + h]; S.u.htab[HASH_SIZE + h] = (uint16_t)cand; }
+                        S.u.htab[h] = (uint16_t)p;
+                    }
                     __builtin_amdgcn_wave_barrier();
                     // of several lanes with one hash the highest position stays
                     for (;;) {
@@ -198,7 +217,7 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
                         if (lose) S.u.htab[h] = (uint16_t)p;
                         __builtin_amdgcn_wave_barrier();
                     }
-                    if (p < len) tokens[p] = cand;
+                    if (p < len) tokens[p] = cand | (cand2 << 16);
                 }
             }
         }
@@ -208,39 +227,49 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
         // come two rounds ahead, and with them -- one round ahead -- the text at the positions and at their candidates.
         // tokens[p] = length << 16 | distance, 0: no match.
         {
-            uint64_t cur_n[PF2], cur2_n[PF2], old_n[PF2], old2_n[PF2];
+            uint64_t cur_n[PF2], cur2_n[PF2], old_n[HASH_WAYS][PF2], old2_n[HASH_WAYS][PF2];
             uint32_t cand_nn[PF2], prev_n[PF2];
-            int cand_n[PF2];
+            int cand_n[HASH_WAYS][PF2];
             auto clean = [&](int p, uint32_t c) -> int { return (p + 4 <= len && c != 0xFFFFu && p - (int)c <= MAX_DIST) ? (int)c : -1; };
 #pragma unroll
             for (int u = 0; u < PF2; ++u) {      // round 0: everything; round 1: the candidates
                 const int p = min(64 * u + lane, len), pn = min(64 * (u + PF2) + lane, len);
-                cand_n[u] = clean(64 * u + lane, tokens[min(p, (int)TOKENS_PER_WAVE - 1)]);
+                const uint32_t raw = tokens[min(p, (int)TOKENS_PER_WAVE - 1)];
                 cand_nn[u] = tokens[min(pn, (int)TOKENS_PER_WAVE - 1)];
                 cur_n[u] = load8(in + p);
                 cur2_n[u] = load8(in + p + 8);
                 prev_n[u] = in[max(p, 1) - 1];
-                old_n[u] = load8(in + max(cand_n[u], 0));
-                old2_n[u] = load8(in + max(cand_n[u], 0) + 8);
+#pragma unroll
+                for (int w = 0; w < HASH_WAYS; ++w) {
+                    cand_n[w][u] = clean(64 * u + lane, w ? raw >> 16 : raw & 0xFFFFu);
+                    old_n[w][u] = load8(in + max(cand_n[w][u], 0));
+                    old2_n[w][u] = load8(in + max(cand_n[w][u], 0) + 8);
+                }
             }
             for (int b0 = 0; b0 < len; b0 += 64 * PF2) {
-                int cand[PF2];
-                uint64_t cur[PF2], cur2[PF2], old[PF2], old2[PF2];
+                int cand[HASH_WAYS][PF2];
+                uint64_t cur[PF2], cur2[PF2], old[HASH_WAYS][PF2], old2[HASH_WAYS][PF2];
                 uint32_t prev[PF2];
 #pragma unroll
                 for (int u = 0; u < PF2; ++u) {
-                    cur[u] = cur_n[u]; cur2[u] = cur2_n[u]; old[u] = old_n[u]; old2[u] = old2_n[u]; prev[u] = prev_n[u]; cand[u] = cand_n[u];
+                    cur[u] = cur_n[u]; cur2[u] = cur2_n[u]; prev[u] = prev_n[u];
+#pragma unroll
+                    for (int w = 0; w < HASH_WAYS; ++w) { old[w][u] = old_n[w][u]; old2[w][u] = old2_n[w][u]; cand[w][u] = cand_n[w][u]; }
                 }
 #pragma unroll
                 for (int u = 0; u < PF2; ++u) {
                     const int q1 = b0 + 64 * (u + PF2) + lane, p1 = min(q1, len), p2 = min(q1 + 64 * PF2, len);
-                    cand_n[u] = clean(q1, cand_nn[u]);
+                    const uint32_t raw = cand_nn[u];
                     cand_nn[u] = tokens[min(p2, (int)TOKENS_PER_WAVE - 1)];
                     cur_n[u] = load8(in + p1);
                     cur2_n[u] = load8(in + p1 + 8);
                     prev_n[u] = in[p1 - 1];
-                    old_n[u] = load8(in + max(cand_n[u], 0));
-                    old2_n[u] = load8(in + max(cand_n[u], 0) + 8);
+#pragma unroll
+                    for (int w = 0; w < HASH_WAYS; ++w) {
+                        cand_n[w][u] = clean(q1, w ? raw >> 16 : raw & 0xFFFFu);
+                        old_n[w][u] = load8(in + max(cand_n[w][u], 0));
+                        old2_n[w][u] = load8(in + max(cand_n[w][u], 0) + 8);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < PF2; ++u) {
@@ -248,12 +277,15 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
                     const bool hashed = p + 4 <= len;
                     int L = 0, D = 0;
                     const int lim = min((int)MAX_MATCH, len - p);
-                    if (cand[u] >= 0) {
-                        const uint64_t x = cur[u] ^ old[u], x2 = cur2[u] ^ old2[u];
-                        int n = x ? (int)(__builtin_ctzll(x) >> 3) : x2 ? 8 + (int)(__builtin_ctzll(x2) >> 3)
-                                                                       : 16 + match_length(in, cand[u] + 16, p + 16, max(0, lim - 16));
-                        n = min(n, lim);
-                        if (n >= MIN_TAKE) { L = n; D = p - cand[u]; }
+#pragma unroll
+                    for (int w = 0; w < HASH_WAYS; ++w) {      // way 0 is the nearer candidate: it wins a tie
+                        if (cand[w][u] >= 0) {
+                            const uint64_t x = cur[u] ^ old[w][u], x2 = cur2[u] ^ old2[w][u];
+                            int n = x ? (int)(__builtin_ctzll(x) >> 3) : x2 ? 8 + (int)(__builtin_ctzll(x2) >> 3)
+                                                                           : 16 + match_length(in, cand[w][u] + 16, p + 16, max(0, lim - 16));
+                            n = min(n, lim);
+                            if (n >= MIN_TAKE && n > L) { L = n; D = p - cand[w][u]; }
+                        }
                     }
                     // a run of one byte (the candidate the table cannot hold: the position just before, inside this step)
                     if (hashed && p > 0 && (uint8_t)prev[u] == (uint8_t)cur[u]) {

@@ -938,6 +938,13 @@ int kbbq_engine_sync(kbbq_engine *e) {
 
 void *kbbq_engine_stream(kbbq_engine *e) { return e ? (void *)e->stream : nullptr; }
 
+int kbbq_engine_dims(kbbq_engine *e, uint64_t *n_rg, uint64_t *n_cycle) {
+    if (!e) return fail(KBBQ_EINVAL, "null engine");
+    if (n_rg) *n_rg = (uint64_t)e->p.n_rg;
+    if (n_cycle) *n_cycle = (uint64_t)e->p.max_read_len;
+    return KBBQ_OK;
+}
+
 int kbbq_engine_tune(kbbq_engine *e, const char *name, uint64_t value) {
     if (!e || !name) return fail(KBBQ_EINVAL, "null argument");
     if (!strcmp(name, "bucket_records")) {

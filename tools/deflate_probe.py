@@ -20,6 +20,11 @@ def main():
     mb = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     text = np.tile(np.frombuffer(fastq_text(mb * 1000000 // 330, np.random.default_rng(5)), dtype=np.uint8), reps)
+    if os.environ.get("KBBQ_PROBE_ZLIB"):      # the same text through zlib level 6 in BGZF-sized blocks (what bgzip / htslib write)
+        import zlib
+        one = text[:text.size // reps].tobytes()
+        z = sum(len(zlib.compress(one[i:i + 0xff00], 6)) - 6 + 26 for i in range(0, len(one), 0xff00))
+        print("zlib level 6, per 0xff00-byte block: %.0f MB for %.0f MB" % (z * reps / 1e6, text.size / 1e6), flush=True)
     w = bgzf.BgzfWriter(0)
     L = _lib.lib()
     have = hasattr(L, "kbbq_bgzf_debug_profile")
