@@ -114,7 +114,8 @@ def exchange_one_rank(e, xch, steps, device):
     n, piece = 8, (xch.slab_words // 8) & ~1
     recv = torch.randint(0, 2 ** 62, (n * piece,), dtype=torch.int64, device="cuda")
     mine = torch.zeros(piece, dtype=torch.int64, device="cuda")
-    peer = xch.peer
+    peer = getattr(xch, "peer", None) or EnginePeer(e)      # (LibExchange has no peer object: the library holds the engine)
+    out["exchange_by"] = "library (include/kbbq_exchange.h: RCCL from C++)" if not hasattr(xch, "peer") else "torch.distributed (kbbq_amd/dist.py)"
     with torch.cuda.stream(peer.torch_stream()):
         peer.or_pieces(mine, recv, piece, n, 3)
         e.sync()
@@ -497,6 +498,9 @@ def main():
                     help="diagnostic (N = 1): a one-rank RCCL group and every exchange step at full size -- all_to_all, OR "
                          "kernel and all_gather over the whole 6.3 + 10.4 GB of filters in 512 MB slabs, histogram sum, delta-Q "
                          "broadcast -- beside the record buffers of the bucketed inserts; adds an `exchange_one_rank` object")
+    ap.add_argument("--exchange", choices=("torch", "lib"), default=os.environ.get("KBBQ_EXCHANGE", "torch"),
+                    help="who runs the exchange steps: torch.distributed collectives + the engine's OR kernel (kbbq_amd/dist.py: Exchange, "
+                         "the default) or the library's own RCCL calls (include/kbbq_exchange.h through dist.py: LibExchange)")
     ap.add_argument("--ab-tune", default=None, metavar="KNOB[,ROUNDS]",
                     help="diagnostic (N = 1): A/B of one kbbq_engine_tune switch inside ONE process on the same resident reads -- "
                          "KNOB=0 / KNOB=1 alternated ROUNDS times (default 4), each an overlapped step (wall time) and an in-order "
@@ -568,8 +572,12 @@ def main():
             ordinals.append((a + s) * nk_per_read)
             mine.append(bool(emu) and emu_range[0] <= s < emu_range[1])
     out_buf = torch.empty(min(BATCH_READS, n_local) * READ_LEN + 16, dtype=torch.uint8, device="cuda")
-    xch = Exchange(EnginePeer(e), device=torch.device("cuda", local_rank) if backend == "nccl" else None,
-                   stage_host=backend != "nccl", force=args.force_exchange)
+    if args.exchange == "lib" and backend == "nccl":
+        from kbbq_amd.dist import LibExchange
+        xch = LibExchange(e, device=local_rank, force=args.force_exchange)
+    else:
+        xch = Exchange(EnginePeer(e), device=torch.device("cuda", local_rank) if backend == "nccl" else None,
+                       stage_host=backend != "nccl", force=args.force_exchange)
 
     def barrier():
         e.sync()

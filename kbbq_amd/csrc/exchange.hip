@@ -274,9 +274,9 @@ int kbbq_exchange_ms(const kbbq_group *g, double out[4]) {
 
 int kbbq_exchange_filter(kbbq_engine *e, int which, kbbq_group *g, uint64_t slab_words, uint64_t *inserted_total) {
     if (!e || !g || which < 0 || which > 1) return fail(KBBQ_EINVAL, "bad argument");
-    const double t0 = now_ms();
     int rc = kbbq_engine_sync(e);      // deferred inserts reach the filter, every kernel of the pass is through
     if (rc) return rc;
+    const double t0 = now_ms();        // (the step's own time: what the pass still had queued is the pass's)
     kbbq_filter_info info;
     if ((rc = kbbq_filter_info_get(e, which, &info))) return rc;
     uint64_t *table = (uint64_t *)kbbq_filter_device_table(e, which);
@@ -321,9 +321,9 @@ int kbbq_exchange_filter(kbbq_engine *e, int which, kbbq_group *g, uint64_t slab
 
 int kbbq_exchange_histograms(kbbq_engine *e, kbbq_group *g) {
     if (!e || !g) return fail(KBBQ_EINVAL, "bad argument");
-    const double t0 = now_ms();
     int rc = kbbq_engine_sync(e);
     if (rc) return rc;
+    const double t0 = now_ms();
     uint64_t n_words = 0;
     uint64_t *h = (uint64_t *)kbbq_covariates_device(e, &n_words);
     if (!h || !n_words) return fail(KBBQ_ESTATE, "the engine has no histograms");

@@ -217,6 +217,73 @@ class Exchange:
         return out
 
 
+class LibExchange:
+    """The same steps through the library's own exchange (include/kbbq_exchange.h, kbbq_amd/csrc/exchange.hip): RCCL called
+    directly from C++ on the engine's HIP stream -- grouped ncclSend/ncclRecv, the OR kernel, ncclAllGather per slab;
+    ncclAllReduce for counters and histograms; ncclBroadcast for the delta-Q tables.  This class only makes the group
+    (rank 0's ncclUniqueId travels through torch.distributed, whatever its backend) and calls the three entry points; a
+    C++ caller needs no Python at all.  Same interface as Exchange."""
+
+    def __init__(self, engine, group=None, slab_words=1 << 26, device=0, force=False):
+        import ctypes
+        from . import _lib
+        self.e = engine
+        self.L = _lib.lib()
+        self._lib = _lib
+        self.slab_words = slab_words
+        self.rank, self.n = world(group)
+        self.force = force
+        self.ms = {"filter0": 0.0, "filter1": 0.0, "histograms": 0.0, "broadcast": 0.0}
+        self.g = None
+        if self.n > 1 or force:
+            uid = np.zeros(128, dtype=np.uint8)
+            if self.rank == 0:
+                _lib.check(self.L.kbbq_group_rccl_unique_id(uid.ctypes.data))
+            if self.n > 1:
+                box = [uid.tobytes()]
+                dist.broadcast_object_list(box, src=0, group=group)      # (works on gloo and nccl alike)
+                uid = np.frombuffer(box[0], dtype=np.uint8).copy()
+            g = _lib.c_vp()
+            _lib.check(self.L.kbbq_group_rccl_create(uid.ctypes.data, self.rank, self.n, device, ctypes.byref(g)))
+            self.g = g
+        self._ctypes = ctypes
+
+    def close(self):
+        if self.g:
+            self.L.kbbq_group_destroy(self.g)
+            self.g = None
+
+    def reset_timers(self):
+        for k in self.ms:
+            self.ms[k] = 0.0
+
+    def _add_ms(self):
+        out = (self._ctypes.c_double * 4)()
+        self._lib.check(self.L.kbbq_exchange_ms(self.g, out))
+        return list(out)
+
+    def filter_done(self, which):
+        if not self.g:
+            return self.e.filter_info(which)["inserted"]
+        tot = self._ctypes.c_uint64()
+        self._lib.check(self.L.kbbq_exchange_filter(self.e.h, which, self.g, self.slab_words, self._ctypes.byref(tot)))
+        self.ms["filter%d" % which] += self._add_ms()[which]
+        return tot.value
+
+    def histograms_done(self):
+        if not self.g:
+            return
+        self._lib.check(self.L.kbbq_exchange_histograms(self.e.h, self.g))
+        self.ms["histograms"] += self._add_ms()[2]
+
+    def train_and_share(self):
+        if not self.g:
+            return self.e.get_dqs()
+        self._lib.check(self.L.kbbq_exchange_dq(self.e.h, self.g))
+        self.ms["broadcast"] += self._add_ms()[3]
+        return self.e.dq()
+
+
 class EnginePeer:
     """Adapter: a kbbq_amd.engine.Engine seen through the Exchange protocol."""
 

@@ -69,3 +69,21 @@ def test_bench_two_ranks_reproduce_one_rank():
     assert set(b["exchange_ms"]) == {"filter0", "filter1", "histograms", "broadcast"} and b["exchange_ms"]["filter1"] > 0
     for key in ("sampled_inserted", "trusted_inserted", "fpr", "recal_qual_sum"):
         assert a["result"][key] == b["result"][key], key
+
+
+def test_bench_exchange_in_the_library_gives_the_same_answer():
+    """bench.py --exchange lib --force-exchange: every exchange step of a step runs through the library's own RCCL calls
+    (include/kbbq_exchange.h; a group of one rank on this box) at the bench's launch sizes; counts, fpr and digest must be the
+    plain run's, and the line says who exchanged."""
+    common_args = ["--steps", "1", "--warmup", "0", "--genome-len", "30000000", "--no-cpu-baseline", "--no-pcie", "--no-exclusive-step"]
+    one = subprocess.run([sys.executable, "bench.py"] + common_args, cwd=common.ROOT, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    lib = subprocess.run([sys.executable, "bench.py", "--force-exchange", "--exchange", "lib"] + common_args, cwd=common.ROOT, capture_output=True, text=True,
+                         timeout=900)
+    assert lib.returncode == 0, lib.stderr[-3000:]
+    a = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    b = json.loads([ln for ln in lib.stdout.splitlines() if ln.startswith("{")][-1])
+    for key in ("sampled_inserted", "trusted_inserted", "fpr", "recal_qual_sum"):
+        assert a["result"][key] == b["result"][key], key
+    x = b["exchange_one_rank"]
+    assert x["exchange_by"].startswith("library") and all(v > 0 for v in x["exchange_ms_per_step"].values())
