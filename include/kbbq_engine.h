@@ -205,6 +205,10 @@ int kbbq_pack_bases_case(const uint8_t *seq, uint64_t n_bases, uint64_t *bases_o
  * device pointers (on_device=1).  Free with kbbq_reads_free. */
 int kbbq_reads_upload(kbbq_engine *e, const kbbq_reads *host, kbbq_reads *dev);
 int kbbq_reads_free(kbbq_engine *e, kbbq_reads *dev);
+/* A device batch copied onto `device` (arrays owned by the library; free with that device current, or through an engine
+ * of that device): a single-process multi-device caller gives every engine its shard this way.  with_hints != 0: with zeroed
+ * hint arrays (kbbq_reads_alloc_hints). */
+int kbbq_reads_clone(const kbbq_reads *src, int32_t device, int32_t with_hints, kbbq_reads *out);
 /* Page-locked host memory for batch arrays and outputs (hipHostMalloc): what makes the copies of host batches
  * true DMA at the link's rate.  kbbq_measure_host_link times one `bytes`-sized copy each way from such memory. */
 int kbbq_host_alloc(size_t bytes, void **out);

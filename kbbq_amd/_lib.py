@@ -167,6 +167,7 @@ SYMBOLS = {
                                                  ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "kbbq_fastq_reader_attach": (ctypes.c_int, [c_vp, ctypes.POINTER(Reads)]),
     "kbbq_fastq_reader_kernel_ms": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "kbbq_reads_clone": (ctypes.c_int, [ctypes.POINTER(Reads), ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(Reads)]),
     "kbbq_engine_dims": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "kbbq_group_rccl_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "kbbq_group_rccl_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(c_vp)]),

@@ -1229,6 +1229,48 @@ int kbbq_reads_upload(kbbq_engine *e, const kbbq_reads *host, kbbq_reads *dev) {
     return KBBQ_OK;
 }
 
+// A device batch copied to another device (or the same one): what a single-process multi-device caller hands the engines of
+// the other devices (their shards of a data set that was made resident on the first).  with_hints: zeroed hint arrays too.
+int kbbq_reads_clone(const kbbq_reads *src, int32_t device, int32_t with_hints, kbbq_reads *out) {
+    if (!src || !out || !src->on_device) return fail(KBBQ_EINVAL, "not a device batch");
+    DeviceGuard guard(device);
+    HIP_TRY(guard.err);
+    hipStream_t cs = shared_copy_stream(device);
+    if (!cs) return fail(KBBQ_EIO, "no copy stream for device %d", device);
+    *out = *src;
+    out->hint_sampled = nullptr; out->hint_trusted = nullptr;
+    out->bases = nullptr; out->nmask = nullptr; out->qual = nullptr; out->offsets = nullptr; out->flags = nullptr; out->rg = nullptr; out->offcase = nullptr;
+#define CL(field, type, count, pad)                                                               \
+    if (src->field) {                                                                             \
+        void *d = nullptr;                                                                        \
+        hipError_t he = hipMalloc(&d, ((count) + (pad)) * sizeof(type));                          \
+        if (he == hipSuccess) {                                                                   \
+            out->field = (const type *)d;                                                         \
+            if (pad) he = hipMemsetAsync((char *)d + (count) * sizeof(type), 0, (pad) * sizeof(type), cs); \
+        }                                                                                         \
+        if (he == hipSuccess) he = hipMemcpyAsync(d, src->field, (count) * sizeof(type), hipMemcpyDefault, cs); \
+        if (he != hipSuccess) {                                                                   \
+            hipStreamSynchronize(cs);                                                             \
+            kbbq_reads_free(nullptr, out);                                                        \
+            return fail(he == hipErrorOutOfMemory ? KBBQ_ENOMEM : KBBQ_EIO, "copy of %s: %s", #field, hipGetErrorString(he)); \
+        }                                                                                         \
+    }
+    CL(bases, uint64_t, src->n_bases / 32 + 1, 1)
+    CL(nmask, uint64_t, src->n_bases / 64 + 1, 1)
+    CL(qual, uint8_t, src->n_bases, 16)
+    CL(offsets, uint64_t, src->n_reads + 1, 0)
+    CL(flags, uint8_t, src->n_reads, 0)
+    CL(rg, uint16_t, src->n_reads, 0)
+    CL(offcase, uint64_t, src->n_bases / 64 + 1, 1)
+#undef CL
+    HIP_TRY(hipStreamSynchronize(cs));
+    if (with_hints) {
+        const int rc = kbbq_reads_alloc_hints(out);      // (on the current device: the guard's)
+        if (rc) { kbbq_reads_free(nullptr, out); return rc; }
+    }
+    return KBBQ_OK;
+}
+
 // ---- page-locked host memory for batches, and what the host link delivers
 int kbbq_host_alloc(size_t bytes, void **out) {
     if (!out || !bytes) return fail(KBBQ_EINVAL, "bad argument");

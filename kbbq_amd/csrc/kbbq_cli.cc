@@ -43,6 +43,7 @@
 #include <vector>
 
 #include "../../include/kbbq_bgzf.h"
+#include "../../include/kbbq_exchange.h"
 #include "../../include/kbbq_engine.h"
 #include "bam_io.h"
 #include "fastq_io.h"
@@ -1398,6 +1399,7 @@ int main(int argc, char *argv[]) {
 
     clock.mark("scan+pack+upload");
     kbbq_engine *e = nullptr;
+    bool multi_device_done = false;      // KBBQ_DEVICES: passes 1-3 and the model ran sharded over several devices
     if (resident.on)
         std::cerr << put_now << " Reads are resident on the GPU: " << resident.dev.size() << " batches"
                   << (resident.keep_recs ? ", their records in host memory." : ".") << std::endl;
@@ -1460,8 +1462,132 @@ int main(int argc, char *argv[]) {
         p.max_read_len = (int32_t)std::max<size_t>(1, longest);
         if (kbbq_engine_create(&p, &e) < 0) return fail_engine("cannot create the engine");
 
+        // KBBQ_DEVICES=0,1,...: the hot path -- passes 1-3 and the model -- sharded over several GPUs of the node inside this
+        // process (contiguous shards of the reads in file order, full filter replicas, three exchange steps
+        // and a broadcast: include/kbbq_exchange.h).  The reads were made resident on the first device by the scan; every
+        // other device gets a copy of its shard; one host thread per device runs the passes on its engine and meets the
+        // others in the exchanges -- over RCCL when the devices are distinct, through device-to-device copies when one device
+        // is listed several times (RCCL refuses that; KBBQ_EXCHANGE=local forces it).  The first device then holds the
+        // global model and writes the output exactly as a one-device run does: same bytes, whatever the list.
+        std::vector<int> devices;
+        if (const char *dl = getenv("KBBQ_DEVICES")) {
+            for (const char *q = dl; *q;) {
+                char *end = nullptr;
+                const long v = strtol(q, &end, 10);
+                if (end == q) break;
+                devices.push_back((int)v);
+                q = *end == ',' ? end + 1 : end;
+            }
+        }
+        if (devices.size() > 1 && (!resident.on || devices[0] != 0)) {
+            std::cerr << put_now << " KBBQ_DEVICES needs the reads resident on device 0 (the first entry): running on one device." << std::endl;
+            devices.clear();
+        }
+        if (devices.size() > 1) {
+            const int N = (int)devices.size();
+            const size_t nb = resident.dev.size();
+            // global k-mer ordinals of the batches (the sampler's draw stream is one, in file order), shards balanced by bases
+            std::vector<uint64_t> ordinal(nb + 1, 0), bases(nb + 1, 0);
+            for (size_t b = 0; b < nb; ++b) {
+                uint64_t nk = 0;
+                if (kbbq_count_kmer_positions(e, &resident.dev[b], &nk) < 0) return fail_engine("sampling");
+                ordinal[b + 1] = ordinal[b] + nk;
+                bases[b + 1] = bases[b] + resident.dev[b].n_bases;
+            }
+            std::vector<size_t> first(N + 1, nb);
+            first[0] = 0;
+            for (int d = 1; d < N; ++d) {
+                const uint64_t want = bases[nb] * (uint64_t)d / (uint64_t)N;
+                size_t b = first[d - 1];
+                while (b < nb && bases[b] < want) ++b;
+                first[d] = b;
+            }
+            std::vector<kbbq_engine *> eng(N, nullptr);
+            std::vector<std::vector<kbbq_reads>> shard(N);
+            std::vector<kbbq_group *> grp(N, nullptr);
+            eng[0] = e;
+            bool distinct = true;
+            for (int a = 0; a < N; ++a) for (int b = a + 1; b < N; ++b) if (devices[a] == devices[b]) distinct = false;
+            const bool use_rccl = distinct && !(getenv("KBBQ_EXCHANGE") && !strcmp(getenv("KBBQ_EXCHANGE"), "local"));
+            uint8_t uid[KBBQ_RCCL_ID_BYTES];
+            if (use_rccl) { if (kbbq_group_rccl_unique_id(uid) < 0) return fail_engine("RCCL"); }
+            else if (kbbq_group_local_create(N, grp.data()) < 0) return fail_engine("exchange group");
+            for (int d = 1; d < N; ++d) {
+                kbbq_params pd = p;
+                pd.device = devices[d];
+                if (kbbq_engine_create(&pd, &eng[d]) < 0) return fail_engine("cannot create an engine");
+                for (size_t b = first[d]; b < first[d + 1]; ++b) {
+                    kbbq_reads c;
+                    if (kbbq_reads_clone(&resident.dev[b], devices[d], 1, &c) < 0) return fail_engine("copying a shard");
+                    shard[d].push_back(c);
+                }
+            }
+            for (size_t b = first[0]; b < first[1]; ++b) shard[0].push_back(resident.dev[b]);      // (views: owned by `resident`)
+            std::cerr << put_now << " Passes 1-3 on " << N << " devices (" << (use_rccl ? "RCCL" : "in-process copies") << "): shards of";
+            for (int d = 0; d < N; ++d) std::cerr << " " << first[d + 1] - first[d];
+            std::cerr << " batches." << std::endl;
+            char alpha_text[64];
+            snprintf(alpha_text, sizeof alpha_text, "%.25Le", alpha);
+            std::atomic<int> gate_seen(0);
+            // one rank: returns 0, or exits the process on an error (a rank that fails must not leave the others in a collective)
+            auto die = [&](const char *what) { std::cerr << put_now << " Error " << what << ": " << kbbq_last_error() << std::endl; _exit(1); };
+            auto rank_body = [&](int d) {
+                kbbq_engine *ed = eng[d];
+                if (use_rccl && kbbq_group_rccl_create(uid, d, N, devices[d], &grp[d]) < 0) die("joining the RCCL group");
+                for (size_t i = 0; i < shard[d].size(); ++i)
+                    if (kbbq_sample_batch(ed, &shard[d][i], ordinal[first[d] + i]) < 0) die("sampling");
+                uint64_t inserted = 0, total = 0;
+                if (kbbq_sample_finish(ed, &inserted) < 0 || kbbq_exchange_filter(ed, 0, grp[d], 0, &total) < 0) die("sampling");
+                if (d == 0) std::cerr << put_now << " Sampled " << total << " valid kmers." << std::endl;
+                // every rank computes the same thresholds from the same (global) filter and count (kbbq.cc:304-331)
+                char p_text[64];
+                std::vector<int32_t> thresholds(k + 1);
+                double fprd = 0;
+                const int gate = kbbq_compute_thresholds(ed, alpha_text, thresholds.data(), &fprd, p_text, sizeof p_text);
+                if (gate < 0) die("thresholds");
+                if (d == 0) {
+                    const long double fpr = fprd;
+                    std::cerr << put_now << " Approximate false positive rate: " << fpr << std::endl;
+                    if (gate != 1) {
+                        const long double p_hit = strtold(p_text, nullptr);
+                        std::cerr << put_now << " log CDF: [ ";
+                        for (long double c : log_binom_cdf_values((unsigned long long)k, p_hit)) std::cerr << c << " ";
+                        std::cerr << "]" << std::endl;
+                    }
+                }
+                if (gate == 1) { gate_seen = 1; return; }      // (every rank sees the same gate)
+                if (d == 0) { clock.mark("pass1"); std::cerr << put_now << " Finding trusted kmers" << std::endl; }
+                for (auto &b : shard[d])
+                    if (kbbq_trusted_batch(ed, &b, nullptr) < 0) die("finding trusted kmers");
+                uint64_t trusted_inserted = 0;
+                if (kbbq_trusted_finish(ed, nullptr) < 0 || kbbq_exchange_filter(ed, 1, grp[d], 0, &trusted_inserted) < 0) die("finding trusted kmers");
+                if (d == 0 && getenv("KBBQ_QUAL_DIGEST") && atoi(getenv("KBBQ_QUAL_DIGEST"))) std::cerr << "[digest] trusted_inserted " << trusted_inserted << std::endl;
+                if (d == 0) { clock.mark("pass2"); std::cerr << put_now << " Finding errors" << std::endl; }
+                for (auto &b : shard[d])
+                    if (kbbq_errors_batch(ed, &b, nullptr) < 0) die("finding errors");
+                if (kbbq_exchange_histograms(ed, grp[d]) < 0) die("summing the histograms");
+                if (d == 0) { clock.mark("pass3"); std::cerr << put_now << " Training model" << std::endl; }
+                if (kbbq_exchange_dq(ed, grp[d]) < 0) die("training");      // rank 0 trains, the tables are broadcast
+            };
+            std::vector<std::thread> ranks;
+            for (int d = 1; d < N; ++d) ranks.emplace_back(rank_body, d);
+            rank_body(0);
+            for (auto &t : ranks) t.join();
+            for (int d = 0; d < N; ++d) if (grp[d]) kbbq_group_destroy(grp[d]);
+            for (int d = 1; d < N; ++d) {
+                for (auto &c : shard[d]) { kbbq_reads_free_hints(&c); kbbq_reads_free(eng[d], &c); }
+                kbbq_engine_destroy(eng[d]);
+            }
+            if (gate_seen) {
+                std::cerr << put_now << " Error: false positive rate is too high. "
+                          << "Increase genomelen parameter and try again." << std::endl;
+                return 1;
+            }
+            multi_device_done = true;
+        }
+
         // pass 1, kbbq.cc:277-283
-        {
+        if (!multi_device_done) {
             uint64_t ordinal = 0, nk = 0;
             if (resident.on) {
                 for (auto &d : resident.dev) {
@@ -1485,6 +1611,7 @@ int main(int argc, char *argv[]) {
             if (kbbq_sample_finish(e, &inserted) < 0) return fail_engine("sampling");
             std::cerr << put_now << " Sampled " << inserted << " valid kmers." << std::endl;
         }
+        if (!multi_device_done) {
         // kbbq.cc:304-331
         char alpha_text[64], p_text[64];
         snprintf(alpha_text, sizeof alpha_text, "%.25Le", alpha);
@@ -1537,6 +1664,7 @@ int main(int argc, char *argv[]) {
                 if (batch.fatal) return 1;
             }
         }
+        }      // (!multi_device_done)
     } else {
         // --fixed, kbbq.cc:367-378: errors = bases that differ from the corrected file
         std::cerr << put_now << " Using fixed file to find errors." << std::endl;
@@ -1573,9 +1701,11 @@ int main(int argc, char *argv[]) {
     }
 
     // kbbq.cc:405-407
-    clock.mark("pass3");
-    std::cerr << put_now << " Training model" << std::endl;
-    if (kbbq_train(e) < 0) return fail_engine("training");
+    if (!multi_device_done) {
+        clock.mark("pass3");
+        std::cerr << put_now << " Training model" << std::endl;
+        if (kbbq_train(e) < 0) return fail_engine("training");
+    }
 
     // pass 4, kbbq.cc:455-457: recalibrate_and_write(file, dqs, "-")
     clock.mark("model");

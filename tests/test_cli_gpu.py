@@ -506,3 +506,34 @@ def test_cli_bam_shapes_the_device_path_hands_back(tmp_path):
         bamutil.record(r["name"], r["flag"], r["seq"], r["qual"], r["tags"]) for r in recs3)))
     rc, out, err = run_cli([p3], {"KBBQ_SEED": "5"})
     assert rc != 0 and "Unable to read RG tag on read " + recs3[31]["name"] in err
+
+
+@pytest.mark.parametrize("fmt", ["fastq_rg_names", "bam"])
+def test_cli_on_several_devices_writes_the_same_bytes(tmp_path, fmt):
+    """KBBQ_DEVICES: passes 1-3 and the model sharded over several engines of one process (contiguous shards, global k-mer
+    ordinals, the library's exchange steps between the passes: include/kbbq_exchange.h), output by the first device.  The
+    list names the box's one GPU two and three times -- engines that meet through device-to-device copies, since RCCL
+    refuses two ranks on one device -- and a list of one runs as before.  Every variant must write the one-device bytes and
+    log the same counts."""
+    if fmt == "bam":
+        d, recs, path, n_rg = bam_dataset(tmp_path, rg_header=True, seed=515, genome_len=40000, coverage=24, n_per_million=2000, ragged=True, extra_errors=80)
+        args = ["--set-oq", path]
+    else:
+        d, names, n_rg = named_dataset(seed=516, genome_len=40000, coverage=24, n_per_million=2000, ragged=True, extra_errors=80)
+        path = tmp_path / "in.fq.gz"
+        write_fastq(path, d, names, ["" for _ in names])
+        args = ["-g", d["genome_len"], path]
+    env = {"KBBQ_SEED": "99", "KBBQ_BATCH_READS": "700", "KBBQ_READER_PIECE_KB": "64", "KBBQ_QUAL_DIGEST": "1"}
+    rc, want, err1 = run_cli(args, env)
+    assert rc == 0, err1
+    assert "Passes 1-3 on" not in err1
+
+    def counts(err):
+        return [ln.split("] ", 1)[-1] for ln in err.splitlines() if "Sampled " in ln or "trusted_inserted" in ln or "false positive rate" in ln]
+    for devs in ("0,0", "0,0,0", "0"):
+        rc, out, err = run_cli(args, dict(env, KBBQ_DEVICES=devs))
+        assert rc == 0, err
+        n = len(devs.split(","))
+        assert ("Passes 1-3 on %d devices (in-process copies)" % n in err) == (n > 1), err[-1500:]
+        assert out == want, devs
+        assert counts(err) == counts(err1), (counts(err), counts(err1))
