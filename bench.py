@@ -718,7 +718,7 @@ def main():
         # is the committed rocprofv3 --pmc summary of this same command at the same launch size
         traffic, traffic_note = None, "no PMC summary for this launch size"
         try:
-            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_latest.json")))
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_pmc_latest.json")))
             k = pmc["kernels"].get(dom)
             launches_per_step = kernels[dom]["launches"] // args.steps
             full_launches = (n_local // BATCH_READS) >= 1 and READ_LEN == 150 and BATCH_READS == 1 << 22
