@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/cli_profile.sh TAG GENOME_LEN CASE -- rocprofv3 --kernel-trace --stats of ONE command-line run on the bench's own reads
-# as a file (tools/r04_e2e.sh's cases: fastq, bam, bam_setoq, bamoq_useoq_setoq), output to /dev/null:
+# as a file (tools/e2e.sh's cases: fastq, bam, bam_setoq, bamoq_useoq_setoq), output to /dev/null:
 # gpurun_out/cli_kernel_stats_TAG.csv, and the same run without the profiler for its phase split.
 set -o pipefail
 tag=$1; G=${2:-100000000}; c=${3:-bam_setoq}

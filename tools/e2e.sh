@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/r04_e2e.sh TAG GENOME_LEN "CASES" [DIR] -- the command line end to end on the bench's OWN reads as files
+# tools/e2e.sh TAG GENOME_LEN "CASES" [DIR] -- the command line end to end on the bench's OWN reads as files
 # (kbbq --io-test synth-fastq / synth-bam: k_synth -> record text / BAM records -> k_deflate on the device), 30x of
 # GENOME_LEN, sampler seed 777 as in bench.py: per-phase split (KBBQ_TIMING=1), the insert counts of the log, the digest of
 # the recalibrated qualities taken on the device (KBBQ_QUAL_DIGEST=1) -- to be compared with bench.py's
