@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(256) k_bam_records(const uint8_t *text, uint64
         const uint64_t v = rg_at + 1;
         for (uint32_t i = 0; i < T.n_ids && rg == 0xFFFF; ++i) {
             const uint32_t o = T.id_off[i], len = T.id_off[i + 1] - o;
-            bool same = text[v + len] == 0;
+            bool same = v + len < end && text[v + len] == 0;      // (the value's NUL lies inside the record)
             for (uint32_t j = 0; j < len && same; ++j) same = text[v + j] == T.ids[o + j];
             if (same) rg = i;
         }

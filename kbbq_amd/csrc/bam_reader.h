@@ -25,7 +25,7 @@ struct kbbq_bam_reader {
     uint64_t carry_bytes = 0;
     // the current chunk
     uint64_t text_bytes = 0, n_records = 0, n_bases = 0, idx_cap = 0;
-    uint32_t longest = 0, shortest = 0;
+    uint32_t longest = 0, shortest = 0, chunk_flags = 0;
     bool have_chunk = false;
     double ms_inflate = 0, ms_index = 0, ms_rewrite = 0;
     // chunks of the first scan kept for pass 4: the COMPRESSED bytes (a third of the stream) with their block table and the
@@ -265,6 +265,7 @@ int bam_index_stream(kbbq_bam_reader *r, uint64_t text, uint64_t skip, int32_t l
     r->carry_bytes = left;
     r->text_bytes = text;
     r->have_chunk = true;
+    r->chunk_flags = info->flags;
     info->n_records = r->n_records;
     info->n_bases = r->n_bases;
     info->longest = r->n_records ? r->longest : 0;
@@ -473,6 +474,7 @@ int kbbq_bam_reader_select(kbbq_bam_reader *r, uint64_t i, kbbq_bam_chunk *info)
 int kbbq_bam_reader_batch(kbbq_bam_reader *r, kbbq_reads *dev) {
     if (!r || !dev) return fail(KBBQ_EINVAL, "null argument");
     if (!r->have_chunk || !r->n_records) return fail(KBBQ_ESTATE, "no records in the current chunk");
+    if (r->chunk_flags & BAMF_FALLBACK) return fail(KBBQ_ESTATE, "the chunk holds a shape this reader does not take (flags %u): the host parser's", r->chunk_flags);
     KbbqDeviceGuard guard(r->device);
     HIP_TRY(guard.err);
     const uint64_t n = r->n_records, nbases = r->n_bases;
@@ -527,6 +529,8 @@ int kbbq_bam_reader_write(kbbq_bam_reader *r, kbbq_bgzf *z, const uint8_t *d_qua
     if (!r || !z || !d_qual) return fail(KBBQ_EINVAL, "null argument");
     if (!r->have_chunk || !r->n_records) return fail(KBBQ_ESTATE, "no records in the current chunk");
     if (r->device != z->device) return fail(KBBQ_EINVAL, "reader and writer are on different devices");
+    if (r->chunk_flags & BAMF_FALLBACK) return fail(KBBQ_ESTATE, "the chunk holds a shape this reader does not take (flags %u)", r->chunk_flags);
+    if (set_oq && (r->chunk_flags & BAMF_OQ_UNWRITABLE)) return fail(KBBQ_EINVAL, "Tag data is corrupt: a record's OQ tag cannot be updated");
     KbbqDeviceGuard guard(z->device);
     HIP_TRY(guard.err);
     const uint64_t n = r->n_records;

@@ -65,7 +65,14 @@ def make_records(n, seed, lens=None, oq_every=3, big_quals=True):
             tags.insert(int(rng.randint(0, len(tags) + 1)), ("OQ", "Z", oq))
         if r % 4 == 0:
             tags.append(("XT", "i", -5))
-        recs.append(dict(name="read%d" % r if r % 9 else "r", flag=flag, seq=seq, qual=qual, tags=tags))
+        rec = dict(name="read%d" % r if r % 9 else "r", flag=flag, seq=seq, qual=qual, tags=tags)
+        if r % 3 == 1:      # an aligned record: reference, position, one to four CIGAR operations (op | len << 4), a mate, extra flag bits
+            n_ops = int(rng.randint(1, 5))
+            rec["aln"] = (int(rng.randint(0, 2)), int(rng.randint(0, 900)), int(rng.randint(0, 61)),
+                          [(int(rng.randint(1, 200)) << 4) | int(rng.choice([0, 1, 2, 4])) for _ in range(n_ops)],
+                          int(rng.randint(-1, 2)), int(rng.randint(-1, 900)), int(rng.randint(-500, 500)))
+            rec["flag"] = (flag & ~4) | int(rng.choice([0, 0x100, 0x800, 0x400, 2]))
+        recs.append(rec)
     return recs
 
 
@@ -74,8 +81,12 @@ def record_bytes(r):
     packed = bytearray((l + 1) // 2)
     for i, ch in enumerate(r["seq"]):
         packed[i >> 1] |= bamutil.CODES[ch] << (4 if i % 2 == 0 else 0)
-    body = struct.pack("<iiBBHHHIiii", -1, -1, len(r["name"]) + 1, 0, 4680, 0, r["flag"], l, -1, -1, 0)
-    body += r["name"].encode() + b"\0" + bytes(packed) + bytes(bytearray(int(q) for q in r["qual"])) + aux_raw(r["tags"])
+    # aligned records carry a reference, a position, CIGAR operations and a mate (r["aln"] = (refID, pos, mapq, cigar words,
+    # next refID, next pos, tlen)); the others are unaligned
+    ref, pos, mapq, cigar, nref, npos, tlen = r.get("aln", (-1, -1, 0, [], -1, -1, 0))
+    body = struct.pack("<iiBBHHHIiii", ref, pos, len(r["name"]) + 1, mapq, 4680, len(cigar), r["flag"], l, nref, npos, tlen)
+    body += r["name"].encode() + b"\0" + b"".join(struct.pack("<I", c) for c in cigar) + bytes(packed)
+    body += bytes(bytearray(int(q) for q in r["qual"])) + aux_raw(r["tags"])
     return struct.pack("<I", len(body)) + body
 
 
@@ -255,6 +266,37 @@ def test_rewritten_records_equal_the_reference_rules(use_oq, set_oq):
         assert b"".join(bgzf_blocks(blob)) == rewritten(recs[at_rec:at_rec + n], newq[at_base:at_base + nb], set_oq)
         at_rec += n
         at_base += nb
+    reader.close()
+    writer.close()
+
+
+def test_a_flagged_chunk_gives_no_batch_and_no_output():
+    """kbbq_bam_reader_batch / _write refuse a chunk whose flags say "host parser": no caller can get a wrong batch by
+    ignoring them; and --set-oq is refused where bam_aux_update_str would fail."""
+    import torch
+    base = make_records(30, seed=19, oq_every=0)
+    head = bamutil.header(HEADER_TEXT, [("chr1", 1000), ("c2", 5)])
+    bad = [dict(r) for r in base]
+    bad[4] = dict(bad[4], tags=[t for t in bad[4]["tags"] if t[0] != "RG"])
+    reader = bgzf.BamReader(len(head), 2, RG_IDS)
+    info = reader.chunk(bamutil.bgzf_compress(head + b"".join(record_bytes(r) for r in bad)), True)
+    assert info["flags"] & 1
+    with pytest.raises(_lib.KbbqError):
+        reader.batch()
+    reader.close()
+    odd = [dict(r) for r in base]
+    odd[4] = dict(odd[4], tags=odd[4]["tags"] + [("OQ", "A", "x")])
+    reader = bgzf.BamReader(len(head), 2, RG_IDS)
+    writer = bgzf.BgzfWriter()
+    info = reader.chunk(bamutil.bgzf_compress(head + b"".join(record_bytes(r) for r in odd)), True)
+    assert info["flags"] == 8
+    dq = torch.zeros(info["n_bases"] + 16, dtype=torch.uint8, device="cuda")
+    with pytest.raises(_lib.KbbqError):
+        reader.write(writer, dq.data_ptr(), set_oq=True)
+    reader.write(writer, dq.data_ptr(), set_oq=False)              # without --set-oq the tag is not touched
+    blob, n_payload = writer.collect()
+    newq = np.zeros(info["n_bases"], dtype=np.uint8)
+    assert b"".join(bgzf_blocks(blob)) == rewritten(odd, newq, False)
     reader.close()
     writer.close()
 
