@@ -105,6 +105,12 @@ int kbbq_fastq_reader_attach(kbbq_fastq_reader *r, const kbbq_reads *batch);
  * Every block's CRC-32 and ISIZE are checked as bgzf_read checks them; a block that does not inflate to them is
  * KBBQ_EIO ("CRC32 checksum mismatch" / "does not inflate"). */
 int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uint64_t n_bytes, int32_t last, kbbq_fastq_chunk *info);
+/* Optional: start copying a piece of the file to the device AHEAD of the kbbq_fastq_reader_chunk call that will take it --
+ * from the caller's I/O thread, the moment the piece has been read (page-locked memory) -- so that the host link moves piece
+ * i + 1 while the kernels of piece i run.  The chunk call recognises the piece by its address: file_bytes of that call may
+ * start up to front_room bytes BEFORE these bytes (what the call before left unconsumed, put in front by the caller) and must
+ * end where they end.  The memory must stay as it is until that chunk call has returned.  Two pieces may be ahead. */
+int kbbq_fastq_reader_preload(kbbq_fastq_reader *r, const uint8_t *file_bytes, uint64_t n_bytes, uint64_t front_room);
 /* kbbq_reads_upload (kbbq_engine.h) for a batch whose bases are still text: host's bases / nmask / offcase are ignored,
  * seq_text holds its n_bases sequence characters and is packed on the device (kbbq_pack_bases_case's table).  e may be
  * NULL like there. */
@@ -158,6 +164,7 @@ int kbbq_bam_reader_keep(kbbq_bam_reader *r, int32_t on);
 int kbbq_bam_reader_kept(kbbq_bam_reader *r, uint64_t *n_chunks, uint64_t *n_bytes);
 int kbbq_bam_reader_select(kbbq_bam_reader *r, uint64_t i, kbbq_bam_chunk *info);
 int kbbq_bam_reader_chunk(kbbq_bam_reader *r, const uint8_t *file_bytes, uint64_t n_bytes, int32_t last, kbbq_bam_chunk *info);
+int kbbq_bam_reader_preload(kbbq_bam_reader *r, const uint8_t *file_bytes, uint64_t n_bytes, uint64_t front_room);   /* as kbbq_fastq_reader_preload */
 /* The read groups met so far in dense-index order: table_index[d] = index into rg_ids of the group with dense index d. */
 int kbbq_bam_reader_read_groups(kbbq_bam_reader *r, uint32_t *table_index, uint32_t capacity, uint32_t *n);
 /* The current chunk's records as a device batch (arrays owned by the library: kbbq_reads_free), rg = dense indices. */

@@ -182,6 +182,8 @@ SYMBOLS = {
     "kbbq_digest_add": (ctypes.c_int, [c_vp, c_vp, ctypes.c_uint64]),
     "kbbq_digest_get": (ctypes.c_int, [c_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int32]),
     "kbbq_bgzf_submit_synth": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint64)]),
+    "kbbq_fastq_reader_preload": (ctypes.c_int, [c_vp, c_vp, c_u64, c_u64]),
+    "kbbq_bam_reader_preload": (ctypes.c_int, [c_vp, c_vp, c_u64, c_u64]),
     "kbbq_bam_reader_create": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_char_p),
                                               ctypes.c_uint32, ctypes.POINTER(c_vp)]),
     "kbbq_bam_reader_destroy": (None, [c_vp]),

@@ -4,6 +4,7 @@
 #pragma once
 
 struct kbbq_bam_reader {
+    Preload pre;                            // pieces of the file copied ahead of their chunk call (kbbq_bam_reader_preload)
     int device = 0;
     hipStream_t st = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr, t2 = nullptr;
@@ -288,6 +289,7 @@ void kbbq_bam_reader_destroy(kbbq_bam_reader *r) {
                   &r->seg_counts, &r->idx_u32, &r->idx_u16, &r->idx_u64, &r->d_out, &r->rg_ids, &r->rg_off, &r->first_seen, &r->dense, &r->seq_text,
                   &r->counter};
     for (Buf *b : all) b->release();
+    r->pre.release();
     bam_release_kept(r);
     hipEvent_t evs[] = {r->t0, r->t1, r->t2};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
@@ -401,13 +403,17 @@ int kbbq_bam_reader_chunk(kbbq_bam_reader *r, const uint8_t *file_bytes, uint64_
         }
         return rc2;
     };
-    if ((rc = reserve_or_drop(r->comp, at + 4096))) return rc;
+    void *d_comp = r->pre.take(file_bytes, n_bytes, r->st);      // copied ahead by the caller's I/O thread?
+    if (!d_comp && (rc = reserve_or_drop(r->comp, at + 4096))) return rc;
     if ((rc = reserve_or_drop(r->text, text + 4096))) return rc;
     const uint64_t carry_in = r->carry_bytes;
     if (carry_in) HIP_TRY(hipMemcpyAsync(r->text.p, r->carry.p, carry_in, hipMemcpyDeviceToDevice, r->st));
-    if (at) {
-        HIP_TRY(hipMemcpyAsync(r->comp.p, file_bytes, at, hipMemcpyHostToDevice, r->st));
-        HIP_TRY(hipMemsetAsync((char *)r->comp.p + at, 0, 4096, r->st));
+    if (!d_comp) {
+        d_comp = r->comp.p;
+        if (at) {
+            HIP_TRY(hipMemcpyAsync(d_comp, file_bytes, at, hipMemcpyHostToDevice, r->st));
+            HIP_TRY(hipMemsetAsync((char *)d_comp + at, 0, 4096, r->st));
+        }
     }
     // the header's bytes come first in the stream; a header longer than this chunk's stream is not this path's case
     uint64_t skip = 0;
@@ -427,11 +433,12 @@ int kbbq_bam_reader_chunk(kbbq_bam_reader *r, const uint8_t *file_bytes, uint64_
             r->keeping = false;
             keep_this = false;
         } else {
-            HIP_TRY(hipMemcpyAsync(k.comp.p, r->comp.p, at + 4096, hipMemcpyDeviceToDevice, r->st));
+            HIP_TRY(hipMemcpyAsync(k.comp.p, d_comp, at, hipMemcpyDeviceToDevice, r->st));
+            HIP_TRY(hipMemsetAsync((char *)k.comp.p + at, 0, 4096, r->st));
             if (carry_in) HIP_TRY(hipMemcpyAsync(k.carry.p, r->carry.p, carry_in, hipMemcpyDeviceToDevice, r->st));
         }
     }
-    if ((rc = bam_inflate(r, r->comp.p, c_off, o_off, c_len, o_len, text))) { k.comp.release(); k.carry.release(); return rc; }
+    if ((rc = bam_inflate(r, d_comp, c_off, o_off, c_len, o_len, text))) { k.comp.release(); k.carry.release(); return rc; }
     info->text_bytes = text - carry_in;
     rc = bam_index_stream(r, text, skip, last, true, info);
     if (rc) { k.comp.release(); k.carry.release(); return rc; }
@@ -590,6 +597,13 @@ int kbbq_bgzf_submit_synth(kbbq_bgzf *z, kbbq_engine *e, const kbbq_synth_params
     HIP_TRY(hipEventSynchronize(s.t1));      // the batch is freed on return: the formatting kernel must be through with it
     if (payload_bytes) *payload_bytes = t;
     return KBBQ_OK;
+}
+
+int kbbq_bam_reader_preload(kbbq_bam_reader *r, const uint8_t *file_bytes, uint64_t n_bytes, uint64_t front_room) {
+    if (!r || !file_bytes || !n_bytes) return fail(KBBQ_EINVAL, "bad argument");
+    KbbqDeviceGuard guard(r->device);
+    HIP_TRY(guard.err);
+    return r->pre.start(r->device, file_bytes, n_bytes, front_room);
 }
 
 int kbbq_bam_reader_kernel_ms(kbbq_bam_reader *r, double *inflate_ms, double *index_ms) {

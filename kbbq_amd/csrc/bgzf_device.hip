@@ -324,7 +324,61 @@ int kbbq_bgzf_kernel_ms(kbbq_bgzf *z, double *format_ms, double *deflate_ms, dou
 
 // ============================================================ the input side: BGZF FASTQ read on the device
 
+// A piece of the file copied to the device AHEAD of the chunk call that will take it (kbbq_*_reader_preload): the caller's I/O
+// thread starts the copy the moment a piece has been read, on a copy stream of the reader's own, so the host link moves piece
+// i + 1 while the kernels of piece i run -- without it a chunk's 256 MB cross the link in front of its own inflation, 1.1 s
+// of a 30x run.  Two slots; a slot holds the host range [host, host + n) at dev + front: the bytes a chunk call carries over
+// from the piece before (less than a BGZF block) go in front of them.
+struct Preload {
+    hipStream_t copy = nullptr;
+    Buf dev[2];
+    hipEvent_t done[2] = {nullptr, nullptr};
+    const uint8_t *host[2] = {nullptr, nullptr};
+    uint64_t n[2] = {0, 0};
+    uint64_t front = 0;
+    int next = 0;
+    int start(int device, const uint8_t *bytes, uint64_t n_bytes, uint64_t front_room) {
+        if (!copy) {
+            HIP_TRY(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        }
+        const int i = next;
+        next ^= 1;
+        host[i] = nullptr;
+        front = front_room;
+        int rc = dev[i].reserve(front_room + n_bytes + 4096);
+        if (rc) { (void)hipGetLastError(); return KBBQ_OK; }      // no room: the chunk call copies as before
+        HIP_TRY(hipMemcpyAsync((char *)dev[i].p + front_room, bytes, n_bytes, hipMemcpyHostToDevice, copy));
+        HIP_TRY(hipMemsetAsync((char *)dev[i].p + front_room + n_bytes, 0, 4096, copy));
+        HIP_TRY(hipEventRecord(done[i], copy));
+        host[i] = bytes;
+        n[i] = n_bytes;
+        return KBBQ_OK;
+    }
+    // the device address of file_bytes[0, n_bytes) if it ends a preloaded piece and starts at most `front` bytes before it
+    // (those first bytes are copied here, on st); st then waits for the piece's copy.  nullptr: not preloaded.
+    void *take(const uint8_t *file_bytes, uint64_t n_bytes, hipStream_t st) {
+        for (int i = 0; i < 2; ++i) {
+            if (!host[i] || file_bytes > host[i] || file_bytes + n_bytes != host[i] + n[i]) continue;
+            const uint64_t prefix = (uint64_t)(host[i] - file_bytes);
+            if (prefix > front) continue;
+            char *at = (char *)dev[i].p + front - prefix;
+            if (prefix && hipMemcpyAsync(at, file_bytes, prefix, hipMemcpyHostToDevice, st) != hipSuccess) return nullptr;
+            if (hipStreamWaitEvent(st, done[i], 0) != hipSuccess) return nullptr;
+            host[i] = nullptr;      // (the slot is written again only by a later preload: the caller's buffer protocol orders that)
+            return at;
+        }
+        return nullptr;
+    }
+    void release() {
+        for (int i = 0; i < 2; ++i) { dev[i].release(); if (done[i]) (void)hipEventDestroy(done[i]); done[i] = nullptr; host[i] = nullptr; }
+        if (copy) (void)hipStreamDestroy(copy);
+        copy = nullptr;
+    }
+};
+
 struct kbbq_fastq_reader {
+    Preload pre;
     int device = 0;
     hipStream_t st = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr, t2 = nullptr;
@@ -501,6 +555,7 @@ void kbbq_fastq_reader_destroy(kbbq_fastq_reader *r) {
     Buf *all[] = {&r->comp, &r->text, &r->status, &r->blk_meta, &r->h_meta, &r->tile_counts, &r->tile_sums, &r->nl_pos, &r->idx_u32,
                   &r->idx_second, &r->base_sz, &r->text_sz, &r->flags, &r->carry, &r->h_small, &r->seq_text, &r->counter};
     for (Buf *b : all) b->release();
+    r->pre.release();
     release_kept(r);
     hipEvent_t evs[] = {r->t0, r->t1, r->t2};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
@@ -623,7 +678,8 @@ int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uin
         return rc2;
     };
     // ---- compressed bytes and block table to the device, inflate
-    if ((rc = r->comp.reserve(at + 4096))) return rc;
+    void *d_comp = r->pre.take(file_bytes, n_bytes, r->st);      // copied ahead by the caller's I/O thread?
+    if (!d_comp && (rc = r->comp.reserve(at + 4096))) return rc;
     if ((rc = reserve_or_drop(r->text, text + 4096))) return rc;
     if ((rc = r->status.reserve((size_t)nb * 4 + 64))) return rc;
     const size_t meta_bytes = (size_t)nb * 24 + 64;
@@ -639,14 +695,17 @@ int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uin
     }
     if (r->carry_bytes) HIP_TRY(hipMemcpyAsync(r->text.p, r->carry.p, r->carry_bytes, hipMemcpyDeviceToDevice, r->st));
     if (nb) {
-        HIP_TRY(hipMemcpyAsync(r->comp.p, file_bytes, at, hipMemcpyHostToDevice, r->st));
-        HIP_TRY(hipMemsetAsync((char *)r->comp.p + at, 0, 4096, r->st));
+        if (!d_comp) {
+            d_comp = r->comp.p;
+            HIP_TRY(hipMemcpyAsync(d_comp, file_bytes, at, hipMemcpyHostToDevice, r->st));
+            HIP_TRY(hipMemsetAsync((char *)d_comp + at, 0, 4096, r->st));
+        }
         HIP_TRY(hipMemcpyAsync(r->blk_meta.p, hm, (size_t)nb * 24, hipMemcpyHostToDevice, r->st));
     }
     HIP_TRY(hipEventRecord(r->t0, r->st));      // (the kernel alone: the upload of the compressed bytes is not in its time)
     if (nb) {
         InflateArgs A;
-        A.comp = (const uint8_t *)r->comp.p;
+        A.comp = (const uint8_t *)d_comp;
         A.c_off = (const uint64_t *)r->blk_meta.p;
         A.o_off = A.c_off + nb;
         A.c_len = (const uint32_t *)(A.c_off + 2 * (size_t)nb);
@@ -862,14 +921,16 @@ int kbbq_fastq_reader_batch(kbbq_fastq_reader *r, kbbq_reads *dev) {
     void *b = nullptr, *m = nullptr, *q = nullptr, *oc = nullptr, *off = nullptr, *fl = nullptr;
     auto release = [&]() { void *all[] = {b, m, q, oc, off, fl}; for (void *x : all) (void)hipFree(x); };
     int rc0;
-    if ((rc0 = r->seq_text.reserve(nbases + 64))) return rc0;
-    if ((rc0 = r->counter.reserve(64))) return rc0;
-    void *seq_text = r->seq_text.p, *cnt = r->counter.p;
-#define RB_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { release(); return fail(_e == hipErrorOutOfMemory ? KBBQ_ENOMEM : KBBQ_EIO, "%s: %s", #expr, hipGetErrorString(_e)); } } while (0)
     const uint64_t words = nbases / 64 + 1;
+    if ((rc0 = r->seq_text.reserve(nbases + 64))) return rc0;
+    // [0..1] the two counts of k_pack_text, behind them the off-case words: nearly every chunk has none, and an array
+    // allocated and freed again per chunk was a hipMalloc (which clears) and a hipFree (which waits for the device) for nothing
+    if ((rc0 = r->counter.reserve((words + 4) * 8 + 64))) return rc0;
+    void *seq_text = r->seq_text.p, *cnt = r->counter.p;
+    void *oc_scratch = (char *)r->counter.p + 16;
+#define RB_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { release(); return fail(_e == hipErrorOutOfMemory ? KBBQ_ENOMEM : KBBQ_EIO, "%s: %s", #expr, hipGetErrorString(_e)); } } while (0)
     RB_TRY(hipMalloc(&b, (2 * words + 2) * 8));
     RB_TRY(hipMalloc(&m, (words + 2) * 8));
-    RB_TRY(hipMalloc(&oc, (words + 2) * 8));
     RB_TRY(hipMalloc(&q, nbases + 16));
     RB_TRY(hipMalloc(&fl, n));
     const bool uniform = r->longest == r->shortest;
@@ -877,22 +938,26 @@ int kbbq_fastq_reader_batch(kbbq_fastq_reader *r, kbbq_reads *dev) {
     RB_TRY(hipMemsetAsync(cnt, 0, 16, r->st));
     RB_TRY(hipMemsetAsync((char *)b + 2 * words * 8, 0, 16, r->st));
     RB_TRY(hipMemsetAsync((char *)m + words * 8, 0, 16, r->st));
-    RB_TRY(hipMemsetAsync((char *)oc + words * 8, 0, 16, r->st));
+    RB_TRY(hipMemsetAsync((char *)oc_scratch + words * 8, 0, 16, r->st));
     RB_TRY(hipMemsetAsync((char *)q + nbases, 0, 16, r->st));
     hipLaunchKernelGGL(k_fastq_gather, dim3((unsigned)std::min<uint64_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, r->st, (const uint8_t *)r->text.p, X,
                        (const uint64_t *)X.base_sz, n, (uint8_t *)seq_text, (uint8_t *)q);
     hipLaunchKernelGGL(k_pack_text, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, r->st, (const uint8_t *)seq_text, nbases, (uint64_t *)b,
-                       (uint64_t *)m, (uint64_t *)oc, (unsigned long long *)cnt);
+                       (uint64_t *)m, (uint64_t *)oc_scratch, (unsigned long long *)cnt);
     RB_TRY(hipGetLastError());
     RB_TRY(hipMemcpyAsync(fl, X.second, n, hipMemcpyDeviceToDevice, r->st));
     if (!uniform) RB_TRY(hipMemcpyAsync(off, X.base_sz, (n + 1) * 8, hipMemcpyDeviceToDevice, r->st));
     unsigned long long counts[2] = {0, 0};      // off-case bases; characters the packed form cannot give back
     RB_TRY(hipMemcpyAsync(counts, cnt, 16, hipMemcpyDeviceToHost, r->st));
     RB_TRY(hipStreamSynchronize(r->st));
-#undef RB_TRY
     const unsigned long long n_off = counts[0];
+    if (n_off) {      // soft-masked text: the batch gets its off-case bits
+        RB_TRY(hipMalloc(&oc, (words + 2) * 8));
+        RB_TRY(hipMemcpyAsync(oc, oc_scratch, (words + 2) * 8, hipMemcpyDeviceToDevice, r->st));
+        RB_TRY(hipStreamSynchronize(r->st));
+    }
+#undef RB_TRY
     r->packed_is_exact = counts[1] == 0;
-    if (!n_off) { (void)hipFree(oc); oc = nullptr; }
     dev->bases = (const uint64_t *)b;
     dev->nmask = (const uint64_t *)m;
     dev->qual = (const uint8_t *)q;
@@ -999,6 +1064,13 @@ int kbbq_reads_upload_text(kbbq_engine *e, const kbbq_reads *host, const uint8_t
     dev->nmask = (const uint64_t *)m;
     dev->offcase = (const uint64_t *)oc;
     return KBBQ_OK;
+}
+
+int kbbq_fastq_reader_preload(kbbq_fastq_reader *r, const uint8_t *file_bytes, uint64_t n_bytes, uint64_t front_room) {
+    if (!r || !file_bytes || !n_bytes) return fail(KBBQ_EINVAL, "bad argument");
+    KbbqDeviceGuard guard(r->device);
+    HIP_TRY(guard.err);
+    return r->pre.start(r->device, file_bytes, n_bytes, front_room);
 }
 
 int kbbq_fastq_reader_kernel_ms(kbbq_fastq_reader *r, double *inflate_ms, double *index_ms) {

@@ -576,6 +576,11 @@ public:
                     if (r <= 0) { ok = false; break; }
                     got += (uint64_t)r;
                 }
+                // the piece starts for the device at once: its copy overlaps the kernels of the piece before it
+                if (ok && !(getenv("KBBQ_PRELOAD") && atoi(getenv("KBBQ_PRELOAD")) == 0)) {
+                    if (bam) (void)kbbq_bam_reader_preload(bam, buf_[b] + kFront, n, kFront);
+                    else if (reader) (void)kbbq_fastq_reader_preload(reader, buf_[b] + kFront, n, kFront);
+                }
                 {
                     std::lock_guard<std::mutex> lk(mu_);
                     if (!ok) io_error_ = true;
