@@ -4,7 +4,8 @@
 # GENOME_LEN, sampler seed 777 as in bench.py: per-phase split (KBBQ_TIMING=1), the insert counts of the log, the digest of
 # the recalibrated qualities taken on the device (KBBQ_QUAL_DIGEST=1) -- to be compared with bench.py's
 # result.sampled_inserted / trusted_inserted / recal_qual_sum at the same size -- peak host RSS, output size.
-# CASES: fastq bam bam_setoq bamoq_useoq_setoq ; suffix _host = the host parsers (KBBQ_DEVICE_READER=0) ; _md5 = also the md5
+# CASES: fastq bam bam_setoq bamoq_useoq_setoq ; suffix _host = the host parsers (KBBQ_DEVICE_READER=0) ; _file = output into a
+# regular file instead of a pipe ; _md5 = also the md5
 # of the decompressed output (small sizes only).  Log: gpurun_out/r04_e2e_TAG.log
 set -o pipefail
 tag=$1; G=${2:-100000000}; cases=${3:-"fastq bam bam_setoq bamoq_useoq_setoq"}
@@ -24,7 +25,7 @@ gen() {      # gen NAME io-test-args...
     echo "generated in.$name: $(stat -c %s $D/in.$name) bytes in $(( (e - s) / 1000000 )) ms" | tee -a $L
 }
 for c in $cases; do
-    base=${c%%_host*}; base=${base%%_md5*}
+    base=${c%%_host*}; base=${base%%_md5*}; base=${base%%_file*}
     env_extra=""
     [[ $c == *_host* ]] && env_extra="KBBQ_DEVICE_READER=0"
     # (one input at a time: at 9e10 bases each is about 60 GB)
@@ -37,7 +38,10 @@ for c in $cases; do
         *) echo "unknown case $c"; exit 1 ;;
     esac
     s=$(date +%s%N)
-    if [[ $c == *_md5* ]]; then
+    if [[ $c == *_file* ]]; then      # into a regular file beside the input (four pwrite threads by default) instead of a pipe
+        env $env_extra KBBQ_TIMING=1 KBBQ_QUAL_DIGEST=1 KBBQ_SEED=777 $R/kbbq_amd/kbbq $args $in 2> $D/err_$c.txt > $D/out_$c.bin || { echo "$c failed"; tail -3 $D/err_$c.txt; exit 1; }
+        stat -c %s $D/out_$c.bin > $D/out_$c.bytes; rm -f $D/out_$c.bin
+    elif [[ $c == *_md5* ]]; then
         env $env_extra KBBQ_TIMING=1 KBBQ_QUAL_DIGEST=1 KBBQ_SEED=777 $R/kbbq_amd/kbbq $args $in 2> $D/err_$c.txt | tee >(wc -c > $D/out_$c.bytes) | gzip -dc | md5sum > $D/out_$c.md5 || { echo "$c failed"; tail -3 $D/err_$c.txt; exit 1; }
     else
         env $env_extra KBBQ_TIMING=1 KBBQ_QUAL_DIGEST=1 KBBQ_SEED=777 $R/kbbq_amd/kbbq $args $in 2> $D/err_$c.txt | wc -c > $D/out_$c.bytes || { echo "$c failed"; tail -3 $D/err_$c.txt; exit 1; }
