@@ -80,7 +80,12 @@ struct BamRgTable {
     const uint8_t *ids;         // the ids back to back
     const uint32_t *id_off;     // n_ids + 1 offsets
     uint32_t n_ids;
+    // more than a handful of @RG lines (merged cohorts carry hundreds): an open-addressing table over the ids' FNV-1a
+    // hashes, so that a record compares its RG value with one or two ids instead of all of them
+    const uint16_t *hash_slots; // hash_mask + 1 entries: id index, 0xFFFF = empty
+    uint32_t hash_mask;         // 0: no table (few ids: compared one by one)
 };
+__host__ __device__ __forceinline__ uint32_t bam_fnv1a(uint32_t h, uint8_t c) { return (h ^ c) * 16777619u; }
 
 // unaligned little-endian loads from the stream (the buffer is readable 4 KB behind its end)
 __device__ __forceinline__ uint32_t bam_ld32(const uint8_t *t, uint64_t p) {
@@ -325,11 +330,23 @@ __global__ void __launch_bounds__(256) k_bam_records(const uint8_t *text, uint64
         fl |= BAMF_FALLBACK;
     } else {
         const uint64_t v = rg_at + 1;
-        for (uint32_t i = 0; i < T.n_ids && rg == 0xFFFF; ++i) {
+        auto same_as = [&](uint32_t i) -> bool {
             const uint32_t o = T.id_off[i], len = T.id_off[i + 1] - o;
             bool same = v + len < end && text[v + len] == 0;      // (the value's NUL lies inside the record)
             for (uint32_t j = 0; j < len && same; ++j) same = text[v + j] == T.ids[o + j];
-            if (same) rg = i;
+            return same;
+        };
+        if (T.hash_mask) {
+            uint32_t h = 2166136261u;
+            for (uint64_t j = v; j < end && text[j]; ++j) h = bam_fnv1a(h, text[j]);
+            for (uint32_t probe = 0; probe <= T.hash_mask && rg == 0xFFFF; ++probe) {
+                const uint32_t i = T.hash_slots[(h + probe) & T.hash_mask];
+                if (i == 0xFFFF) break;
+                if (same_as(i)) rg = i;
+            }
+        } else {
+            for (uint32_t i = 0; i < T.n_ids && rg == 0xFFFF; ++i)
+                if (same_as(i)) rg = i;
         }
         if (rg == 0xFFFF) fl |= BAMF_FALLBACK;      // a read group without an @RG line: the host path's dictionary handles it
         // first appearance: a look first -- after the first wavefronts of a chunk nearly every record finds a smaller

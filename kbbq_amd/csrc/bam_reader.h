@@ -16,7 +16,8 @@ struct kbbq_bam_reader {
     Buf seg_u32, seg_slots, seg_counts;     // BamSegs
     Buf idx_u32, idx_u16, idx_u64;          // BamIndex
     Buf d_out;                              // small device words: [0..1] chain flags, [4..6] record flags / longest / shortest
-    Buf rg_ids, rg_off, first_seen, dense;  // the header's @RG table, first appearance per chunk, table index -> dense index
+    Buf rg_ids, rg_off, rg_hash, first_seen, dense;  // the header's @RG table (+ hash slots), first appearance per chunk, table index -> dense index
+    uint32_t rg_hash_mask = 0;
     Buf seq_text, counter;                  // scratch of kbbq_bam_reader_batch
     std::vector<uint8_t> h_ids;
     std::vector<uint32_t> h_id_off;
@@ -223,6 +224,7 @@ int bam_index_stream(kbbq_bam_reader *r, uint64_t text, uint64_t skip, int32_t l
             hipLaunchKernelGGL(k_bam_rec_offsets, dim3(n_segs), dim3(256), 0, r->st, G, (const uint64_t *)counts, (uint32_t)bias, X.rec_off);
             BamRgTable T;
             T.ids = (const uint8_t *)r->rg_ids.p; T.id_off = (const uint32_t *)r->rg_off.p; T.n_ids = (uint32_t)r->dense_of.size();
+            T.hash_slots = (const uint16_t *)r->rg_hash.p; T.hash_mask = r->rg_hash_mask;
             hipLaunchKernelGGL(k_bam_records, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, r->st, t, n_rec, r->use_oq, T, X, out + 4,
                                (unsigned long long *)r->first_seen.p);
             HIP_TRY(hipGetLastError());
@@ -286,7 +288,7 @@ void kbbq_bam_reader_destroy(kbbq_bam_reader *r) {
     KbbqDeviceGuard guard(r->device);
     if (r->st) (void)hipStreamSynchronize(r->st);
     Buf *all[] = {&r->comp, &r->text, &r->status, &r->blk_meta, &r->h_meta, &r->h_small, &r->carry, &r->tile_sums, &r->seg_u32, &r->seg_slots,
-                  &r->seg_counts, &r->idx_u32, &r->idx_u16, &r->idx_u64, &r->d_out, &r->rg_ids, &r->rg_off, &r->first_seen, &r->dense, &r->seq_text,
+                  &r->seg_counts, &r->idx_u32, &r->idx_u16, &r->idx_u64, &r->d_out, &r->rg_ids, &r->rg_off, &r->rg_hash, &r->first_seen, &r->dense, &r->seq_text,
                   &r->counter};
     for (Buf *b : all) b->release();
     r->pre.release();
@@ -331,6 +333,30 @@ int kbbq_bam_reader_create(int32_t device, int32_t use_oq, int32_t n_ref, uint64
             if (he == hipSuccess) he = hipMemcpy(r->rg_off.p, r->h_id_off.data(), r->h_id_off.size() * 4, hipMemcpyHostToDevice);
             if (he == hipSuccess) he = hipMemset(r->first_seen.p, 0xFF, (size_t)n_rg_ids * 8 + 64);
             if (he == hipSuccess) he = hipMemset(r->dense.p, 0, (size_t)n_rg_ids * 2 + 64);
+        }
+        if (he == hipSuccess && !rc && n_rg_ids > 8) {
+            // open addressing over the ids' hashes, at most half full (an id listed twice keeps its first index: the first wins
+            // a linear comparison as well)
+            uint32_t size = 16;
+            while (size < 2 * n_rg_ids) size *= 2;
+            std::vector<uint16_t> slots(size, 0xFFFF);
+            for (uint32_t i = 0; i < n_rg_ids; ++i) {
+                uint32_t h = 2166136261u;
+                for (uint32_t j = r->h_id_off[i]; j < r->h_id_off[i + 1]; ++j) h = bam_fnv1a(h, r->h_ids[j]);
+                uint32_t at = h & (size - 1);
+                bool dup = false;
+                while (slots[at] != 0xFFFF) {
+                    const uint32_t o = slots[at];
+                    const uint32_t la = r->h_id_off[o + 1] - r->h_id_off[o], lb = r->h_id_off[i + 1] - r->h_id_off[i];
+                    if (la == lb && !memcmp(&r->h_ids[r->h_id_off[o]], &r->h_ids[r->h_id_off[i]], la)) { dup = true; break; }
+                    at = (at + 1) & (size - 1);
+                }
+                if (!dup) slots[at] = (uint16_t)i;
+            }
+            if (!(rc = r->rg_hash.reserve((size_t)size * 2 + 64))) {
+                he = hipMemcpy(r->rg_hash.p, slots.data(), (size_t)size * 2, hipMemcpyHostToDevice);
+                r->rg_hash_mask = size - 1;
+            }
         }
     }
     if (he != hipSuccess || rc) {

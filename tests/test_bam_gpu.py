@@ -270,6 +270,35 @@ def test_rewritten_records_equal_the_reference_rules(use_oq, set_oq):
     writer.close()
 
 
+def test_hundreds_of_read_groups_go_through_the_hash_table(tmp_path):
+    """More than eight @RG lines: the record kernel finds a record's group through a hash table over the ids instead of
+    comparing with every one (merged cohorts carry hundreds).  Ids that are prefixes of each other, an id listed twice, one
+    group that never occurs; dense indices by first appearance as always."""
+    ids = ["s%d.lane%d" % (i // 4, i % 4) for i in range(300)] + ["s1", "s1.lane", "s1.lane1", "never"]
+    rng = np.random.RandomState(77)
+    used = [ids[int(i)] for i in rng.choice(len(ids) - 1, 40, replace=False)]
+    recs = make_records(3000, seed=55, oq_every=0)
+    for i, r in enumerate(recs):
+        g = used[int(rng.randint(0, len(used)))]
+        r["tags"] = [(t[0], t[1], g) if t[0] == "RG" else t for t in r["tags"]]
+    text = "@HD\tVN:1.6\n" + "".join("@RG\tID:%s\n" % i for i in ids)
+    comp, head_len, n_ref = bam_file(recs, text=text)
+    path = tmp_path / "a.bam"
+    path.write_bytes(comp)
+    rows, rc = host_rows(path, False)
+    assert rc == -1 and len(rows) == len(recs)
+    reader = bgzf.BamReader(head_len, n_ref, ids)
+    got = []
+    for info in feed(reader, comp, [len(comp) // 2 + 3]):
+        assert info["flags"] == 0, info
+        d = reader.batch()
+        got.append((info, download_batch(d), download_rg(d)))
+        _lib.check(_lib.lib().kbbq_reads_free(None, ctypes.byref(d)))
+    check_batches(got, rows)
+    assert len(reader.read_groups()) == len(set(r[2] for r in rows))
+    reader.close()
+
+
 def test_a_flagged_chunk_gives_no_batch_and_no_output():
     """kbbq_bam_reader_batch / _write refuse a chunk whose flags say "host parser": no caller can get a wrong batch by
     ignoring them; and --set-oq is refused where bam_aux_update_str would fail."""
