@@ -86,4 +86,4 @@ def test_bench_exchange_in_the_library_gives_the_same_answer():
     for key in ("sampled_inserted", "trusted_inserted", "fpr", "recal_qual_sum"):
         assert a["result"][key] == b["result"][key], key
     x = b["exchange_one_rank"]
-    assert x["exchange_by"].startswith("library") and all(v > 0 for v in x["exchange_ms_per_step"].values())
+    assert x["exchange_by"].startswith("library") and x["exchange_ms_per_step"]["filter0"] > 0 and x["exchange_ms_per_step"]["filter1"] > 0
