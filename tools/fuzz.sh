@@ -11,3 +11,7 @@ done
 for seed in ${SEEDS2:-33}; do
   timeout -k 10 700 python -u fuzz_parity.py 150 $seed > $R/gpurun_out/fuzz_$seed.log 2>&1; echo "direct seed $seed rc $? $(tail -1 $R/gpurun_out/fuzz_$seed.log)"
 done
+# the BAM path on the device against the host codec (tests/fuzz_bam.py)
+for seed in ${SEEDS3:-51}; do
+  timeout -k 10 900 python -u fuzz_bam.py ${BAM_CASES:-120} $seed > $R/gpurun_out/fuzz_bam_$seed.log 2>&1; echo "bam seed $seed rc $? $(tail -1 $R/gpurun_out/fuzz_bam_$seed.log)"
+done
