@@ -137,13 +137,7 @@ int bam_inflate(kbbq_bam_reader *r, const void *d_comp, const std::vector<uint64
         A.out = (uint8_t *)r->text.p;
         A.n_blocks = nb;
         A.status = (uint32_t *)r->status.p;
-        if (!r->inflate_grid) {
-            hipDeviceProp_t prop;
-            HIP_TRY(hipGetDeviceProperties(&prop, r->device));
-            int per_cu = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate, 64 * INF_WAVES, 0));
-            r->inflate_grid = (unsigned)std::max(1, prop.multiProcessorCount) * (unsigned)std::max(1, per_cu);
-        }
+        if (!r->inflate_grid && (rc = inflate_resident_waves(r->device, &r->inflate_grid))) return rc;
         hipLaunchKernelGGL(k_inflate, dim3(std::min<unsigned>(nb, r->inflate_grid)), dim3(64 * INF_WAVES), 0, r->st, A);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_block_crc, dim3(std::min<unsigned>((nb + 3) / 4, 256 * 16)), dim3(256), 0, r->st, A);      // as bgzf_read verifies them

@@ -377,6 +377,18 @@ struct Preload {
     }
 };
 
+// How many k_inflate wavefronts the device keeps resident (registers and LDS decide): the grid of every inflate launch -- blocks
+// are handed out round-robin, a second round of workgroups would only queue behind the first.  KBBQ_DEBUG_CODEC=1 prints it.
+static int inflate_resident_waves(int device, unsigned *out) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate, 64 * INF_WAVES, 0));
+    *out = (unsigned)std::max(1, prop.multiProcessorCount) * (unsigned)std::max(1, per_cu);
+    if (getenv("KBBQ_DEBUG_CODEC")) fprintf(stderr, "k_inflate: %d wavefronts per CU on %d CUs\n", per_cu, prop.multiProcessorCount);
+    return KBBQ_OK;
+}
+
 struct kbbq_fastq_reader {
     Preload pre;
     int device = 0;
@@ -715,13 +727,7 @@ int kbbq_fastq_reader_chunk(kbbq_fastq_reader *r, const uint8_t *file_bytes, uin
         A.status = (uint32_t *)r->status.p;
         // as many wavefronts as stay resident (5.6 KB of LDS each: 2 KB ring + 9-bit table): blocks are handed out round-robin, a second round of
         // workgroups would only queue behind the first
-        if (!r->inflate_grid) {
-            hipDeviceProp_t prop;
-            HIP_TRY(hipGetDeviceProperties(&prop, r->device));
-            int per_cu = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate, 64 * INF_WAVES, 0));
-            r->inflate_grid = (unsigned)std::max(1, prop.multiProcessorCount) * (unsigned)std::max(1, per_cu);
-        }
+        if (!r->inflate_grid && (rc = inflate_resident_waves(r->device, &r->inflate_grid))) return rc;
         const unsigned grid = std::min<unsigned>(nb, r->inflate_grid);
         hipLaunchKernelGGL(k_inflate, dim3(grid), dim3(64 * INF_WAVES), 0, r->st, A);
         HIP_TRY(hipGetLastError());
@@ -881,13 +887,7 @@ int kbbq_fastq_reader_inflate(kbbq_fastq_reader *r, const uint8_t *file_bytes, u
     A.out = (uint8_t *)r->text.p;
     A.n_blocks = nb;
     A.status = (uint32_t *)r->status.p;
-    if (!r->inflate_grid) {
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, r->device));
-        int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_inflate, 64 * INF_WAVES, 0));
-        r->inflate_grid = (unsigned)std::max(1, prop.multiProcessorCount) * (unsigned)std::max(1, per_cu);
-    }
+    if (!r->inflate_grid && (rc = inflate_resident_waves(r->device, &r->inflate_grid))) return rc;
     hipLaunchKernelGGL(k_inflate, dim3(std::min<unsigned>(nb, r->inflate_grid)), dim3(64 * INF_WAVES), 0, r->st, A);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_block_crc, dim3(std::min<unsigned>((nb + 3) / 4, 256 * 16)), dim3(256), 0, r->st, A);

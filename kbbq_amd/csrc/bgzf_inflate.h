@@ -41,6 +41,10 @@ constexpr int INF_FLUSH = 256;               // bytes that leave the ring for HB
 constexpr int INF_NEAR = INF_RING - 512;     // a match at most this far back still lies in the ring (the 512: lanes write up to 63
                                              // bytes ahead of the output position, see the literal and match copies)
 constexpr int INF_TBITS = 9;                 // the literal/length table is indexed by the next 9 bits of the stream
+#ifndef KBBQ_INF_DBITS
+#define KBBQ_INF_DBITS 8
+#endif
+constexpr int INF_DBITS = KBBQ_INF_DBITS;    // the distance table by the next 8
 constexpr int INF_WAVES = 1;                 // one wavefront per workgroup
 
 // status codes of a block
@@ -72,18 +76,27 @@ struct CodeBounds {
 
 // Entries of the literal/length table (u32), found by the next INF_TBITS bits of the stream as they lie in it (LSB first):
 //   literals   [3:0] bits of the codes together  [5:4] how many literals (1..3)  [15:8] [23:16] [31:24] the bytes
-//   otherwise  [5:4] = 0 and [7:6]: 0 a length code: [3:0] code bits, [12:8] extra bits, [24:16] base length
+//   otherwise  [5:4] = 0 and [7:6]: 0 a length code: [3:0] code bits, [12:8] extra bits, [24:16] base length, [28:25] code +
+//                                     extra bits
 //                                   1 end of block:  [3:0] code bits
 //                                   2 a code longer than INF_TBITS bits (or no code at all): decoded by the bounds
 //                                   3 a symbol the alphabet does not have (286, 287)
 enum : uint32_t { INF_E_LENGTH = 0u << 6, INF_E_EOB = 1u << 6, INF_E_LONG = 2u << 6, INF_E_BAD = 3u << 6 };
+// Entries of the distance table (u32), found by the next INF_DBITS bits:
+//   [3:0] code bits  [7:4] extra bits  [12:8] both together  [31:16] base distance
+//   [13] instead: a code longer than INF_DBITS bits, no code at all, or a symbol the alphabet does not have (30, 31) -- decoded
+//        (or refused) by the bounds
+enum : uint32_t { INF_D_SLOW = 1u << 13 };
 
 struct InflateLds {
     alignas(16) uint8_t ring[INF_RING];
     uint32_t ll[1 << INF_TBITS];
+    union {
+        uint32_t dd[1 << INF_DBITS];     // (built last, when the code lengths have served)
+        uint8_t lens[320];               // code lengths of a dynamic block (literal/length then distance)
+    };
     uint16_t sorted_ll[320];     // literal/length symbols in (length, value) order
     uint16_t sorted_small[64];   // the same of the code-length alphabet, then of the distance alphabet
-    uint8_t lens[320];           // code lengths of a dynamic block (literal/length then distance)
     alignas(16) uint8_t head[INF_FLUSH];      // the block's first line while it is incomplete in HBM (it starts inside it)
 };
 
@@ -126,18 +139,44 @@ __device__ __forceinline__ bool build_code(const uint8_t *lens, int n, uint16_t 
     return ok;
 }
 
-// The bit reader: 256 bytes of the stream per vector register (lane i = dword i), two registers ahead; the bit buffer and
-// its counters are wave-uniform.  It never reads further than two 256-byte pieces behind the end of the stream it was
-// given (a damaged stream cannot walk out of the buffer); consumed() against the stream's length tells an overrun.
+// A wave-uniform value the compiler takes for a per-lane one: what is computed from it is computed by the vector ALU.
+// The decoder's loop is one serial chain per wavefront in uniform control flow, and left to itself the compiler puts all of
+// that chain on the scalar unit -- one scalar instruction per cycle and CU, shared by the two dozen wavefronts a CU holds,
+// which is what the kernel then waits for (0.8 scalar instructions per cycle and CU, profiles/r04_sq_inflate.txt), while the
+// vector ALUs idle.  With the stream's bits and the table entries in vector registers the table index, the extra bits of
+// lengths and distances and the byte extraction are computed there; the scalar unit keeps the counters and the branches.
+__device__ __forceinline__ uint32_t in_vgpr(uint32_t x) {
+    uint32_t r;
+    asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t in_sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// The bit reader: 256 bytes of the stream per vector register (lane i = dword i), two registers ahead; from them a window of
+// two consecutive dwords, the same in every lane (in_vgpr above), and the scalar count of the window's bits already used.
+// The next 32 bits of the stream are one v_alignbit away; using bits up moves nothing but the count.  It never reads further
+// than two 256-byte pieces behind the end of the stream it was given (a damaged stream cannot walk out of the buffer);
+// consumed() against the stream's length tells an overrun.
 struct BitReader {
     const uint32_t *base;     // dword-aligned start
     uint32_t w0, w1;          // current and next 64 dwords (per lane)
-    uint32_t idx;             // next dword of w0 to take (0..64)
+    uint32_t idx;             // the dword of w0 that enters the window next (0..63)
     uint32_t chunk;           // index of the 256-byte chunk in w0
     uint32_t last_chunk;      // the last chunk that may be loaded
-    uint64_t buf;             // bits not consumed yet, LSB first
-    int cnt;                  // how many
+    uint32_t wa, wb;          // the window: dwords D and D + 1 of the stream
+    uint32_t used;            // bits of the window behind the reader (< 32 after refill())
     uint32_t skip;            // bits of the first dword that lie before the stream
+    __device__ __forceinline__ uint32_t next_dword() {
+        const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)w0, (int)idx);
+        if (++idx == 64) {
+            idx = 0;
+            ++chunk;
+            w0 = w1;
+            const uint32_t next = chunk + 1 < last_chunk ? chunk + 1 : last_chunk;
+            w1 = base[(size_t)next * 64 + (threadIdx.x & 63)];
+        }
+        return d;
+    }
     __device__ __forceinline__ void init(const uint8_t *p, uint32_t n_bytes, int lane) {
         const uintptr_t a = (uintptr_t)p;
         base = reinterpret_cast<const uint32_t *>(p - (a & 3));      // (pointer arithmetic: the loads stay global ones)
@@ -146,31 +185,26 @@ struct BitReader {
         w1 = base[64 + lane];
         idx = 0;
         chunk = 0;
-        buf = 0;
-        cnt = 0;
+        wa = in_vgpr(next_dword());
+        wb = in_vgpr(next_dword());
         skip = (uint32_t)(a & 3) * 8;
-        refill();
-        buf >>= skip;
-        cnt -= (int)skip;
+        used = skip;
     }
-    __device__ __forceinline__ void refill() {      // at least 33 valid bits afterwards (25 right behind init)
-        if (cnt <= 32) {
-            const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)w0, (int)idx);
-            buf |= (uint64_t)d << cnt;
-            cnt += 32;
-            if (++idx == 64) {
-                idx = 0;
-                ++chunk;
-                w0 = w1;
-                const uint32_t next = chunk + 1 < last_chunk ? chunk + 1 : last_chunk;
-                w1 = base[(size_t)next * 64 + (threadIdx.x & 63)];
-            }
+    __device__ __forceinline__ void refill() {      // 32 valid bits afterwards
+        if (used >= 32) {
+            const uint32_t d = next_dword();
+            // (both registers updated in place: written as two assignments the window travels through copies on every turn
+            // of the decoder's loop, also the turns that do not come by here)
+            asm("v_mov_b32 %0, %1\n\tv_mov_b32 %1, %2" : "+v"(wa), "+v"(wb) : "s"(d));
+            used -= 32;
         }
     }
-    __device__ __forceinline__ uint64_t consumed() const { return ((uint64_t)chunk * 64 + idx) * 32 - (uint64_t)cnt - skip; }
-    __device__ __forceinline__ uint32_t bits() const { return (uint32_t)buf; }
-    __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(buf & ((1ull << n) - 1)); }
-    __device__ __forceinline__ void drop(int n) { buf >>= n; cnt -= n; }
+    __device__ __forceinline__ uint64_t consumed() const { return ((uint64_t)chunk * 64 + idx - 2) * 32 + used - skip; }
+    __device__ __forceinline__ uint32_t vbits() const { return __builtin_amdgcn_alignbit(wb, wa, used); }      // in a vector register
+    __device__ __forceinline__ uint32_t bits() const { return in_sgpr(vbits()); }                             // in a scalar one
+    __device__ __forceinline__ uint32_t peek(int n) const { return bits() & ((1u << n) - 1u); }
+    __device__ __forceinline__ void drop(int n) { used += (uint32_t)n; }      // (at most 32 between two refill()s)
+    __device__ __forceinline__ void to_byte_boundary() { drop((int)((0u - (used - skip)) & 7u)); }
     __device__ __forceinline__ uint32_t get(int n) {      // n <= 16
         refill();
         const uint32_t v = peek(n);
@@ -222,7 +256,7 @@ __device__ __forceinline__ void build_ll_table(InflateLds &S, const CodeBounds &
             else if (sym <= 285) {
                 int base, eb;
                 length_base((int)sym - 257, &base, &eb);
-                ent = len | INF_E_LENGTH | ((uint32_t)eb << 8) | ((uint32_t)base << 16);
+                ent = len | INF_E_LENGTH | ((uint32_t)eb << 8) | ((uint32_t)base << 16) | ((len + (uint32_t)eb) << 25);
             } else ent = len | INF_E_BAD;
         }
         e[j] = ent;
@@ -265,6 +299,33 @@ __device__ __forceinline__ uint32_t distance_info(uint32_t ds) {
     if (ds < 4) return 1u + ds;
     const uint32_t de = (ds >> 1) - 1;
     return (1u + ((2u + (ds & 1u)) << de)) | (de << 16);
+}
+
+// The distance table of a block, as the literal/length one: every lane decodes its share of the bit patterns by the bounds.
+__device__ __forceinline__ void build_dd_table(InflateLds &S, const CodeBounds &DD, uint32_t n_coded, int lane) {
+    constexpr int PER = (1 << INF_DBITS) / 64;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const uint32_t x = (uint32_t)(64 * j + lane);
+        const uint32_t v = (__brev(x) >> (32 - INF_DBITS)) << (MAX_BITS - INF_DBITS);
+        uint32_t len = 0, off = 0;
+        for (int l = INF_DBITS; l >= 1; --l) {
+            const uint32_t lim_l = (uint32_t)__builtin_amdgcn_readlane((int)DD.lim, l);
+            const uint32_t off_l = (uint32_t)__builtin_amdgcn_readlane((int)DD.offs, l);
+            if (v < lim_l) { len = (uint32_t)l; off = off_l; }
+        }
+        uint32_t ent = INF_D_SLOW;
+        if (len) {
+            const uint32_t index = off + (v >> (MAX_BITS - len));
+            const uint32_t ds = index < n_coded ? S.sorted_small[index] : 31u;
+            if (ds < 30) {
+                const uint32_t info = distance_info(ds);
+                ent = len | ((info >> 16) << 4) | ((len + (info >> 16)) << 8) | ((info & 0xFFFFu) << 16);
+            }
+        }
+        S.dd[x] = ent;
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 
 __global__ void __launch_bounds__(64 * INF_WAVES, 6) k_inflate(InflateArgs A) {
@@ -318,7 +379,7 @@ __global__ void __launch_bounds__(64 * INF_WAVES, 6) k_inflate(InflateArgs A) {
             if (type == 0) {
                 // stored: to the next byte boundary, LEN, ~LEN, the bytes
                 B.refill();
-                B.drop(B.cnt & 7);
+                B.to_byte_boundary();
                 const uint32_t len = B.get(16), nlen = B.get(16);
                 const uint64_t at = bits_before + B.consumed();
                 if ((len ^ nlen) != 0xFFFFu) { err = INF_BAD_STORED; break; }
@@ -409,97 +470,106 @@ __global__ void __launch_bounds__(64 * INF_WAVES, 6) k_inflate(InflateArgs A) {
                 if (!build_code<1>(S.lens, hdist, S.sorted_small, DD, &n_dd, lane)) { err = INF_BAD_LENGTHS; break; }
             }
             build_ll_table(S, LL, n_ll, lane);
-            // lane i: base distance and extra bits of the i-th distance symbol in (length, value) order
+            build_dd_table(S, DD, n_dd, lane);
+            // lane i: base distance and extra bits of the i-th distance symbol in (length, value) order (codes the table leaves out)
             const uint32_t dd_info = (uint32_t)lane < n_dd ? distance_info(S.sorted_small[lane]) : 0u;
-            // ---- the block's symbols
+            // ---- the block's symbols.  One loop with two ways out (the end-of-block code, a failed line flush): a code or a
+            // distance the stream cannot mean is noted in `bad` and replaced by something harmless, and `bad` is looked at with
+            // every line and at the block's end -- fewer ways out of the loop are fewer scalar moves on every way round it.
+            // The lengths and distances are worked out from the vector copies of the bits and of the table entries.
+            uint32_t bad = 0;
             for (;;) {
-                // Runs of literals stay in a loop of their own (lookup, store, advance; nothing else is live across it):
-                // one to three literals per turn, lane i writes byte i -- the lanes behind them write bytes that the
-                // following symbols overwrite (what lies up to 63 bytes ahead of the output position is nobody's yet).
-                uint32_t bits, ent;
-                bool line_done = false;
+                // Runs of literals stay in a loop of their own (lookup, store, advance): one to three literals per turn, lane i
+                // writes byte i -- the lanes behind them write bytes that the following symbols overwrite (what lies up to 63
+                // bytes ahead of the output position is nobody's yet).
+                uint32_t vb, vent, ent;
                 for (;;) {
                     B.refill();
-                    bits = B.bits();
-                    ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.ll[bits & ((1u << INF_TBITS) - 1)]);
+                    vb = B.vbits();
+                    vent = S.ll[vb & ((1u << INF_TBITS) - 1)];      // (every lane the same entry)
+                    ent = in_sgpr(vent);
                     if (!(ent & 0x30u)) break;
-                    S.ring[(sp + (uint32_t)lane) & MASK] = (uint8_t)(ent >> lit_shift);
+                    S.ring[(sp + (uint32_t)lane) & MASK] = (uint8_t)(vent >> lit_shift);
                     B.drop((int)(ent & 15u));
                     sp += (ent >> 4) & 3u;
-                    if (sp >= next_line) { line_done = true; break; }
+                    if (sp >= next_line) break;
                 }
-                if (line_done) {
+                if (sp >= next_line) {      // (the one place where lines leave; a symbol looked up but not taken is looked up again)
                     __builtin_amdgcn_wave_barrier();
                     flush_lines();
+                    if (bad) err = INF_BAD_CODE;
                     if (err != INF_OK) break;
                     continue;
                 }
-                int len;
-                if ((ent & 0xC0u) == INF_E_LENGTH) {
-                    const int nb = (int)(ent & 15u), eb = (int)((ent >> 8) & 31u);
-                    len = (int)((ent >> 16) & 511u) + (int)((bits >> nb) & ((1u << eb) - 1u));
-                    B.drop(nb + eb);
-                } else if ((ent & 0xC0u) == INF_E_EOB) {
-                    B.drop((int)(ent & 15u));
-                    break;
-                } else if ((ent & 0xC0u) == INF_E_BAD) {
-                    err = INF_BAD_CODE;
-                    break;
-                } else {
-                    // a code longer than the table's index
-                    int cl = 0;
-                    const int ci = decode_index(bits, LL, &cl);
-                    if (ci < 0 || (uint32_t)ci >= n_ll) { err = INF_BAD_CODE; break; }
-                    B.drop(cl);
-                    const int sym = __builtin_amdgcn_readfirstlane((int)S.sorted_ll[ci]);
-                    if (sym < 256) {
-                        S.ring[sp & MASK] = (uint8_t)sym;      // (every lane the same byte to the same place)
-                        ++sp;
-                        if (sp >= next_line) { __builtin_amdgcn_wave_barrier(); flush_lines(); if (err != INF_OK) break; }
-                        continue;
+                if (ent & 0xC0u) {      // not a length code of the table
+                    if (ent & 0x80u) {
+                        // A code longer than the table's index, or none: decoded by the bounds into the entry a table wide
+                        // enough would have held (what the stream cannot mean becomes a literal 0 of one bit, and is noted).
+                        int cl = 1;
+                        int ci = (ent & 0xC0u) == INF_E_LONG ? decode_index(in_sgpr(vb), LL, &cl) : -1;
+                        uint32_t sym = 0;
+                        if (ci < 0 || (uint32_t)ci >= n_ll) bad = 1;
+                        else sym = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.sorted_ll[ci]);
+                        if (sym > 285) { bad = 1; sym = 0; }
+                        if (sym < 256) {
+                            S.ring[sp & MASK] = (uint8_t)sym;      // (every lane the same byte to the same place)
+                            B.drop(cl);
+                            ++sp;
+                            continue;
+                        }
+                        if (sym == 256) ent = (uint32_t)cl | INF_E_EOB;
+                        else {
+                            int base, eb;
+                            length_base((int)sym - 257, &base, &eb);
+                            ent = (uint32_t)cl | INF_E_LENGTH | ((uint32_t)eb << 8) | ((uint32_t)base << 16) | ((uint32_t)(cl + eb) << 25);
+                        }
+                        vent = in_vgpr(ent);
                     }
-                    if (sym == 256) break;
-                    if (sym > 285) { err = INF_BAD_CODE; break; }
-                    int base, eb;
-                    length_base(sym - 257, &base, &eb);
-                    len = base + (int)((bits >> cl) & ((1u << eb) - 1u));
-                    B.drop(eb);
+                    if (ent & 0x40u) {      // the end-of-block code
+                        B.drop((int)(ent & 15u));
+                        break;
+                    }
                 }
+                // a length: base + extra bits
+                const uint32_t vlen = ((vent >> 16) & 511u) + __builtin_amdgcn_ubfe(vb, vent & 15u, (vent >> 8) & 31u);
+                B.drop((int)((ent >> 25) & 31u));
                 // the distance
                 B.refill();
-                bits = B.bits();
-                int dl = 0;
-                const int di = decode_index(bits, DD, &dl);
-                if (di < 0 || (uint32_t)di >= n_dd) { err = INF_BAD_CODE; break; }
-                const uint32_t dinfo = (uint32_t)__builtin_amdgcn_readlane((int)dd_info, di);
-                const int de = (int)(dinfo >> 16);
-                const uint32_t dist = (dinfo & 0xFFFFu) + ((bits >> dl) & ((1u << de) - 1u));
-                B.drop(dl + de);
-                if (dist > sp - skew) { err = INF_BAD_DISTANCE; break; }
+                const uint32_t vb2 = B.vbits();
+                uint32_t vde = S.dd[vb2 & ((1u << INF_DBITS) - 1)];
+                uint32_t de = in_sgpr(vde);
+                if (de & INF_D_SLOW) {
+                    int dl = 1;
+                    const int di = decode_index(in_sgpr(vb2), DD, &dl);
+                    if (di < 0 || (uint32_t)di >= n_dd) { bad = 1; de = 1u | (1u << 8) | (1u << 16); }      // (one bit, distance 1)
+                    else {
+                        const uint32_t dinfo = (uint32_t)__builtin_amdgcn_readlane((int)dd_info, di);
+                        de = (uint32_t)dl | ((dinfo >> 16) << 4) | (((uint32_t)dl + (dinfo >> 16)) << 8) | ((dinfo & 0xFFFFu) << 16);
+                    }
+                    vde = in_vgpr(de);
+                }
+                const uint32_t vdist = (vde >> 16) + __builtin_amdgcn_ubfe(vb2, vde & 15u, (vde >> 4) & 15u);
+                B.drop((int)((de >> 8) & 31u));
+                const uint32_t len = in_sgpr(vlen);
+                uint32_t dist = in_sgpr(vdist);
+                if (dist > sp - skew) { bad = 1; dist = 1; }      // (then a copy inside the ring, whatever lies there)
                 // The copy: byte i of the match is byte (i mod dist) of the dist bytes before it.  A source inside the ring is an
-                // LDS-to-LDS copy; a source further back has left the ring long ago (at least 7 KB of output lie between it and
-                // the flush frontier) and is read back from HBM, behind a wait for this wave's own stores.  Like the literals,
-                // the lanes behind the match's length copy bytes nobody owns yet.
+                // LDS-to-LDS copy; a source further back has left the ring long ago (at least 1 KB of output lies between it and
+                // the flush frontier) and is read back from HBM -- behind this wave's own stores of those lines, which the
+                // memory pipeline of a CU keeps in order.  Like the literals, the lanes behind the match's length copy bytes
+                // nobody owns yet.
                 __builtin_amdgcn_wave_barrier();
                 if (dist <= (uint32_t)INF_NEAR) {
-                    if (dist >= (uint32_t)len) {
-                        // source and destination apart: all reads, then all writes
-                        const uint32_t from = sp - dist + (uint32_t)lane, to = sp + (uint32_t)lane;
-                        if (len <= 64) {
-                            const uint8_t v = S.ring[from & MASK];
-                            S.ring[to & MASK] = v;
-                        } else {
-                            uint8_t v[5];
-#pragma unroll
-                            for (int r = 0; r < 5; ++r) v[r] = S.ring[(from + 64u * r) & MASK];
-#pragma unroll
-                            for (int r = 0; r < 5; ++r) if (64 * r < len) S.ring[(to + 64u * r) & MASK] = v[r];
-                        }
+                    if (len <= min(dist, 64u)) {
+                        // source and destination apart, one round: all reads, then all writes
+                        const uint8_t v = S.ring[(sp - dist + (uint32_t)lane) & MASK];
+                        S.ring[(sp + (uint32_t)lane) & MASK] = v;
                     } else {
-                        // the match runs into itself: the first `dist` bytes, then twice as many, ... (every round's source is
-                        // finished, its stride a multiple of dist)
+                        // rounds of up to 64 bytes whose source is finished: of a match that runs into itself the first `dist`
+                        // bytes, then twice as many, ... (the stride stays a multiple of dist)
                         uint32_t c = dist;
-                        for (uint32_t done = 0; done < (uint32_t)len;) {
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+                        for (uint32_t done = 0; done < len;) {
                             const uint32_t n = min(c, 64u);
                             const uint8_t v = S.ring[(sp + done - c + (uint32_t)lane) & MASK];
                             __builtin_amdgcn_wave_barrier();
@@ -510,21 +580,22 @@ __global__ void __launch_bounds__(64 * INF_WAVES, 6) k_inflate(InflateArgs A) {
                         }
                     }
                 } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     // (lanes behind the match's length read bytes of this block's own output that may not have arrived yet:
                     // they land ahead of the output position like every other such byte)
                     // The block's first line is not in HBM before the block's end: its bytes come from `head`.
                     const uint32_t head_stop = head_whole ? 0u : head_end;
-                    for (int i0 = 0; i0 < len; i0 += 64) {
-                        const uint32_t from = sp - dist + (uint32_t)(i0 + lane);
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+                    for (uint32_t i0 = 0; i0 < len; i0 += 64) {
+                        const uint32_t from = sp - dist + i0 + (uint32_t)lane;
                         const uint8_t g = dst_base[from], h = S.head[from & (INF_FLUSH - 1)];
-                        S.ring[(sp + (uint32_t)(i0 + lane)) & MASK] = from < head_stop ? h : g;
+                        S.ring[(sp + i0 + (uint32_t)lane) & MASK] = from < head_stop ? h : g;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
-                sp += (uint32_t)len;
-                if (sp >= next_line) { flush_lines(); if (err != INF_OK) break; }
+                sp += len;
             }
+            if (err == INF_OK && sp >= next_line) { __builtin_amdgcn_wave_barrier(); flush_lines(); }      // (behind the last symbol)
+            if (bad && err == INF_OK) err = INF_BAD_CODE;
             if (err == INF_OK && bits_before + B.consumed() > src_bits) err = INF_OVERRUN_IN;
         }
         if (err == INF_OK && sp != sp_end) err = sp > sp_end ? INF_OVERRUN_OUT : INF_SIZE_MISMATCH;

@@ -52,6 +52,8 @@ def main():
     print("text", len(text), flush=True)
     cases = [("huffman_only", dict(strategy=zlib.Z_HUFFMAN_ONLY)), ("w9", dict(wbits=9)), ("w12", dict(wbits=12)),
              ("w13", dict(wbits=13)), ("w15", dict(wbits=15)), ("level1", dict(level=1))]
+    if len(sys.argv) > 3:      # only these cases (a counter run wants one kind of stream per process)
+        cases = [c for c in cases if c[0] in sys.argv[3].split(",")]
     r = bgzf.FastqReader(0)
     for name, kw in cases:
         t0 = time.time()
