@@ -7,14 +7,16 @@
 // the host only finds the block boundaries (18-byte headers) and reads the file.
 //
 //   k_inflate            RFC 1951 decoder, one BGZF block per wavefront.  The decoder is a serial machine, so a wave runs
-//                        it in uniform control flow (everything it decides lives in scalar registers) and uses its lanes
-//                        as storage and for the copies: the canonical-code tables sit in vector registers (lane l holds
-//                        the bound of the codes of length l: one compare + ballot finds a code's length, v_readlane
-//                        fetches its symbol), 256 bytes of the compressed stream per vector register, a 512-entry
-//                        literal/length table in LDS, and the most recent 2 KB of output in an LDS ring laid out at
-//                        (HBM address) mod 2 KB: a match inside the ring is an LDS-to-LDS copy by up to 64 lanes, a
-//                        finished 256-byte line leaves for HBM as 64 coalesced dword stores, and a match that reaches
-//                        further back (DEFLATE allows 32 KB) is read back from HBM behind a wait for the wave's own stores.
+//                        it in uniform control flow and uses its lanes as storage and for the copies: 256 bytes of the
+//                        compressed stream per vector register, a 512-entry literal/length table (up to three literals
+//                        per entry) and a 256-entry distance table in LDS, the canonical-code bounds in vector registers for
+//                        the codes the tables leave out (lane l holds the bound of the codes of length l: one compare +
+//                        ballot finds a code's length, v_readlane fetches its symbol), and the most recent 2 KB of output
+//                        in an LDS ring laid out at (HBM address) mod 2 KB: a match inside the ring is an LDS-to-LDS copy
+//                        by up to 64 lanes, a finished 256-byte line leaves for HBM as 64 coalesced dword stores, and a
+//                        match that reaches further back (DEFLATE allows 32 KB) is read back from HBM.  What the serial
+//                        chain computes is split between the scalar unit (counters, branches) and the vector ALU (the
+//                        stream's bits, table indices, lengths and distances): in_vgpr below.
 //   k_count_newlines / k_newline_positions   where the lines of the inflated text start
 //   k_fastq_records      per record (four lines): name / comment / sequence / quality fields, kseq's rules
 //                        (htsiter.cc:52-59, kseq.h) and the read-name rules of readutils.cc:74-97 that need no dictionary
@@ -34,7 +36,7 @@ namespace dfl {
 // profiles/r03_inflate_variants.txt): the decoder is bound by the latency of its own serial chain, so what counts is how many
 // wavefronts a CU holds -- 8 KB ring + 10-bit table, 12 per CU: 17.8 GB/s of zlib-6 FASTQ text; 4 KB + 10 bits, 16: 28.7;
 // 2 KB + 9 bits at six waves per SIMD (80 registers), 24: 32.7 -- although most matches of a 32 KB window then come back
-// from HBM.
+// from HBM.  Round 4 (profiles/r04_inflate_variants.txt): 6 KB of LDS and 71 registers, 26 per CU, 40.8 GB/s of that text.
 constexpr int INF_RING = 2048;               // the recent output of one wavefront in LDS: matches that reach no further back are
                                              // LDS-to-LDS copies; the rest of DEFLATE's 32 KB window is read back from HBM
 constexpr int INF_FLUSH = 256;               // bytes that leave the ring for HBM at a time: one aligned 256-byte line of the output
