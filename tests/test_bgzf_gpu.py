@@ -190,6 +190,13 @@ def test_inflate_fixed_codes_and_several_deflate_blocks_in_one_member():
     r.close()
 
 
+def test_inflate_arbitrary_streams_against_zlib():
+    """tests/fuzz_inflate.py: random bytes, runs, long-range repeats and skewed alphabets through every strategy, level, window
+    and flush zlib offers, as BGZF members of random sizes: the device's inflation equals the data byte for byte."""
+    import fuzz_inflate
+    assert fuzz_inflate.run(60, 71) > 0
+
+
 def test_damaged_blocks_are_reported_not_followed():
     """What bgzf_read answers with an error: a flipped bit in the DEFLATE stream (bad code, bad distance, wrong size, or --
     when the stream still decodes to the right number of bytes -- the CRC-32), a wrong CRC in the trailer, a wrong ISIZE.

@@ -15,3 +15,7 @@ done
 for seed in ${SEEDS3:-51}; do
   timeout -k 10 900 python -u fuzz_bam.py ${BAM_CASES:-120} $seed > $R/gpurun_out/fuzz_bam_$seed.log 2>&1; echo "bam seed $seed rc $? $(tail -1 $R/gpurun_out/fuzz_bam_$seed.log)"
 done
+# k_inflate against zlib on arbitrary bytes and every kind of DEFLATE stream (tests/fuzz_inflate.py)
+for seed in ${SEEDS4:-72}; do
+  timeout -k 10 600 python -u fuzz_inflate.py ${INFLATE_CASES:-300} $seed > $R/gpurun_out/fuzz_inflate_$seed.log 2>&1; echo "inflate seed $seed rc $? $(tail -1 $R/gpurun_out/fuzz_inflate_$seed.log)"
+done
