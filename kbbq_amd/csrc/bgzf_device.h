@@ -41,6 +41,7 @@ constexpr int HASH_BITS = KBBQ_DFL_HASH_BITS;
 constexpr int HASH_SIZE = 1 << HASH_BITS;
 constexpr int DFL_WAVES = 1;                        // wavefronts per workgroup: each works alone (no workgroup barrier anywhere), 18 KB of LDS
 constexpr int MIN_TAKE = 4;                         // shortest match the 4-byte hash can find
+constexpr int SWEEP2_BYTES = 16;                    // how far the match-length sweep looks; longer matches are followed by the parse
 constexpr uint32_t SLOT_BYTES = 65536 + 64;         // one finished block per slot; its bytes start at SLOT_SHIFT so that
 constexpr uint32_t SLOT_SHIFT = 6;                  // the DEFLATE stream (behind the 18-byte header) is 8-byte aligned
 constexpr uint32_t TOKENS_PER_WAVE = 65536;
@@ -70,17 +71,6 @@ __device__ __forceinline__ uint64_t load8(const uint8_t *p) {
     return v;
 }
 __device__ __forceinline__ uint32_t hash4(uint32_t v) { return (v * 2654435761u) >> (32 - HASH_BITS); }
-
-// length of the common prefix of in[a..] and in[b..], at most lim (a < b; reads stay inside [0, len + 8))
-__device__ __forceinline__ int match_length(const uint8_t *in, int a, int b, int lim) {
-    int n = 0;
-    while (n < lim) {
-        const uint64_t x = load8(in + a + n) ^ load8(in + b + n);
-        if (x) { n += (int)(__builtin_ctzll(x) >> 3); break; }
-        n += 8;
-    }
-    return n < lim ? n : lim;
-}
 
 // CRC-32 (gzip polynomial, reflected) of len bytes by one wavefront: 256 pieces of q bytes, four per lane (four
 // independent table walks keep the LDS pipe busy), every piece's register started at 0; the pieces are joined by the rule
@@ -222,10 +212,12 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
             }
         }
         DFL_MARK(2);
-        // Sweep 2: how far the candidate matches, two steps at a time, 16 bytes by two compares before any loop (a FASTQ
-        // match is 6 bytes on average, a read name's 9-17).  Nothing a round needs is asked for inside it: the candidates
-        // come two rounds ahead, and with them -- one round ahead -- the text at the positions and at their candidates.
-        // tokens[p] = length << 16 | distance, 0: no match.
+        // Sweep 2: how far the candidate matches, two steps at a time, up to 16 bytes by two compares (a FASTQ match is 6
+        // bytes on average, a read name's 9-17).  A match that may be longer is followed to its end by sweep 3, and only if
+        // the parse takes it: inside the 150-byte runs and repeats of BAM records every position has such a match, and a
+        // lane that compared its 258 bytes alone held up its step (BAM: 52 % of the kernel in this sweep, round 4).  Nothing
+        // a round needs is asked for inside it: the candidates come two rounds ahead, and with them -- one round ahead --
+        // the text at the positions and at their candidates.  tokens[p] = length << 16 | distance, 0: no match.
         {
             uint64_t cur_n[PF2], cur2_n[PF2], old_n[HASH_WAYS][PF2], old2_n[HASH_WAYS][PF2];
             uint32_t cand_nn[PF2], prev_n[PF2];
@@ -281,8 +273,7 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
                     for (int w = 0; w < HASH_WAYS; ++w) {      // way 0 is the nearer candidate: it wins a tie
                         if (cand[w][u] >= 0) {
                             const uint64_t x = cur[u] ^ old[w][u], x2 = cur2[u] ^ old2[w][u];
-                            int n = x ? (int)(__builtin_ctzll(x) >> 3) : x2 ? 8 + (int)(__builtin_ctzll(x2) >> 3)
-                                                                           : 16 + match_length(in, cand[w][u] + 16, p + 16, max(0, lim - 16));
+                            int n = x ? (int)(__builtin_ctzll(x) >> 3) : x2 ? 8 + (int)(__builtin_ctzll(x2) >> 3) : SWEEP2_BYTES;
                             n = min(n, lim);
                             if (n >= MIN_TAKE && n > L) { L = n; D = p - cand[w][u]; }
                         }
@@ -291,8 +282,7 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
                     if (hashed && p > 0 && (uint8_t)prev[u] == (uint8_t)cur[u]) {
                         const uint64_t rep = (uint64_t)(uint8_t)cur[u] * 0x0101010101010101ull;
                         const uint64_t x = cur[u] ^ rep, x2 = cur2[u] ^ rep;
-                        int n = x ? (int)(__builtin_ctzll(x) >> 3) : x2 ? 8 + (int)(__builtin_ctzll(x2) >> 3)
-                                                                       : 16 + match_length(in, p + 15, p + 16, max(0, lim - 16));
+                        int n = x ? (int)(__builtin_ctzll(x) >> 3) : x2 ? 8 + (int)(__builtin_ctzll(x2) >> 3) : SWEEP2_BYTES;
                         n = min(n, lim);
                         if (n >= MIN_TAKE && n > L) { L = n; D = 1; }
                     }
@@ -331,7 +321,8 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
                         ld_ahead[u] = tokens[min(pn, (int)TOKENS_PER_WAVE - 1)];
                         byte_ahead[u] = in[pn];
                     }
-                    const int L = in_block ? (int)(ld >> 16) : 0, D = (int)(ld & 0xFFFFu);      // (past the end: whatever the clamped load found)
+                    int L = in_block ? (int)(ld >> 16) : 0;
+                    const int D = (int)(ld & 0xFFFFu);      // (past the end: whatever the clamped load found)
 #ifdef KBBQ_DFL_PROFILE
                     const unsigned long long pt0 = __builtin_readcyclecounter();
 #endif
@@ -344,11 +335,42 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
                     const bool take = L >= MIN_TAKE && !(lane < 63 && L1 > L);
                     const int nxt = lane + (take ? L : 1);
                     const uint64_t takes = __ballot(take);
+                    const uint64_t longer = __ballot(take && L >= SWEEP2_BYTES);      // (as far as sweep 2 looked)
                     uint64_t starts = 0;
                     int rel = next_free - b0;
-                    while (rel < 64) {
-                        starts |= 1ull << rel;
-                        rel = __builtin_amdgcn_readlane(nxt, rel);
+                    if (!longer) {
+                        while (rel < 64) {
+                            starts |= 1ull << rel;
+                            rel = __builtin_amdgcn_readlane(nxt, rel);
+                        }
+                    } else {
+                        // a token that is such a match: its bytes from SWEEP2_BYTES on, eight per lane, against the candidate's
+                        while (rel < 64) {
+                            starts |= 1ull << rel;
+                            if ((longer >> rel) & 1) {
+                                const int pr = b0 + rel, dr = __builtin_amdgcn_readlane(D, rel);
+                                const int limr = min((int)MAX_MATCH, len - pr);
+                                const int off = SWEEP2_BYTES + 8 * lane;
+                                const bool on = off < limr;
+                                uint64_t x = 0;
+                                if (on) x = load8(in + pr + off) ^ load8(in + pr - dr + off);      // (reads stay inside [0, len + 8))
+                                const uint64_t differ = __ballot(on && x != 0);
+                                int lx;
+                                if (differ) {
+                                    const int f = (int)__builtin_ctzll(differ);
+                                    const uint64_t xf = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, f) |
+                                                        ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), f) << 32);
+                                    lx = SWEEP2_BYTES + 8 * f + (int)(__builtin_ctzll(xf) >> 3);
+                                } else {
+                                    lx = limr;
+                                }
+                                lx = min(lx, limr);
+                                if (lane == rel) L = lx;
+                                rel += lx;
+                            } else {
+                                rel = __builtin_amdgcn_readlane(nxt, rel);
+                            }
+                        }
                     }
                     starts &= valid;
                     const uint64_t taken = starts & takes;

@@ -16,10 +16,29 @@ NAMES = ["reset", "crc bytes", "sweep 1: hash table", "sweep 2: match lengths", 
          "block size + token bits", "crc join + framing"]
 
 
+def bam_bytes(n_reads, rng):
+    """records shaped like the ones kbbq --io-test synth-bam writes with `oq`: 150 bases as 4-bit codes, the quality field all 11,
+    RG:Z and the qualities as OQ:Z"""
+    out = []
+    nib = np.array([1, 2, 4, 8], dtype=np.uint8)
+    for i in range(n_reads):
+        name = b"read%09d\0" % i
+        seq = (nib[rng.integers(0, 4, 75)] << 4 | nib[rng.integers(0, 4, 75)]).astype(np.uint8).tobytes()
+        oq = (rng.choice(np.array([2, 12, 23, 27, 32, 37, 40], dtype=np.uint8), 150, p=[.02, .04, .08, .1, .16, .4, .2]) + 33).astype(np.uint8).tobytes()
+        body = (np.array([0, int(rng.integers(0, 1 << 28))], dtype="<i4").tobytes() + bytes([len(name), 60, 0x49, 0x12]) +
+                np.array([1, 16 if i & 1 else 0], dtype="<u2").tobytes() + np.array([150, -1, -1, 0], dtype="<i4").tobytes() +
+                name + np.array([150 << 4], dtype="<u4").tobytes() + seq + b"\x0b" * 150 + b"RGZgrp0\0" + b"OQZ" + oq + b"\0")
+        out.append(np.array([len(body)], dtype="<u4").tobytes() + body)
+    return b"".join(out)
+
+
 def main():
     mb = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    text = np.tile(np.frombuffer(fastq_text(mb * 1000000 // 330, np.random.default_rng(5)), dtype=np.uint8), reps)
+    if len(sys.argv) > 3 and sys.argv[3] == "bam":      # BAM records instead of FASTQ text
+        text = np.tile(np.frombuffer(bam_bytes(mb * 1000000 // 450, np.random.default_rng(5)), dtype=np.uint8), reps)
+    else:
+        text = np.tile(np.frombuffer(fastq_text(mb * 1000000 // 330, np.random.default_rng(5)), dtype=np.uint8), reps)
     if os.environ.get("KBBQ_PROBE_ZLIB"):      # the same text through zlib level 6 in BGZF-sized blocks (what bgzip / htslib write)
         import zlib
         one = text[:text.size // reps].tobytes()
