@@ -50,8 +50,9 @@ int kbbq_bgzf_submit_fastq(kbbq_bgzf *z, const char *blob, const uint32_t *lens,
                            const uint64_t *d_qual_offsets, uint32_t uniform_len, void *after_stream);
 
 /* Wait for the oldest submission: *blocks points at its BGZF blocks, back to back in file order, *n_bytes long, in
- * page-locked memory of the writer, valid until the next kbbq_bgzf_submit* call that reuses the slot (i.e. the second
- * one from now).  *payload_bytes (optional) = the uncompressed size. */
+ * page-locked memory of the writer, valid until the third kbbq_bgzf_collect from now (three buffers in turn: a caller
+ * may hand the blocks to a writing thread and go on submitting and collecting).  *payload_bytes (optional) = the
+ * uncompressed size. */
 int kbbq_bgzf_collect(kbbq_bgzf *z, const uint8_t **blocks, uint64_t *n_bytes, uint64_t *payload_bytes);
 
 /* The 28-byte empty block that ends a BGZF file. */

@@ -48,7 +48,7 @@ struct Buf {
 };
 
 struct Submission {
-    Buf payload, slots, sizes, offsets, out, h_out, h_meta;      // h_*: page-locked host memory
+    Buf payload, slots, sizes, offsets, out, h_meta;             // h_*: page-locked host memory
     Buf blob, lens, blob_off, text_off, h_off;                  // FASTQ pieces (device) and the host staging of the offsets
     hipEvent_t ev_meta = nullptr, ev_done = nullptr;            // total size known; blocks gathered
     hipEvent_t t0 = nullptr, t1 = nullptr, t2 = nullptr, t3 = nullptr;      // kernel timing: format | deflate | gather
@@ -65,6 +65,8 @@ struct kbbq_bgzf {
     hipEvent_t ev_after = nullptr;
     Submission sub[2];
     int head = 0, tail = 0, in_flight = 0;
+    Buf h_out[3];               // page-locked: the blocks of the last three collected submissions (kbbq_bgzf_collect)
+    int h_next = 0;
     Buf tokens;
 #ifdef KBBQ_DFL_PROFILE
     void *prof = nullptr;
@@ -83,7 +85,6 @@ int launch_deflate(kbbq_bgzf *z, Submission &s) {
     if ((rc = s.offsets.reserve(((size_t)s.n_blocks + 1) * 8))) return rc;
     const size_t bound = (size_t)kbbq_bgzf_bound(s.n);
     if ((rc = s.out.reserve(bound))) return rc;
-    if ((rc = s.h_out.reserve(bound))) return rc;
     if ((rc = s.h_meta.reserve(64))) return rc;
     // one wavefront per block in flight, as many as stay resident (11 KB of LDS, 152 registers: 12 per CU)
     if (!z->grid) {
@@ -156,7 +157,7 @@ int kbbq_bgzf_create(int32_t device, kbbq_bgzf **out) {
     if (he == hipSuccess) he = hipEventCreateWithFlags(&z->ev_after, hipEventDisableTiming);
     for (int i = 0; i < 2 && he == hipSuccess; ++i) {
         Submission &s = z->sub[i];
-        s.h_out.host = s.h_meta.host = s.h_off.host = true;
+        s.h_meta.host = s.h_off.host = true;
         he = hipEventCreateWithFlags(&s.ev_meta, hipEventDisableTiming);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming);
         if (he == hipSuccess) he = hipEventCreate(&s.t0);
@@ -179,12 +180,13 @@ void kbbq_bgzf_destroy(kbbq_bgzf *z) {
     if (z->copy) (void)hipStreamSynchronize(z->copy);
     for (int i = 0; i < 2; ++i) {
         Submission &s = z->sub[i];
-        Buf *all[] = {&s.payload, &s.slots, &s.sizes, &s.offsets, &s.out, &s.h_out, &s.h_meta, &s.blob, &s.lens, &s.blob_off, &s.text_off, &s.h_off};
+        Buf *all[] = {&s.payload, &s.slots, &s.sizes, &s.offsets, &s.out, &s.h_meta, &s.blob, &s.lens, &s.blob_off, &s.text_off, &s.h_off};
         for (Buf *b : all) b->release();
         hipEvent_t evs[] = {s.ev_meta, s.ev_done, s.t0, s.t1, s.t2, s.t3};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     }
     z->tokens.release();
+    for (Buf &b : z->h_out) b.release();
     if (z->ev_after) (void)hipEventDestroy(z->ev_after);
     if (z->copy) (void)hipStreamDestroy(z->copy);
     if (z->st) (void)hipStreamDestroy(z->st);
@@ -277,16 +279,23 @@ int kbbq_bgzf_collect(kbbq_bgzf *z, const uint8_t **blocks, uint64_t *n_bytes, u
     Submission &s = z->sub[z->tail];
     HIP_TRY(hipEventSynchronize(s.ev_meta));
     const uint64_t total = *(const uint64_t *)s.h_meta.p;
-    if (total > s.h_out.bytes) return fail(KBBQ_ESTATE, "compressed size %llu exceeds its bound", (unsigned long long)total);
+    if (total > s.out.bytes) return fail(KBBQ_ESTATE, "compressed size %llu exceeds its bound", (unsigned long long)total);
+    // three host buffers in turn: what a collect returns stays put while the next two are collected (a caller writes one
+    // submission's blocks out while it waits for the next)
+    Buf &h_out = z->h_out[z->h_next];
+    z->h_next = (z->h_next + 1) % 3;
+    h_out.host = true;
+    int rc;
+    if ((rc = h_out.reserve((size_t)total + 64))) return rc;
     // the copy back runs on its own stream: the kernels of the next submission are not held up behind it
     HIP_TRY(hipStreamWaitEvent(z->copy, s.ev_done, 0));
-    HIP_TRY(hipMemcpyAsync(s.h_out.p, s.out.p, total, hipMemcpyDeviceToHost, z->copy));
+    HIP_TRY(hipMemcpyAsync(h_out.p, s.out.p, total, hipMemcpyDeviceToHost, z->copy));
     HIP_TRY(hipStreamSynchronize(z->copy));
     float a = 0, b = 0, c = 0;
     if (hipEventElapsedTime(&a, s.t0, s.t1) == hipSuccess && s.formatted) z->ms_format += a;
     if (hipEventElapsedTime(&b, s.t1, s.t2) == hipSuccess) z->ms_deflate += b;
     if (hipEventElapsedTime(&c, s.t2, s.t3) == hipSuccess) z->ms_gather += c;
-    *blocks = (const uint8_t *)s.h_out.p;
+    *blocks = (const uint8_t *)h_out.p;
     *n_bytes = total;
     if (payload_bytes) *payload_bytes = s.n;
     s.busy = false;

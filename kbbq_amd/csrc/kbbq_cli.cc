@@ -29,6 +29,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -212,9 +213,18 @@ public:
         void *p = nullptr;
         if (kbbq_host_alloc(kChunk, &p) < 0) { failed_ = true; return; }
         buf_ = (char *)p;
+        // Everything else (a pipe, a terminal): the blocks are written in order by a thread of their own, so that the main
+        // thread is back at the device -- the next chunk's inflation, the next submission -- while write(2) waits for the
+        // reader of the pipe.  The encoder keeps a collected submission's blocks in place for the next two collects.
+        if (fd_ < 0) sink_ = std::thread([this] { sink_loop(); });
     }
     ~DeviceBgzfWriter() override {
         close();
+        if (sink_.joinable()) {
+            { std::lock_guard<std::mutex> lk(sink_mu_); sink_stop_ = true; }
+            sink_cv_.notify_all();
+            sink_.join();
+        }
         if (buf_) kbbq_host_free(buf_);
         if (z_) kbbq_bgzf_destroy(z_);
     }
@@ -273,16 +283,18 @@ public:
         ++in_flight_;
         return true;
     }
-    // every submission so far has been written out (a caller may then reuse device memory the submissions read)
-    bool drain() {
-        while (in_flight_ > 0) if (!collect_one()) return false;
+    // every submission so far has left the device (a caller may then reuse device memory the submissions read)
+    bool drain() { return drain_to(0); }
+    // all but the newest `keep` submissions
+    bool drain_to(int keep) {
+        while (in_flight_ > keep) if (!collect_one()) return false;
         return !failed_;
     }
     bool close() override {
         if (closed_) return !failed_;
         closed_ = true;
         if (failed_ || !flush_host() || !drain()) return false;
-        if (!put(kbbq_bgzf_eof_block(), 28)) return false;
+        if (!put(kbbq_bgzf_eof_block(), 28) || !sink_wait(0)) return false;
         if (fd_ >= 0 && lseek(fd_, (off_t)file_at_, SEEK_SET) < 0) return false;      // whoever writes next continues behind the blocks
         return fflush(out_) == 0;
     }
@@ -300,6 +312,7 @@ private:
     bool collect_one() {
         const uint8_t *blocks = nullptr;
         uint64_t n = 0, raw = 0;
+        if (!sink_wait(2)) return false;      // (the buffer this collect fills was handed out three collects ago)
         if (kbbq_bgzf_collect(z_, &blocks, &n, &raw) < 0) return fail_here();
         --in_flight_;
         payload_bytes += raw;
@@ -309,7 +322,16 @@ private:
     // n finished bytes to the output
     bool put(const uint8_t *data, uint64_t n) {
         if (fd_ < 0) {
-            if (fwrite(data, 1, n, out_) != n) { failed_ = true; return false; }
+            if (!sink_.joinable()) {
+                if (fwrite(data, 1, n, out_) != n) { failed_ = true; return false; }
+                return true;
+            }
+            {
+                std::lock_guard<std::mutex> lk(sink_mu_);
+                if (sink_failed_) { failed_ = true; return false; }
+                sink_q_.emplace_back(data, n);
+            }
+            sink_cv_.notify_all();
             return true;
         }
         const uint64_t at = file_at_;
@@ -341,6 +363,29 @@ private:
         while (in_flight_ >= 2) if (!collect_one()) return false;
         return !failed_;
     }
+    // the writing thread of a sequential sink
+    void sink_loop() {
+        std::unique_lock<std::mutex> lk(sink_mu_);
+        for (;;) {
+            sink_cv_.wait(lk, [&] { return sink_stop_ || !sink_q_.empty(); });
+            if (sink_q_.empty()) return;
+            const std::pair<const uint8_t *, uint64_t> job = sink_q_.front();
+            lk.unlock();
+            const bool ok = sink_failed_ || fwrite(job.first, 1, job.second, out_) == job.second;
+            lk.lock();
+            if (!ok) sink_failed_ = true;
+            sink_q_.pop_front();      // (behind the write: a job counts as pending while its bytes are being read)
+            sink_cv_.notify_all();
+        }
+    }
+    // until at most `pending` handed-over pieces are unwritten
+    bool sink_wait(size_t pending) {
+        if (!sink_.joinable()) return !failed_;
+        std::unique_lock<std::mutex> lk(sink_mu_);
+        sink_cv_.wait(lk, [&] { return sink_q_.size() <= pending; });
+        if (sink_failed_) failed_ = true;
+        return !failed_;
+    }
     bool flush_host() {
         if (failed_) return false;
         if (!fill_) return true;
@@ -359,6 +404,11 @@ private:
     size_t fill_ = 0;
     int in_flight_ = 0;
     bool failed_ = false, closed_ = false;
+    std::thread sink_;
+    std::mutex sink_mu_;
+    std::condition_variable sink_cv_;
+    std::deque<std::pair<const uint8_t *, uint64_t>> sink_q_;
+    bool sink_stop_ = false, sink_failed_ = false;
 };
 
 // BGZF input for the host parsers (BAM; FASTQ that the device's record kernels do not take) inflated on the GPU
@@ -1795,7 +1845,7 @@ int main(int argc, char *argv[]) {
                 const kbbq_reads &d = resident.dev[bi];
                 const int t = (int)(bi & 1);
                 ++bi;
-                while (dev_out->in_flight() >= 2) if (!dev_out->drain()) return 1;
+                if (!dev_out->drain_to(1)) return 1;      // (the array this batch writes was read by the submission two back)
                 if (d_q_bytes[t] < d.n_bases + 16) {
                     if (d_q[t] && kbbq_device_free(e, d_q[t]) < 0) return fail_engine("recalibrating");
                     d_q[t] = nullptr;
@@ -1827,7 +1877,7 @@ int main(int argc, char *argv[]) {
                 const RecordStore &st = resident.recs[bi];
                 const int t = (int)(bi & 1);
                 // the array this batch writes was read by the submission two batches ago: that one must be through
-                while (dev_out->in_flight() >= 2) if (!dev_out->drain()) return 1;
+                if (!dev_out->drain_to(1)) return 1;      // (the array this batch writes was read by the submission two back)
                 if (d_q_bytes[t] < d.n_bases + 16) {
                     if (d_q[t] && kbbq_device_free(e, d_q[t]) < 0) return fail_engine("recalibrating");
                     d_q[t] = nullptr;
@@ -1973,7 +2023,7 @@ int main(int argc, char *argv[]) {
                 if (!batch.fill_fast(in.fast, groups, batch_reads, &st)) break;
                 const int t = (int)(n & 1);
                 // the arrays of slot t were read by the submission two batches ago: that one must be through
-                while (dev_out->in_flight() >= 2) if (!dev_out->drain()) return 1;
+                if (!dev_out->drain_to(1)) return 1;      // (the array this batch writes was read by the submission two back)
                 if (up_live[t]) { kbbq_reads_free(e, &up[t]); up_live[t] = false; }
                 const kbbq_reads *d = nullptr;
                 if (resident.on) {

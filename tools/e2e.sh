@@ -37,6 +37,9 @@ for c in $cases; do
         bamoq_useoq) rm -f $D/in.bam $D/in.fq; gen bamoq synth-bam $G 30 oq; in=$D/in.bamoq; args="--use-oq" ;;
         *) echo "unknown case $c"; exit 1 ;;
     esac
+    # E2E_SETTLE=<seconds>: wait before a run -- the driver clears the memory the process before released, and a run
+    # that starts behind a 200 GB one finds its own allocations waiting for that
+    [ -n "$E2E_SETTLE" ] && sleep $E2E_SETTLE
     s=$(date +%s%N)
     if [[ $c == *_file* ]]; then      # into a regular file beside the input (four pwrite threads by default) instead of a pipe
         env $env_extra KBBQ_TIMING=1 KBBQ_QUAL_DIGEST=1 KBBQ_SEED=777 $R/kbbq_amd/kbbq $args $in 2> $D/err_$c.txt > $D/out_$c.bin || { echo "$c failed"; tail -3 $D/err_$c.txt; exit 1; }

@@ -48,16 +48,26 @@ def main():
     mb = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 16      # BGZF blocks stand alone: the same file several times over fills the chip
     rng = np.random.default_rng(5)
-    text = fastq_text(mb * 1000000 // 330, rng)
+    if os.environ.get("INFLATE_DATA") == "bam":      # BAM records (tools/deflate_probe.py) instead of FASTQ text
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from deflate_probe import bam_bytes
+        text = bam_bytes(mb * 1000000 // 450, rng)
+    else:
+        text = fastq_text(mb * 1000000 // 330, rng)
     print("text", len(text), flush=True)
     cases = [("huffman_only", dict(strategy=zlib.Z_HUFFMAN_ONLY)), ("w9", dict(wbits=9)), ("w12", dict(wbits=12)),
-             ("w13", dict(wbits=13)), ("w15", dict(wbits=15)), ("level1", dict(level=1))]
+             ("w13", dict(wbits=13)), ("w15", dict(wbits=15)), ("level1", dict(level=1)), ("device", dict(device=True))]
     if len(sys.argv) > 3:      # only these cases (a counter run wants one kind of stream per process)
         cases = [c for c in cases if c[0] in sys.argv[3].split(",")]
     r = bgzf.FastqReader(0)
     for name, kw in cases:
         t0 = time.time()
-        comp = np.tile(np.frombuffer(bgzf_blocks(text, **kw), dtype=np.uint8), reps)
+        if kw.get("device"):      # the stream this library's own encoder writes (k_deflate)
+            w = bgzf.BgzfWriter(0)
+            comp = np.tile(np.frombuffer(w.compress(np.frombuffer(text, dtype=np.uint8)), dtype=np.uint8), reps)
+            w.close()
+        else:
+            comp = np.tile(np.frombuffer(bgzf_blocks(text, **kw), dtype=np.uint8), reps)
         t_host = time.time() - t0
         best = 1e9
         for rep in range(3):
