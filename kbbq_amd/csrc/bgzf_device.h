@@ -131,6 +131,7 @@ struct WaveLds {
             uint32_t w[N_LL];
             uint16_t runs[N_LL + N_D];
             uint8_t all[N_LL + N_D];
+            alignas(8) unsigned long long stage[64];      // the bits of one step's 64 tokens (at most 48 each) before they leave
         } hs;
     } u;
     uint32_t ll_freq[N_LL];
@@ -432,13 +433,25 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
         const uint32_t dyn_bytes = (uint32_t)((total_bits + 7) >> 3), stored_bytes = (uint32_t)len + 5;
         uint32_t body_bytes;
         if (dyn_bytes < stored_bytes && dyn_bytes + BGZF_HEAD + BGZF_TAIL <= (uint32_t)BGZF_MAX_BLOCK) {
-            // header bits, then the tokens 64 at a time: exclusive prefix sum of their lengths, bits OR-ed into the zeroed slot
-            for (uint32_t i = lane; i * 64 < head_bits; i += 64) {      // 8-byte word i holds the header's bits [64 i, 64 i + 64)
+            // Header bits, then the tokens 64 at a time: an exclusive prefix sum of their lengths places them; the bits of a
+            // step are OR-ed together in LDS and leave as whole 8-byte words, 64 lanes side by side -- the word a step ends
+            // in travels on as `carry`.  (Round 3 OR-ed every token into the zeroed slot with one or two 64-bit atomics in
+            // HBM: 128 of them per step, a fifth of the kernel.)
+            unsigned long long carry = 0;
+            for (uint32_t i0 = 0; i0 * 64 < head_bits; i0 += 64) {      // 8-byte word i holds the header's bits [64 i, 64 i + 64)
+                const uint32_t i = i0 + lane;
                 uint64_t v = 0;
+                if (i * 64 < head_bits) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v |= (uint64_t)S.u.hs.head[i * 8 + k] << (8 * k);
-                if (v) atomicOr(&body64[i], (unsigned long long)v);
+                    for (int k = 0; k < 8; ++k) v |= (uint64_t)S.u.hs.head[i * 8 + k] << (8 * k);
+                    if ((i + 1) * 64 <= head_bits) body64[i] = (unsigned long long)v;
+                }
+                const uint32_t part = head_bits >> 6;      // the word the header ends in (if it ends inside one)
+                if ((head_bits & 63) && part >= i0 && part < i0 + 64)
+                    carry = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)(part - i0)) |
+                            ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)(part - i0)) << 32);
             }
+            __builtin_amdgcn_wave_barrier();
             uint64_t base = head_bits;
             uint32_t tok_ahead[PF];
 #pragma unroll
@@ -446,6 +459,7 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
             for (uint32_t i1 = 0; i1 < n_tok; i1 += 64 * PF) {
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
+                    if (i1 + 64 * u >= n_tok) break;
                     const uint32_t i = i1 + 64 * u + lane;
                     const uint32_t tok = tok_ahead[u];
                     tok_ahead[u] = tokens[min(i + 64 * PF, TOKENS_PER_WAVE - 1)];
@@ -454,20 +468,32 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
                     if (i < n_tok) token_bits(tok, S.codes, v, nb);
                     int incl = nb;
                     for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
-                    const uint64_t at = base + (uint64_t)(incl - nb);
+                    const uint32_t w0 = (uint32_t)(base >> 6);                    // the step's first word: `carry` so far
+                    const uint32_t rel = (uint32_t)(base & 63) + (uint32_t)(incl - nb);      // this token's first bit, from word w0's
+                    S.u.hs.stage[lane] = lane == 0 ? carry : 0ull;
+                    __builtin_amdgcn_wave_barrier();
                     if (nb) {
-                        const uint32_t word = (uint32_t)(at >> 6), sh = (uint32_t)(at & 63);
-                        atomicOr(&body64[word], (unsigned long long)(v << sh));
-                        if (sh + (uint32_t)nb > 64) atomicOr(&body64[word + 1], (unsigned long long)(v >> (64 - sh)));
+                        const uint32_t word = rel >> 6, sh = rel & 63;
+                        atomicOr(&S.u.hs.stage[word], (unsigned long long)(v << sh));
+                        if (sh + (uint32_t)nb > 64) atomicOr(&S.u.hs.stage[word + 1], (unsigned long long)(v >> (64 - sh)));
                     }
+                    __builtin_amdgcn_wave_barrier();
                     base += (uint64_t)__shfl(incl, 63);
+                    const uint32_t full = (uint32_t)(base >> 6) - w0;               // whole words finished by this step (< 50)
+                    const unsigned long long mine = S.u.hs.stage[lane];
+                    if ((uint32_t)lane < full) body64[w0 + lane] = mine;
+                    carry = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)full) |
+                            ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)full) << 32);
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
             if (lane == 0) {
+                // the end-of-block code, then the word(s) still on the way (before the trailer, which may share their bytes)
                 const uint64_t v = S.codes.ll_code[256];
                 const uint32_t word = (uint32_t)(base >> 6), sh = (uint32_t)(base & 63), nb = S.codes.ll_len[256];
-                atomicOr(&body64[word], (unsigned long long)(v << sh));
-                if (sh + nb > 64) atomicOr(&body64[word + 1], (unsigned long long)(v >> (64 - sh)));
+                carry |= (unsigned long long)(v << sh);
+                body64[word] = carry;
+                if (sh + nb > 64) body64[word + 1] = (unsigned long long)(v >> (64 - sh));
             }
             body_bytes = dyn_bytes;
         } else {
