@@ -412,10 +412,41 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
         // ---- codes and header (lane 0; the scratch lies over the hash table, which is done with)
         for (int i = lane; i < HEAD_BYTES; i += 64) S.u.hs.head[i] = 0;
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
-            S.ll_freq[256] += 1;      // end of block
-            build_block_codes(S.ll_freq, S.d_freq, S.codes, S.u.hs.head, S.u.hs.order, S.u.hs.w, S.u.hs.runs, S.u.hs.all);
+        // The literal/length alphabet (up to 286 used symbols in a BAM block) is sorted by (count, symbol) by all lanes: the
+        // rank of a symbol is the number of used symbols with a smaller key, 286 broadcast reads against five keys per lane.
+        // (Lane 0's Shell sort over arrays in LDS was 1.4 of the 2.3 M cycles this phase took per BAM block.)
+        bool ll_done = false;
+        {
+            if (lane == 0) S.ll_freq[256] += 1;      // end of block
+            __builtin_amdgcn_wave_barrier();
+            uint32_t key[5], cnt[5], rank[5];
+            uint32_t m = 0;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int sym = lane + 64 * j;
+                cnt[j] = sym < N_LL ? S.ll_freq[sym] : 0u;
+                key[j] = cnt[j] ? (cnt[j] << 9) | (uint32_t)sym : 0xFFFFFFFFu;
+                rank[j] = 0;
+                if (sym < N_LL) { S.u.hs.w[sym] = key[j]; S.codes.ll_len[sym] = 0; }
+                m += (uint32_t)__popcll(__ballot(cnt[j] != 0));
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 8
+            for (int t = 0; t < N_LL; ++t) {
+                const uint32_t kt = S.u.hs.w[t];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) rank[j] += kt < key[j] ? 1u : 0u;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                if (cnt[j]) { S.u.hs.order[rank[j]] = (uint16_t)(lane + 64 * j); S.u.hs.w[rank[j]] = cnt[j]; }
+            __builtin_amdgcn_wave_barrier();
+            int ok = 0;
+            if (lane == 0) ok = (m >= 2 && lengths_from_sorted((int)m, S.u.hs.order, S.u.hs.w, MAX_BITS, S.codes.ll_len)) ? 1 : 0;
+            ll_done = __builtin_amdgcn_readfirstlane(ok) != 0;      // (a code longer than 15 bits: the serial form raises the rare counts)
         }
+        if (lane == 0) build_block_codes(S.ll_freq, S.d_freq, S.codes, S.u.hs.head, S.u.hs.order, S.u.hs.w, S.u.hs.runs, S.u.hs.all, ll_done);
         __builtin_amdgcn_wave_barrier();
         const uint32_t head_bits = S.codes.head_bits;
 

@@ -61,6 +61,40 @@ DFL_HD uint32_t reverse_bits(uint32_t v, int n) {
 // At least two symbols get a code (a lone symbol is paired with a dummy: inflate implementations want a complete
 // code).  Lengths come from the in-place algorithm of Moffat and Katajainen on the counts sorted upwards; when the
 // longest code exceeds max_bits the counts below a floor are raised to it and the floor doubles until it fits.
+// The code lengths of m >= 2 symbols order[0..m) whose counts w[0..m) are sorted upwards (overwritten): len[order[i]] is set
+// when the longest code fits in max_bits, otherwise nothing is written and false returned.
+DFL_HD bool lengths_from_sorted(int m, const uint16_t *order, uint32_t *w, int max_bits, uint8_t *len) {
+    if (m == 2) {
+        w[0] = w[1] = 1;
+    } else {
+        // phase 1: pair the two smallest items, leaves or internal nodes, left to right
+        w[0] += w[1];
+        int root = 0, leaf = 2;
+        for (int next = 1; next < m - 1; ++next) {
+            if (leaf >= m || w[root] < w[leaf]) { w[next] = w[root]; w[root++] = (uint32_t)next; }
+            else w[next] = w[leaf++];
+            if (leaf >= m || (root < next && w[root] < w[leaf])) { w[next] += w[root]; w[root++] = (uint32_t)next; }
+            else w[next] += w[leaf++];
+        }
+        // phase 2: parent pointers -> depths of the internal nodes
+        w[m - 2] = 0;
+        for (int next = m - 3; next >= 0; --next) w[next] = w[w[next]] + 1;
+        // phase 3: depths of the internal nodes -> depths of the leaves
+        int avail = 1, used = 0, depth = 0, rootp = m - 2, next = m - 1;
+        while (avail > 0) {
+            while (rootp >= 0 && (int)w[rootp] == depth) { ++used; --rootp; }
+            while (avail > used) { w[next--] = (uint32_t)depth; --avail; }
+            avail = 2 * used;
+            ++depth;
+            used = 0;
+        }
+    }
+    // (the rarest symbol comes first: the longest code)
+    if ((int)w[0] > max_bits) return false;
+    for (int i = 0; i < m; ++i) len[order[i]] = (uint8_t)w[i];
+    return true;
+}
+
 DFL_HD void huffman_lengths(const uint32_t *freq, int n, int max_bits, uint8_t *len, uint16_t *order, uint32_t *w) {
     for (uint32_t floor_count = 1;; floor_count <<= 1) {
         int m = 0;
@@ -88,36 +122,7 @@ DFL_HD void huffman_lengths(const uint32_t *freq, int n, int max_bits, uint8_t *
             }
         }
         for (int i = 0; i < m; ++i) w[i] = count_of(order[i]);
-        if (m == 2) {
-            w[0] = w[1] = 1;
-        } else {
-            // phase 1: pair the two smallest items, leaves or internal nodes, left to right
-            w[0] += w[1];
-            int root = 0, leaf = 2;
-            for (int next = 1; next < m - 1; ++next) {
-                if (leaf >= m || w[root] < w[leaf]) { w[next] = w[root]; w[root++] = (uint32_t)next; }
-                else w[next] = w[leaf++];
-                if (leaf >= m || (root < next && w[root] < w[leaf])) { w[next] += w[root]; w[root++] = (uint32_t)next; }
-                else w[next] += w[leaf++];
-            }
-            // phase 2: parent pointers -> depths of the internal nodes
-            w[m - 2] = 0;
-            for (int next = m - 3; next >= 0; --next) w[next] = w[w[next]] + 1;
-            // phase 3: depths of the internal nodes -> depths of the leaves
-            int avail = 1, used = 0, depth = 0, rootp = m - 2, next = m - 1;
-            while (avail > 0) {
-                while (rootp >= 0 && (int)w[rootp] == depth) { ++used; --rootp; }
-                while (avail > used) { w[next--] = (uint32_t)depth; --avail; }
-                avail = 2 * used;
-                ++depth;
-                used = 0;
-            }
-        }
-        // (the rarest symbol comes first: the longest code)
-        if ((int)w[0] <= max_bits) {
-            for (int i = 0; i < m; ++i) len[order[i]] = (uint8_t)w[i];
-            return;
-        }
+        if (lengths_from_sorted(m, order, w, max_bits, len)) return;
     }
 }
 
@@ -191,9 +196,10 @@ constexpr int HEAD_BYTES = 640;
 
 // scratch: order[N_LL], w[N_LL], runs[N_LL + N_D], all[N_LL + N_D] (on the device all of it in LDS: an array of the
 // function's own would live in scratch memory, a trip to HBM per access)
+// ll_lengths_done: B.ll_len holds the literal/length code lengths already (the device sorts that alphabet with all its lanes)
 DFL_HD void build_block_codes(const uint32_t *ll_freq, const uint32_t *d_freq, BlockCodes &B, uint8_t *head, uint16_t *order, uint32_t *w,
-                              uint16_t *runs, uint8_t *all) {
-    huffman_lengths(ll_freq, N_LL, MAX_BITS, B.ll_len, order, w);
+                              uint16_t *runs, uint8_t *all, bool ll_lengths_done = false) {
+    if (!ll_lengths_done) huffman_lengths(ll_freq, N_LL, MAX_BITS, B.ll_len, order, w);
     huffman_lengths(d_freq, N_D, MAX_BITS, B.d_len, order, w);
     canonical_codes(B.ll_len, N_LL, MAX_BITS, B.ll_code);
     canonical_codes(B.d_len, N_D, MAX_BITS, B.d_code);
