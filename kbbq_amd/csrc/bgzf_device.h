@@ -339,15 +339,31 @@ __global__ void __launch_bounds__(64 * DFL_WAVES) k_deflate(DeflateArgs A) {
                     const uint64_t longer = __ballot(take && L >= SWEEP2_BYTES);      // (as far as sweep 2 looked)
                     uint64_t starts = 0;
                     int rel = next_free - b0;
-                    if (!longer) {
+                    // Where matches are dense (FASTQ text: most positions lie in one) the walk reads one lane per token.  Where
+                    // they are sparse (the sequence and quality bytes of BAM records) it goes from match to match: from a
+                    // position without a taken match every position up to the next taken match starts a literal, bits set in
+                    // one go (50 against 46 GB/s on BAM records; on FASTQ text the longer turn costs 14 %, hence the two forms).
+                    if (!longer && __popcll(takes) >= 32) {
                         while (rel < 64) {
                             starts |= 1ull << rel;
                             rel = __builtin_amdgcn_readlane(nxt, rel);
                         }
+                    } else if (!longer) {
+                        while (rel < 64) {
+                            const uint64_t ahead = takes >> rel;
+                            if (!ahead) { starts |= ~0ull << rel; rel = 64; break; }
+                            const int t = rel + (int)__builtin_ctzll(ahead);
+                            starts |= ((2ull << t) - 1) & (~0ull << rel);
+                            rel = __builtin_amdgcn_readlane(nxt, t);
+                        }
                     } else {
                         // a token that is such a match: its bytes from SWEEP2_BYTES on, eight per lane, against the candidate's
                         while (rel < 64) {
-                            starts |= 1ull << rel;
+                            const uint64_t ahead = takes >> rel;
+                            if (!ahead) { starts |= ~0ull << rel; rel = 64; break; }
+                            const int t = rel + (int)__builtin_ctzll(ahead);
+                            starts |= ((2ull << t) - 1) & (~0ull << rel);
+                            rel = t;
                             if ((longer >> rel) & 1) {
                                 const int pr = b0 + rel, dr = __builtin_amdgcn_readlane(D, rel);
                                 const int limr = min((int)MAX_MATCH, len - pr);
