@@ -2097,5 +2097,6 @@ int main(int argc, char *argv[]) {
                   << " ms, deflate " << ms_deflate << " ms, gather " << ms_gather << " ms" << std::endl;
     resident.drop();
     kbbq_engine_destroy(e);
+    clock.mark("release");
     return 0;
 }
