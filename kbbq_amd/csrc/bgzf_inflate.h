@@ -43,6 +43,9 @@ constexpr int INF_FLUSH = 256;               // bytes that leave the ring for HB
 constexpr int INF_NEAR = INF_RING - 512;     // a match at most this far back still lies in the ring (the 512: lanes write up to 63
                                              // bytes ahead of the output position, see the literal and match copies)
 constexpr int INF_TBITS = 9;                 // the literal/length table is indexed by the next 9 bits of the stream
+#ifndef KBBQ_INF_EXPERIMENT_NOFAR
+#define KBBQ_INF_EXPERIMENT_NOFAR 0      // 1: far matches copy nothing (wrong output: a timing experiment, tools/inflate_probe.py)
+#endif
 #ifndef KBBQ_INF_DBITS
 #define KBBQ_INF_DBITS 8
 #endif
@@ -587,7 +590,7 @@ __global__ void __launch_bounds__(64 * INF_WAVES, 6) k_inflate(InflateArgs A) {
                     // The block's first line is not in HBM before the block's end: its bytes come from `head`.
                     const uint32_t head_stop = head_whole ? 0u : head_end;
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-                    for (uint32_t i0 = 0; i0 < len; i0 += 64) {
+                    for (uint32_t i0 = 0; i0 < (KBBQ_INF_EXPERIMENT_NOFAR ? 0u : len); i0 += 64) {
                         const uint32_t from = sp - dist + i0 + (uint32_t)lane;
                         const uint8_t g = dst_base[from], h = S.head[from & (INF_FLUSH - 1)];
                         S.ring[(sp + i0 + (uint32_t)lane) & MASK] = from < head_stop ? h : g;
@@ -635,7 +638,7 @@ __global__ void __launch_bounds__(256) k_block_crc(InflateArgs A) {
         const uint8_t *t = A.comp + A.c_off[blk] + A.c_len[blk];      // CRC32 then ISIZE, little-endian (RFC 1952)
         const uint32_t want = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
         const uint32_t got = wave_crc32(A.out + A.o_off[blk], (int)A.o_len[blk], tab, lane, xq_for, xq, xq4);
-        if (lane == 0 && got != want) A.status[blk] = INF_BAD_CRC;
+        if (lane == 0 && got != want && !KBBQ_INF_EXPERIMENT_NOFAR) A.status[blk] = INF_BAD_CRC;
     }
 }
 
