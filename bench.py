@@ -79,27 +79,42 @@ if os.environ.get("KBBQ_PASS2_SIDE", "1") not in ("", "0"):
     PASS3_KERNELS += ("k_infer", "k_emit_trusted", "k_split_trusted", "k_apply_trusted")
 
 
-def run_step(e, xch, batches, ordinals, out_buf, hints):
-    """One complete pass of the hot path over this rank's shard."""
+def run_step(e, xch, batches, ordinals, out_buf, hints, pass_ms=None):
+    """One complete pass of the hot path over this rank's shard.  pass_ms (a list, diagnostic runs only): receives the wall
+    time of each of the four passes in ms -- the passes end in a wait of their own anyway (the *_finish calls, the histograms)."""
+    marks = []
+
+    def mark(wait=False):
+        if pass_ms is not None:
+            if wait:
+                e.sync()
+            marks.append(time.perf_counter())
     e.reset()
     hints.zero_()
     torch.cuda.synchronize()
+    mark()
     for b, o in zip(batches, ordinals):
         e.subsample_kmers(b, o)
     e.sample_finish()
     sampled = xch.filter_done(0)
     thr, fpr, p_text, too_high = e.compute_thresholds()
+    mark()
     for b in batches:
         e.find_trusted_kmers(b)
     e.trusted_finish()
     trusted = xch.filter_done(1)
+    mark()
     for b in batches:
         e.get_covariatedata(b)
     xch.histograms_done()
     xch.train_and_share()
+    mark(wait=True)
     for b in batches:
         e.recalibrate(b, out_buf.data_ptr())
     e.sync()
+    mark()
+    if pass_ms is not None:
+        pass_ms[:] = [round((marks[i + 1] - marks[i]) * 1e3, 1) for i in range(4)]
     return dict(sampled_inserted=sampled, trusted_inserted=trusted, fpr=fpr, fpr_too_high=too_high)
 
 
@@ -505,6 +520,11 @@ def main():
                     help="diagnostic (N = 1): A/B of one kbbq_engine_tune switch inside ONE process on the same resident reads -- "
                          "KNOB=0 / KNOB=1 alternated ROUNDS times (default 4), each an overlapped step (wall time) and an in-order "
                          "step (exclusive kernel durations); prints one JSON object and exits")
+    ap.add_argument("--ab-set", default=None, metavar="K=V,K=V;K=V,...[;...]",
+                    help="diagnostic (N = 1): several settings of kbbq_engine_tune knobs alternated inside ONE process on the same "
+                         "resident reads (--ab-rounds times each, in turn): wall time of an overlapped step and of its four passes per "
+                         "setting; an empty setting is the default; prints one JSON object and exits")
+    ap.add_argument("--ab-rounds", type=int, default=2)
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -609,6 +629,38 @@ def main():
         _l.check(e.L.kbbq_engine_tune(e.h, b"no_overlap", 0))
         return p
 
+    if args.ab_set is not None:
+        from kbbq_amd import _lib as _l
+        settings = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in part.split(",") if kv) for part in args.ab_set.split(";")]
+        knobs = sorted({k for st in settings for k in st})
+        rows = []
+        for i in range(args.ab_rounds):
+            for st in settings:
+                for k in knobs:
+                    _l.check(e.L.kbbq_engine_tune(e.h, k.encode(), st.get(k, 0)))
+                barrier()
+                passes = []
+                e.profile_reset()
+                t0 = time.perf_counter()
+                info = run_step(e, xch, batches, ordinals, out_buf, hints, pass_ms=passes)
+                barrier()
+                wall = (time.perf_counter() - t0) * 1e3
+                # (event durations of kernels that share the chip with another stream's: from eligible to done, not their own cost)
+                shared = {k: round(ms / n, 3) for k, (n, ms) in e.profile().items() if n}
+                rows.append(dict(round=i, setting=st, step_ms=round(wall, 1), pass_ms=passes, trusted_inserted=info["trusted_inserted"],
+                                 event_avg_ms=shared))
+                log("[ab] %s round %d: step %.0f ms, passes %s" % (st or "default", i, wall, passes))
+        for k in knobs:
+            _l.check(e.L.kbbq_engine_tune(e.h, k.encode(), 0))
+        digest = 0
+        for bt in batches:
+            e.recalibrate(bt, out_buf.data_ptr())
+            e.sync()
+            digest += int(out_buf[:bt.n_bases].to(torch.int64).sum().item())
+        print(json.dumps(dict(ab_set=args.ab_set, genome_len=G, coverage=cov, recal_qual_sum=digest, rows=rows)), flush=True)
+        shard.free()
+        e.close()
+        return
     if args.ab_tune:
         # the card's clock moves a kernel by +-7 % between boxes and within minutes: both settings alternate in one job
         knob, _, rounds = args.ab_tune.partition(",")

@@ -40,8 +40,10 @@ extern "C" {
 #define KBBQ_MAXQ 93            /* covariateutils.hh:3: the largest quality the MODEL proposes and the output clamp (readutils.cc:592-594) */
 #define KBBQ_NQ 256             /* quality rows of every table: an input quality is any uint8_t (a BAM can hold up to 255) and the
                                  * reference's tables grow with the largest one seen (covariateutils.cc:65-76,102-116,147-164) */
-#define KBBQ_MAX_READ_LEN 65535 /* a read's positions travel in 16 bits (the reference has no limit: covariateutils.cc:102-116);
-                                 * reads of up to 512 bases take the staged fast kernels, longer ones the windowed forms */
+#define KBBQ_MAX_READ_LEN 8388607 /* 2^23 - 1: a read's positions travel in 23 bits of a word (the reference has no limit:
+                                   * covariateutils.cc:102-116; the longest nanopore reads published are about half of this);
+                                   * reads of up to 512 bases take the staged fast kernels, longer ones the windowed forms.
+                                   * The tables are [n_rg][256][2][params.max_read_len]: 8 KiB of histogram per cycle and read group */
 #define KBBQ_DEFAULT_BLOOM_SEED 0xA5A5A5A55A5A5A5AULL   /* bloom.hh:389 */
 
 #define KBBQ_SAMPLED 0

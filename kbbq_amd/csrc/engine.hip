@@ -91,6 +91,12 @@ struct Options {
     int bucket = -1;                  // KBBQ_F_BUCKET_ON / _OFF, KBBQ_BUCKET=1/0: bucketed / direct inserts; -1: by filter size
     uint64_t bucket_records = 0;      // KBBQ_BUCKET_RECORDS: records gathered per flush (0: a share of the free HBM)
     uint64_t pass4_piece = 0;         // KBBQ_PASS4_PIECE: piece size of pass 4's pipeline in bases (0: about a quarter of a batch)
+    // Workgroups per CU of the persistent kernels while two streams are in use (0: as many as fit).  k_scan_trusted, k_infer
+    // and k_correct_wave take their reads from a global counter, so a grid of any size finishes the batch; a kernel that
+    // fills every wave slot keeps the other stream's kernel out until its own last read is done.
+    int scan_blocks = 0;              // KBBQ_SCAN_BLOCKS / kbbq_engine_tune("scan_blocks", n)
+    int walk_blocks = 0;              // KBBQ_WALK_BLOCKS / "walk_blocks"
+    int infer_blocks = 0;             // KBBQ_INFER_BLOCKS / "infer_blocks"
 };
 
 struct kbbq_engine {
@@ -241,7 +247,7 @@ static void plan_tally_slots(TallyPlan &P, const uint32_t mask[8], int max_slots
         P.identity = 0;
     }
     if (P.n_slots == 0) { P.n_slots = 1; P.qof[0] = 0; P.qslot[0] = 0; P.identity = 1; }      // (an empty set: one unused slot)
-    P.rg_base = 0; P.n_rgs = 1; P.cbase = 0;
+    P.rg_base = 0; P.n_rgs = 1; P.cbase = 0; P.direct_cycles = 0;
 }
 
 struct Timed {
@@ -481,10 +487,13 @@ int device_view(kbbq_engine *e, const kbbq_reads *in, ReadsDev *out, int *max_le
     return KBBQ_OK;
 }
 
-inline int wave_grid(uint64_t n_reads) {
+// grid of a kernel that handles one read per wavefront, four wavefronts per workgroup; per_cu: Options::*_blocks
+inline int wave_grid(uint64_t n_reads, int per_cu = 0) {
     const uint64_t blocks = (n_reads + 3) / 4;
-    return (int)std::min<uint64_t>(blocks, 256 * 16);
+    return (int)std::min<uint64_t>(blocks, 256 * (uint64_t)(per_cu > 0 ? per_cu : 16));
 }
+// ... the cap only while the other stream has work of the same pass (Options)
+inline int shared_cap(const kbbq_engine *e, int per_cu) { return e->opt.no_overlap ? 0 : per_cu; }
 
 // exclusive k-mer-position prefix for ragged batches (scratch slot 1); null for uniform ones
 int kmer_prefix(kbbq_engine *e, const ReadsDev &R, const uint64_t **kofs, uint64_t *total) {
@@ -767,6 +776,9 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
         o.bucket = (fl & KBBQ_F_BUCKET_ON) ? 1 : (fl & KBBQ_F_BUCKET_OFF) ? 0 : env_set("KBBQ_BUCKET") ? (env_int("KBBQ_BUCKET", 0) != 0 ? 1 : 0) : -1;
         o.bucket_records = env_u64("KBBQ_BUCKET_RECORDS", 0);
         o.pass4_piece = env_u64("KBBQ_PASS4_PIECE", 0);
+        o.scan_blocks = env_int("KBBQ_SCAN_BLOCKS", o.scan_blocks);
+        o.walk_blocks = env_int("KBBQ_WALK_BLOCKS", o.walk_blocks);
+        o.infer_blocks = env_int("KBBQ_INFER_BLOCKS", o.infer_blocks);
     }
     e->K.k = params->k;
     e->K.shift = 2u * (unsigned)(params->k - 1);
@@ -952,6 +964,9 @@ int kbbq_engine_tune(kbbq_engine *e, const char *name, uint64_t value) {
         e->opt.bucket_records = value;
     } else if (!strcmp(name, "pass4_piece")) {
         e->opt.pass4_piece = value;
+    } else if (!strcmp(name, "scan_blocks") || !strcmp(name, "walk_blocks") || !strcmp(name, "infer_blocks")) {
+        if (value > 16) return fail(KBBQ_EINVAL, "%s: 0 (as many as fit) to 16 workgroups per CU", name);
+        (name[0] == 's' ? e->opt.scan_blocks : name[0] == 'w' ? e->opt.walk_blocks : e->opt.infer_blocks) = (int)value;
     } else if (!strcmp(name, "infer_subset")) {
         e->opt.infer_subset = value != 0;      // (same results either way: an A/B switch between two runs)
     } else if (!strcmp(name, "no_overlap")) {
@@ -1472,6 +1487,8 @@ int kbbq_count_kmer_positions(kbbq_engine *e, const kbbq_reads *reads, uint64_t 
 }  // extern "C"
 
 constexpr int kStagedMax = 512;      // longest read the staged kernels take (Stage<8>); longer: long_reads.h
+constexpr int kTallyMaxWindows = 24;  // windows of 192 cycles k_tally takes as launches of their own (reads up to 4608 bases); longer
+                                      // reads: one launch, cycle counters straight to the histograms (run_tally)
 template <template <int> class Launcher, typename... Args>
 static int dispatch_nw(int max_len, Args... args) {
     if (max_len <= 192) return Launcher<3>::go(args...);
@@ -1668,7 +1685,7 @@ template <int NW> struct LaunchTrusted {
             // NK: chunks of 64 lanes that can hold a k-mer start (150-base reads, k = 32: 119 starts, two of the three chunks)
             const bool short_nk = std::max(1, max_len - e->p.k + 1) <= (NW - 1) * 64;
 #define KBBQ_LAUNCH_INFER(NK_, SUB_)                                                                                              \
-    hipLaunchKernelGGL((k_infer<NW, NK_, 1, SUB_>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->stream, R, e->K, e->filt[0].dev(), thr, \
+    hipLaunchKernelGGL((k_infer<NW, NK_, 1, SUB_>), dim3(wave_grid(R.n_reads, shared_cap(e, e->opt.infer_blocks))), dim3(256), 0, e->stream, R, e->K, e->filt[0].dev(), thr, \
                        take_bits, e->filt[1].d_inserted, err_out, e->d_qpresent, e->d_counters + 3, e->d_tickets, edge, pmask)
             if (edge >= 0) { if (short_nk) KBBQ_LAUNCH_INFER(NW - 1, true); else KBBQ_LAUNCH_INFER(NW, true); }
             else { if (short_nk) KBBQ_LAUNCH_INFER(NW - 1, false); else KBBQ_LAUNCH_INFER(NW, false); }
@@ -1816,10 +1833,10 @@ template <int NW> struct LaunchScan {
         HIP_TRY(hipMemsetAsync(ticket, 0, 4, e->cur));
         Timed t(e, "k_scan_trusted", e->cur);
         if (std::max(1, max_len - e->p.k + 1) <= (NW - 1) * 64)      // (NK: see k_infer)
-            hipLaunchKernelGGL((k_scan_trusted<NW, NW - 1>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->cur, R, e->K,
+            hipLaunchKernelGGL((k_scan_trusted<NW, NW - 1>), dim3(wave_grid(R.n_reads, shared_cap(e, e->opt.scan_blocks))), dim3(256), 0, e->cur, R, e->K,
                                e->filt[1].dev(), tmask, dirty, err_bits, e->cur_cnt, fast, ticket);
         else
-            hipLaunchKernelGGL((k_scan_trusted<NW, NW>), dim3(wave_grid(R.n_reads)), dim3(256), 0, e->cur, R, e->K,
+            hipLaunchKernelGGL((k_scan_trusted<NW, NW>), dim3(wave_grid(R.n_reads, shared_cap(e, e->opt.scan_blocks))), dim3(256), 0, e->cur, R, e->K,
                                e->filt[1].dev(), tmask, dirty, err_bits, e->cur_cnt, fast, ticket);
         HIP_TRY(hipGetLastError());
         return KBBQ_OK;
@@ -1867,7 +1884,7 @@ static int launch_correct_wave(kbbq_engine *e, ReadsDev R, const uint32_t *list,
     unsigned int *ticket = e->d_tickets + 3 + (e->cur_cnt != e->d_counters ? 1 : 0);      // per side of pass 3
     HIP_TRY(hipMemsetAsync(ticket, 0, 4, e->cur));
     Timed t(e, "k_correct_wave", e->cur);
-    const int blocks = (int)std::min<uint64_t>((R.n_reads + 3) / 4, 256 * 16);
+    const int blocks = wave_grid(R.n_reads, shared_cap(e, e->opt.walk_blocks));
     hipLaunchKernelGGL((k_correct_wave<NB, NN>), dim3(blocks), dim3(256), 0, e->cur, R, e->K, e->filt[1].dev(), list,
                        (const unsigned long long *)e->cur_cnt, tmask, tw, err_bits, patch, e->cur_cnt, ticket);
     HIP_TRY(hipGetLastError());
@@ -1908,10 +1925,16 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
         HIP_TRY(hipMemcpyAsync(e->qpresent, e->d_qpresent, 32, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
     }
+    // Reads of many thousand bases: a launch per window of ccap cycles would read the batch max_len / ccap times over, and a
+    // long read's cycle counters are as many addresses as it has bases anyway -- one launch, cycle counts straight to the
+    // histograms, only the dinucleotide counters in LDS (TallyPlan::direct_cycles).
+    const int n_windows = (max_len + ccap - 1) / ccap;
+    const bool direct_cycles = n_windows > kTallyMaxWindows;
     // per quality slot: totals and errors of 2 x ccap cycles as 16-bit counters + 2 x 16 dinucleotide words
-    const size_t per_slot = (size_t)8 * ccap + 128;
+    const size_t per_slot = (direct_cycles ? 0 : (size_t)8 * ccap) + 128;
     TallyPlan P;
     plan_tally_slots(P, e->qpresent, (int)((152 * 1024 - 512) / per_slot), n_rg);
+    P.direct_cycles = direct_cycles ? 1 : 0;
     const size_t per_rg = (size_t)P.n_slots * per_slot;
     // (half of the LDS if everything fits in it: two blocks per CU)
     const size_t budget = (size_t)n_rg * per_rg <= 70 * 1024 ? 70 * 1024 : 140 * 1024;
@@ -1937,7 +1960,6 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
         hipLaunchKernelGGL(k_rg_presence, dim3((unsigned)((R.n_reads + 255) / 256)), dim3(256), 0, stream, R.rg, R.n_reads, (uint32_t)e->p.n_rg, pr);
         present = pr;
     }
-    const int n_windows = (max_len + ccap - 1) / ccap;
     // the common shape -- equally long reads, one read group, every cycle in one table -- has a kernel of its own
     if (!e->opt.tally_general && !R.offsets && n_rg == 1 && n_windows == 1 && R.read_len >= 16 && (int)R.read_len <= ccap && R.n_bases < (1ULL << 32) && vec_ok &&
         e->p.n_rg == 1) {
@@ -1950,7 +1972,7 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
     }
     Timed t(e, "k_tally", stream);
     for (int g = 0; g < n_rg; g += per_launch)
-        for (int w = 0; w < n_windows; ++w) {
+        for (int w = 0; w < (direct_cycles ? 1 : n_windows); ++w) {
             P.rg_base = g;
             P.n_rgs = std::min(per_launch, n_rg - g);
             P.cbase = w * ccap;

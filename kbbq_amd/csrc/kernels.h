@@ -868,6 +868,10 @@ struct HistDev {
     int n_rg, n_cycle;
 };
 
+// A read's patch word (k_correct / k_correct_wave): bit 31 = the walk returned early with one base replaced
+// (readutils.cc:263-265), bits 8-30 = its position in the read (KBBQ_MAX_READ_LEN is what 23 bits hold), bits 0-1 = the base.
+__device__ __forceinline__ int patch_at(uint32_t pt) { return (int)((pt >> 8) & 0x7FFFFFu); }
+
 __device__ __forceinline__ uint64_t cyc_index(const HistDev &H, int rg, int q, int s, int c) {
     return ((((uint64_t)rg * KBBQ_NQ + q) * 2 + s) * H.n_cycle + c) * 2;
 }
@@ -899,6 +903,10 @@ struct TallyPlan {
     int identity;          // slot == quality for every quality below n_slots (few, small values: no lookup needed)
     int rg_base, n_rgs;    // this launch tallies the read groups [rg_base, rg_base + n_rgs)
     int cbase;             // ... and the cycles [cbase, cbase + ccap)
+    int direct_cycles;     // k_tally only: the cycle counters have no LDS table (reads of many thousand bases: a window of ccap
+                           // cycles per launch would re-read the batch once per window) -- every cycle in one launch, straight to
+                           // the histograms, where a long read's counters are as many addresses as it has bases; the few, hot
+                           // dinucleotide counters stay in LDS
 };
 
 // The quality axis of the LDS tables is compacted to the values the batches hold (TallyPlan; a quality is any uint8_t,
@@ -916,7 +924,8 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
     // layout per read group: cycle totals [2][ns][ccap] u16 (packed, cycle slots permuted), cycle errors likewise,
     // dinuc totals [ns][16] u32, dinuc errors [ns][16] u32 (few, hot addresses: global atomics on them serialise
     // at the memory side); then the quality -> slot map and the reads-touched counter
-    const int cyc_words = (2 * ccap * ns + 1) / 2;
+    const bool direct = P.direct_cycles != 0;
+    const int cyc_words = direct ? 0 : (2 * ccap * ns + 1) / 2;
     const int per_rg = 2 * cyc_words + 2 * ns * 16;
     uint32_t *l_reads = lds + P.n_rgs * per_rg;
     uint8_t *l_qslot = reinterpret_cast<uint8_t *>(l_reads + 1);
@@ -927,9 +936,22 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
     // one base: cycle and dinucleotide counters of (read group slot lr, quality q, second, cycle cyc)
     auto count = [&](int lr, int rg, int q, int second, int cyc, int er, bool dinuc_ok, int d) {
         const int cr = cyc - cbase;      // inside this launch's cycle window?
-        if ((unsigned)cr >= (unsigned)ccap) return;
+        if (!direct && (unsigned)cr >= (unsigned)ccap) return;
         const int sl = (int)l_qslot[q];
-        if (sl != 255) {
+        if (direct) {
+            atomicAdd(&H.cycle[cyc_index(H, rg, q, second, cyc) + 1], 1ULL);
+            if (er) atomicAdd(&H.cycle[cyc_index(H, rg, q, second, cyc)], 1ULL);
+            if (dinuc_ok) {
+                if (sl != 255) {
+                    uint32_t *t = lds + lr * per_rg;
+                    atomicAdd(&t[sl * 16 + d], 1u);
+                    if (er) atomicAdd(&t[ns * 16 + sl * 16 + d], 1u);
+                } else {
+                    atomicAdd(&H.dinuc[(((uint64_t)rg * KBBQ_NQ + q) * 16 + d) * 2 + 1], 1ULL);
+                    if (er) atomicAdd(&H.dinuc[(((uint64_t)rg * KBBQ_NQ + q) * 16 + d) * 2], 1ULL);
+                }
+            }
+        } else if (sl != 255) {
             uint32_t *t = lds + lr * per_rg;
             // lanes of one instruction are 16 cycles apart: store cycle c at slot (c%16)*(ccap/16) + c/16 so that
             // they land in neighbouring words, not in two banks
@@ -1009,7 +1031,7 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
             if (n == 16 && one_boundary && !mine1 && (bpos == 16 || !mine2)) {
                 starts += bpos < 16 ? 1 : 0;       // a group of other launches' read groups
             } else if (n == 16 && one_boundary && c0 + bpos <= H.n_cycle && 16 - bpos <= H.n_cycle) {
-                const int pp1 = (pt >> 31) ? (int)((pt >> 8) & 0xFFFF) : -2, pp2 = (pt2 >> 31) ? (int)((pt2 >> 8) & 0xFFFF) : -2;
+                const int pp1 = (pt >> 31) ? patch_at(pt) : -2, pp2 = (pt2 >> 31) ? patch_at(pt2) : -2;
                 if (pp1 >= 0 && pp1 == c0 - 1) { prev_b = (int)(pt & 3); prev_n = 0; }
                 starts += bpos < 16 ? 1 : 0;
 #pragma unroll
@@ -1027,7 +1049,7 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
                 }
             } else {
             // the read this group starts in may carry a patch on the base just before the group
-            if ((pt >> 31) && g0 > start && (int)((pt >> 8) & 0xFFFF) == (int)(g0 - 1 - start)) { prev_b = (int)(pt & 3); prev_n = 0; }
+            if ((pt >> 31) && g0 > start && patch_at(pt) == (int)(g0 - 1 - start)) { prev_b = (int)(pt & 3); prev_n = 0; }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const uint64_t g = g0 + i;
@@ -1042,7 +1064,7 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
                     }
                     const int cyc = (int)(g - start);
                     int b = (int)((bw >> (2 * i)) & 3), nn = (int)((nw >> i) & 1);
-                    if ((pt >> 31) && (int)((pt >> 8) & 0xFFFF) == cyc) { b = (int)(pt & 3); nn = 0; }
+                    if ((pt >> 31) && patch_at(pt) == cyc) { b = (int)(pt & 3); nn = 0; }
                     const int q = qv[i];
                     const int lr = rg - P.rg_base;
                     if ((unsigned)lr < (unsigned)P.n_rgs && rg < H.n_rg && cyc < H.n_cycle)
@@ -1065,7 +1087,8 @@ __global__ void __launch_bounds__(1024) k_tally(ReadsDev R, HistDev H, const uin
         }
         __syncthreads();
         // a block-uniform decision: everyone reads the counter before anyone may add to it again (next iteration)
-        const bool flush = *l_reads >= 40000u || it + 1 == iters;
+        // (direct_cycles: only the 32-bit dinucleotide counters are in LDS, and a block adds at most 2^14 per iteration to one)
+        const bool flush = (direct ? (it & 0xFFFF) == 0xFFFF : *l_reads >= 40000u) || it + 1 == iters;
         __syncthreads();
         if (flush) {
             for (int lr = 0; lr < P.n_rgs; ++lr) {
@@ -1198,7 +1221,7 @@ __global__ void __launch_bounds__(1024) k_tally_uniform(ReadsDev R, HistDev H, c
             const int sec1 = R.flags ? (R.flags[r] & 1) : 0;
             const int sec2 = two && R.flags ? (R.flags[r + 1] & 1) : 0;
             const uint32_t pt1 = patch ? patch[r] : 0u, pt2 = two && patch ? patch[r + 1] : 0u;
-            const int pp1 = (pt1 >> 31) ? (int)((pt1 >> 8) & 0xFFFF) : -2, pp2 = (pt2 >> 31) ? (int)((pt2 >> 8) & 0xFFFF) : -2;
+            const int pp1 = (pt1 >> 31) ? patch_at(pt1) : -2, pp2 = (pt2 >> 31) ? patch_at(pt2) : -2;
             if (pp1 >= 0 && pp1 == c0 - 1) { prev_b = (int)(pt1 & 3); prev_n = 0; }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -1218,7 +1241,7 @@ __global__ void __launch_bounds__(1024) k_tally_uniform(ReadsDev R, HistDev H, c
                 const uint64_t r = g / (uint64_t)L;
                 const int cyc = (int)(g - r * (uint64_t)L);
                 const uint32_t pt = patch ? patch[r] : 0u;
-                const int pp = (pt >> 31) ? (int)((pt >> 8) & 0xFFFF) : -2;
+                const int pp = (pt >> 31) ? patch_at(pt) : -2;
                 auto base_at = [&](uint64_t x, int cx, int &bb, int &nb) {
                     bb = (int)((R.bases[x >> 5] >> ((x & 31) * 2)) & 3);
                     nb = (int)((R.nmask[x >> 6] >> (x & 63)) & 1);

@@ -206,6 +206,14 @@ PARITY_CASES = {
                              dict(n_rg=2), dict(uniform=False, n_batches=2)),
     "long_uniform_1000_softmasked_k25": (make_softmasked_dataset, dict(seed=1000, frac=0.3, genome_len=40000, coverage=24, read_len=1000,
                                                                       extra_errors=80, clusters=40), dict(k=25), dict(uniform=True, n_batches=3)),
+    # reads longer than the 4608 bases k_tally takes in windows of 192 cycles: one launch, cycle counters straight to the histograms
+    "long_ragged_2000_9000": (make_dataset, dict(seed=9000, genome_len=90000, coverage=24, read_len=9000, ragged=True, ragged_min=2000,
+                                                 n_per_million=1500, extra_errors=20, clusters=10, n_rg=2, paired=True),
+                              dict(n_rg=2), dict(uniform=False, n_batches=2)),
+    # ... and than the 65 535 bases that were the engine's limit until round 4 (positions in 16 bits): nanopore-class lengths
+    "long_ragged_30000_70000": (make_dataset, dict(seed=70000, genome_len=300000, coverage=14, read_len=70000, ragged=True, ragged_min=30000,
+                                                   n_per_million=2500, extra_errors=6, clusters=4),
+                                dict(), dict(uniform=False, n_batches=2)),
     "reads_400": (make_dataset, dict(seed=400, genome_len=20000, coverage=20, read_len=400, n_per_million=500,
                                      extra_errors=60), dict(), dict(uniform=True)),
     # qualities above 93 (BAM-only values): 256 quality rows in every table, as the reference's growing tables
