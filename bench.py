@@ -523,7 +523,7 @@ def main():
     ap.add_argument("--ab-set", default=None, metavar="K=V,K=V;K=V,...[;...]",
                     help="diagnostic (N = 1): several settings of kbbq_engine_tune knobs alternated inside ONE process on the same "
                          "resident reads (--ab-rounds times each, in turn): wall time of an overlapped step and of its four passes per "
-                         "setting; an empty setting is the default; prints one JSON object and exits")
+                         "setting; a knob a setting does not name has its default; prints one JSON object and exits")
     ap.add_argument("--ab-rounds", type=int, default=2)
     args = ap.parse_args()
 
@@ -633,11 +633,12 @@ def main():
         from kbbq_amd import _lib as _l
         settings = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in part.split(",") if kv) for part in args.ab_set.split(";")]
         knobs = sorted({k for st in settings for k in st})
+        defaults = {"scan_blocks": 17, "walk_blocks": 17, "infer_subset": 1, "pass2_side": 2}      # (17: the engine's own choice)
         rows = []
         for i in range(args.ab_rounds):
             for st in settings:
                 for k in knobs:
-                    _l.check(e.L.kbbq_engine_tune(e.h, k.encode(), st.get(k, 0)))
+                    _l.check(e.L.kbbq_engine_tune(e.h, k.encode(), st.get(k, defaults.get(k, 0))))
                 barrier()
                 passes = []
                 e.profile_reset()
@@ -651,7 +652,7 @@ def main():
                                  event_avg_ms=shared))
                 log("[ab] %s round %d: step %.0f ms, passes %s" % (st or "default", i, wall, passes))
         for k in knobs:
-            _l.check(e.L.kbbq_engine_tune(e.h, k.encode(), 0))
+            _l.check(e.L.kbbq_engine_tune(e.h, k.encode(), defaults.get(k, 0)))
         digest = 0
         for bt in batches:
             e.recalibrate(bt, out_buf.data_ptr())

@@ -84,7 +84,10 @@ struct Options {
     bool no_fastpath = false;         // KBBQ_F_NO_FASTPATH / KBBQ_NO_FASTPATH: every read with untrusted k-mers takes the walk
     bool lane_walk = false;           // KBBQ_F_LANE_WALK / KBBQ_CORRECT=lane: the one-read-per-lane form of the walk
     bool no_pass4_pipeline = false;   // KBBQ_F_NO_PASS4_PIPELINE / KBBQ_NO_PASS4_PIPELINE: pass 4 of a host batch in one piece
-    bool pass2_side = true;           // KBBQ_F_PASS2_INORDER / KBBQ_PASS2_SIDE=0 clear it: the insert side of pass 2 beside k_infer
+    int pass2_side = 2;               // KBBQ_F_PASS2_INORDER / KBBQ_PASS2_SIDE=0: pass 2 in order; 1: its insert side (emit, split, apply) on the
+                                      // side stream beside k_infer; 2: only the emits there, a flush on the engine's stream between two k_infer.
+                                      // profiles/r04_ab_pass2_side_modes.json: pass 2 1868 / 1836 / 1816 ms -- k_apply beside k_infer takes 87 ms
+                                      // instead of 16.7 (both wait for the L2's request path), the ALU-bound emit costs k_infer half its own time
     bool tally_general = false;       // KBBQ_TALLY_GENERAL: the general tally kernel for every batch shape (A/B)
     bool infer_subset = true;         // KBBQ_INFER_SUBSET=0 / kbbq_engine_tune("infer_subset", 0): k_infer makes every lookup at once (round 3's form)
     bool debug_bucket = false;        // KBBQ_DEBUG_BUCKET: one stderr line per flush of the bucketed inserts
@@ -94,9 +97,19 @@ struct Options {
     // Workgroups per CU of the persistent kernels while two streams are in use (0: as many as fit).  k_scan_trusted, k_infer
     // and k_correct_wave take their reads from a global counter, so a grid of any size finishes the batch; a kernel that
     // fills every wave slot keeps the other stream's kernel out until its own last read is done.
-    int scan_blocks = 0;              // KBBQ_SCAN_BLOCKS / kbbq_engine_tune("scan_blocks", n)
-    int walk_blocks = 0;              // KBBQ_WALK_BLOCKS / "walk_blocks"
+    // Measured on the 30x workload (profiles/r04_ab_pass3_grid_caps.json, r04_ab_grid_caps_b.json): pass 3 with four scan and two
+    // walk workgroups per CU 1415 ms against 1568 ms uncapped; k_infer capped loses (its insert side needs more room than a cap
+    // that it tolerates leaves).  -1 = that setting for reads the three-word kernels take (up to 192 bases), none otherwise.
+    int scan_blocks = -1;             // KBBQ_SCAN_BLOCKS / kbbq_engine_tune("scan_blocks", n)
+    int walk_blocks = -1;             // KBBQ_WALK_BLOCKS / "walk_blocks"
     int infer_blocks = 0;             // KBBQ_INFER_BLOCKS / "infer_blocks"
+    bool tally_behind = false;        // KBBQ_TALLY_BEHIND=1 / "tally_behind": 1 = the next batch but one waits for a batch's walk only, not
+                                      // for its tally (three sets of flag arrays).  Measured and lost (profiles/r04_ab_tally_behind.json:
+                                      // pass 3 1990 ms against 1507): the tally then runs beside a scan whose resident workgroups leave
+                                      // it one of its two per CU -- 7.7 ms instead of 1.05 -- and the next walk queues behind it
+    int tally_threads = 0;            // KBBQ_TALLY_THREADS / "tally_threads": 256 or 512 = k_tally_uniform in workgroups of that size (with tally_behind)
+    int apply_small = 0;              // KBBQ_APPLY_SMALL / "apply_small": 1 = k_apply in workgroups of 512 for the flushes in the middle of pass 2
+    int walk_regs = 0;                // KBBQ_WALK_REGS / "walk_regs": 1 = k_correct_wave built for four wavefronts per SIMD (128 registers, no spills)
 };
 
 struct kbbq_engine {
@@ -114,6 +127,11 @@ struct kbbq_engine {
     bool ins_pending[2] = {false, false};
     int draw_turn = 0;
     bool side_busy[2] = {false, false};     // a batch of pass 3 used that side since the totals were last read
+    // ... its error flags and patches exist three times: the tally of batch i (side stream, behind its walk) reads them while the
+    // scan of batch i+2 (same side, engine's stream) clears the set it will write -- that scan waits for walk i only (ev_walk)
+    hipEvent_t ev_walk[2] = {nullptr, nullptr};
+    int flag_turn = 0;
+    bool pass3_shared = false;              // the batch being submitted shares the chip with its neighbours' kernels (grid caps)
     unsigned long long *d_totals = nullptr; // pass 3: [0] reads sent to the correction kernels, [1] Bloom queries there (k_add_counters)
     int side_turn = 0;
     uint32_t *d_qpresent = nullptr;     // quality values seen by pass 2 (256 bits), read at kbbq_trusted_finish
@@ -139,8 +157,8 @@ struct kbbq_engine {
     int8_t *d_dq_cycle = nullptr;
     int8_t *d_dq_dinuc = nullptr;
     // scratch
-    void *scratch[24] = {};
-    size_t scratch_bytes[24] = {};
+    void *scratch[28] = {};
+    size_t scratch_bytes[28] = {};
     unsigned long long *d_counters = nullptr;   // [0] work-list length, [1] correction queries, [2] scan total
     unsigned int *d_tickets = nullptr;          // chunk counters of the kernels that hand their reads out dynamically (ReadChunks): [0] k_infer, [1 + side] k_scan_trusted, [3 + side] k_correct_wave
     // Host batches: a ring of device staging slots owned by the engine and a copy stream.  A host batch is copied
@@ -493,7 +511,10 @@ inline int wave_grid(uint64_t n_reads, int per_cu = 0) {
     return (int)std::min<uint64_t>(blocks, 256 * (uint64_t)(per_cu > 0 ? per_cu : 16));
 }
 // ... the cap only while the other stream has work of the same pass (Options)
-inline int shared_cap(const kbbq_engine *e, int per_cu) { return e->opt.no_overlap ? 0 : per_cu; }
+inline int shared_cap(const kbbq_engine *e, int per_cu, int auto_value = 0, int max_len = 0) {
+    if (e->opt.no_overlap) return 0;
+    return per_cu >= 0 ? per_cu : max_len <= 192 ? auto_value : 0;
+}
 
 // exclusive k-mer-position prefix for ragged batches (scratch slot 1); null for uniform ones
 int kmer_prefix(kbbq_engine *e, const ReadsDev &R, const uint64_t **kofs, uint64_t *total) {
@@ -663,6 +684,12 @@ int bucket_flush(kbbq_engine *e, int w, bool barrier = true) {
     const FiltDev F = e->filt[w].dev();
     const hipStream_t emit_st = bucket_stream(e, w);
     hipStream_t st = emit_st;
+    if (w == 1 && e->opt.pass2_side == 2 && emit_st != e->stream) {
+        // the flush alone on the engine's stream, behind the emits that filled the buffers; the emits after it wait for it
+        HIP_TRY(hipEventRecord(b.ev_flush, emit_st));
+        HIP_TRY(hipStreamWaitEvent(e->stream, b.ev_flush, 0));
+        st = e->stream;
+    }
     HIP_TRY(hipMemsetAsync(b.tickets, 0, kTicketBytes, st));
     {
         Timed t(e, w ? "k_split_trusted" : "k_split_sampled", st);
@@ -672,11 +699,17 @@ int bucket_flush(kbbq_engine *e, int w, bool barrier = true) {
     }
     {
         Timed t(e, w ? "k_apply_trusted" : "k_apply_sampled", st);
-        hipLaunchKernelGGL(k_apply, dim3(B.n_sub), dim3(APPLY_THREADS), 0, st, F, B);
+        // (a flush in the middle of pass 2 shares the chip with k_infer: the form that fits beside it)
+        if (w == 1 && !barrier && st != e->stream && e->opt.apply_small) hipLaunchKernelGGL(k_apply<512>, dim3(B.n_sub), dim3(512), 0, st, F, B);
+        else hipLaunchKernelGGL(k_apply<1024>, dim3(B.n_sub), dim3(1024), 0, st, F, B);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemsetAsync(b.l1_cnt, 0, kL1CntBytes, st));
     HIP_TRY(hipMemsetAsync(b.l2_cnt, 0, (size_t)B.nb1 * NB2 * 4, st));
+    if (st != emit_st) {
+        HIP_TRY(hipEventRecord(b.ev_flush, st));
+        HIP_TRY(hipStreamWaitEvent(emit_st, b.ev_flush, 0));
+    }
     if (st != e->stream && barrier) {
         HIP_TRY(hipEventRecord(b.ev_flush, st));
         HIP_TRY(hipStreamWaitEvent(e->stream, b.ev_flush, 0));
@@ -769,7 +802,7 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
         o.no_fastpath = (fl & KBBQ_F_NO_FASTPATH) || env_set("KBBQ_NO_FASTPATH");
         o.lane_walk = (fl & KBBQ_F_LANE_WALK) || (getenv("KBBQ_CORRECT") && !strcmp(getenv("KBBQ_CORRECT"), "lane"));
         o.no_pass4_pipeline = (fl & KBBQ_F_NO_PASS4_PIPELINE) || env_set("KBBQ_NO_PASS4_PIPELINE");      // (no_overlap implies it, where it is used)
-        o.pass2_side = !(fl & KBBQ_F_PASS2_INORDER) && env_int("KBBQ_PASS2_SIDE", 1) != 0;                // (no_overlap switches it off, where it is used)
+        o.pass2_side = (fl & KBBQ_F_PASS2_INORDER) ? 0 : env_int("KBBQ_PASS2_SIDE", o.pass2_side);                // (no_overlap switches it off, where it is used)
         o.tally_general = env_set("KBBQ_TALLY_GENERAL");
         o.infer_subset = env_int("KBBQ_INFER_SUBSET", 1) != 0;
         o.debug_bucket = env_set("KBBQ_DEBUG_BUCKET");
@@ -779,6 +812,10 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
         o.scan_blocks = env_int("KBBQ_SCAN_BLOCKS", o.scan_blocks);
         o.walk_blocks = env_int("KBBQ_WALK_BLOCKS", o.walk_blocks);
         o.infer_blocks = env_int("KBBQ_INFER_BLOCKS", o.infer_blocks);
+        o.walk_regs = env_int("KBBQ_WALK_REGS", o.walk_regs);
+        o.apply_small = env_int("KBBQ_APPLY_SMALL", o.apply_small);
+        o.tally_threads = env_int("KBBQ_TALLY_THREADS", o.tally_threads);
+        o.tally_behind = env_int("KBBQ_TALLY_BEHIND", 0) != 0;
     }
     e->K.k = params->k;
     e->K.shift = 2u * (unsigned)(params->k - 1);
@@ -799,6 +836,7 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
     for (int t = 0; t < 2 && he == hipSuccess; ++t) he = hipEventCreateWithFlags(&e->ev_ins[t], hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_side[0], hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_side[1], hipEventDisableTiming);
+    for (int t = 0; t < 2 && he == hipSuccess; ++t) he = hipEventCreateWithFlags(&e->ev_walk[t], hipEventDisableTiming);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->copy, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->bk.ev_flush, hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->bk.ev_est, hipEventDisableTiming);
@@ -906,6 +944,7 @@ void kbbq_engine_destroy(kbbq_engine *e) {
     if (e->ev_draw) hipEventDestroy(e->ev_draw);
     for (int t = 0; t < 2; ++t) if (e->ev_ins[t]) hipEventDestroy(e->ev_ins[t]);
     for (int i = 0; i < 2; ++i) if (e->ev_side[i]) hipEventDestroy(e->ev_side[i]);
+    for (int i = 0; i < 2; ++i) if (e->ev_walk[i]) hipEventDestroy(e->ev_walk[i]);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -965,10 +1004,30 @@ int kbbq_engine_tune(kbbq_engine *e, const char *name, uint64_t value) {
     } else if (!strcmp(name, "pass4_piece")) {
         e->opt.pass4_piece = value;
     } else if (!strcmp(name, "scan_blocks") || !strcmp(name, "walk_blocks") || !strcmp(name, "infer_blocks")) {
-        if (value > 16) return fail(KBBQ_EINVAL, "%s: 0 (as many as fit) to 16 workgroups per CU", name);
-        (name[0] == 's' ? e->opt.scan_blocks : name[0] == 'w' ? e->opt.walk_blocks : e->opt.infer_blocks) = (int)value;
+        // (17 = the default: the measured setting for short reads, none otherwise)
+        if (value > 17) return fail(KBBQ_EINVAL, "%s: 0 (as many as fit) to 16 workgroups per CU, 17 = default", name);
+        (name[0] == 's' ? e->opt.scan_blocks : name[0] == 'w' ? e->opt.walk_blocks : e->opt.infer_blocks) = value == 17 ? (name[0] == 'i' ? 0 : -1) : (int)value;
+    } else if (!strcmp(name, "tally_behind")) {
+        ENGINE_DEVICE(e);
+        int rc = sync_engine(e);      // (the order of the events changes: between two runs)
+        if (rc) return rc;
+        e->opt.tally_behind = value != 0;
+    } else if (!strcmp(name, "walk_regs")) {
+        e->opt.walk_regs = value != 0;
+    } else if (!strcmp(name, "apply_small")) {
+        e->opt.apply_small = value != 0;
+    } else if (!strcmp(name, "tally_threads")) {
+        e->opt.tally_threads = (int)value;
     } else if (!strcmp(name, "infer_subset")) {
         e->opt.infer_subset = value != 0;      // (same results either way: an A/B switch between two runs)
+    } else if (!strcmp(name, "pass2_side")) {
+        ENGINE_DEVICE(e);
+        { int frc = bucket_flush_all(e); if (frc) return frc; }
+        int rc = sync_engine(e);
+        if (rc) return rc;
+        if (value > 2) return fail(KBBQ_EINVAL, "pass2_side: 0, 1 or 2");
+        e->opt.pass2_side = (int)value;
+        e->bk.stream[0] = e->bk.stream[1] = nullptr;
     } else if (!strcmp(name, "no_overlap")) {
         // between two runs: every kernel in order on one stream (exclusive kernel durations for a profile) or back
         ENGINE_DEVICE(e);
@@ -1700,7 +1759,7 @@ template <int NW> struct LaunchTrusted {
             // inserts of long reads are ordered against that stream by events, kbbq_trusted_batch.)
             // Measured +2.4 % on the 30x workload (profiles/r02_bench_full_i_{side,noside}.json); the exclusive duration
             // of k_infer -- the kernel the roofline is quoted for -- comes from the in-order run (KBBQ_F_NO_OVERLAP).
-            const bool side = e->opt.pass2_side && !e->opt.no_overlap;
+            const bool side = e->opt.pass2_side != 0 && !e->opt.no_overlap;
             e->bk.stream[1] = side ? e->stream2 : e->stream;
             if (side) {
                 HIP_TRY(hipEventRecord(e->ev_infer, e->stream));
@@ -1833,10 +1892,10 @@ template <int NW> struct LaunchScan {
         HIP_TRY(hipMemsetAsync(ticket, 0, 4, e->cur));
         Timed t(e, "k_scan_trusted", e->cur);
         if (std::max(1, max_len - e->p.k + 1) <= (NW - 1) * 64)      // (NK: see k_infer)
-            hipLaunchKernelGGL((k_scan_trusted<NW, NW - 1>), dim3(wave_grid(R.n_reads, shared_cap(e, e->opt.scan_blocks))), dim3(256), 0, e->cur, R, e->K,
+            hipLaunchKernelGGL((k_scan_trusted<NW, NW - 1>), dim3(wave_grid(R.n_reads, e->pass3_shared ? shared_cap(e, e->opt.scan_blocks, 4, max_len) : 0)), dim3(256), 0, e->cur, R, e->K,
                                e->filt[1].dev(), tmask, dirty, err_bits, e->cur_cnt, fast, ticket);
         else
-            hipLaunchKernelGGL((k_scan_trusted<NW, NW>), dim3(wave_grid(R.n_reads, shared_cap(e, e->opt.scan_blocks))), dim3(256), 0, e->cur, R, e->K,
+            hipLaunchKernelGGL((k_scan_trusted<NW, NW>), dim3(wave_grid(R.n_reads, e->pass3_shared ? shared_cap(e, e->opt.scan_blocks, 4, max_len) : 0)), dim3(256), 0, e->cur, R, e->K,
                                e->filt[1].dev(), tmask, dirty, err_bits, e->cur_cnt, fast, ticket);
         HIP_TRY(hipGetLastError());
         return KBBQ_OK;
@@ -1884,7 +1943,11 @@ static int launch_correct_wave(kbbq_engine *e, ReadsDev R, const uint32_t *list,
     unsigned int *ticket = e->d_tickets + 3 + (e->cur_cnt != e->d_counters ? 1 : 0);      // per side of pass 3
     HIP_TRY(hipMemsetAsync(ticket, 0, 4, e->cur));
     Timed t(e, "k_correct_wave", e->cur);
-    const int blocks = wave_grid(R.n_reads, shared_cap(e, e->opt.walk_blocks));
+    const int blocks = wave_grid(R.n_reads, e->pass3_shared ? shared_cap(e, e->opt.walk_blocks, 2, NB <= 5 ? 160 : 512) : 0);
+    if (e->opt.walk_regs)
+        hipLaunchKernelGGL((k_correct_wave<NB, NN, 4>), dim3(blocks), dim3(256), 0, e->cur, R, e->K, e->filt[1].dev(), list,
+                           (const unsigned long long *)e->cur_cnt, tmask, tw, err_bits, patch, e->cur_cnt, ticket);
+    else
     hipLaunchKernelGGL((k_correct_wave<NB, NN>), dim3(blocks), dim3(256), 0, e->cur, R, e->K, e->filt[1].dev(), list,
                        (const unsigned long long *)e->cur_cnt, tmask, tw, err_bits, patch, e->cur_cnt, ticket);
     HIP_TRY(hipGetLastError());
@@ -1965,8 +2028,12 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
         e->p.n_rg == 1) {
         const unsigned long long inv_len = ~0ULL / R.read_len + 1;      // ceil(2^64 / read_len): read_len is no power of two times... exact below
         Timed t(e, "k_tally", stream);
-        if (P.identity) hipLaunchKernelGGL(k_tally_uniform<false>, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, inv_len, P);
-        else hipLaunchKernelGGL(k_tally_uniform<true>, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, inv_len, P);
+        // (tally_threads: workgroups of 256 or 512, one per CU -- the form that finds room beside the next batches' scan and walk
+        // when the tally is left behind, Options::tally_behind)
+        const int tt = e->pass3_shared && (e->opt.tally_threads == 256 || e->opt.tally_threads == 512) ? e->opt.tally_threads : 1024;
+        const int tb = tt == 1024 ? blocks : (int)std::min<uint64_t>((groups + tt - 1) / tt, 256);
+        if (P.identity) hipLaunchKernelGGL(k_tally_uniform<false>, dim3(tb), dim3(tt), lds, stream, R, H, err_bits, patch, ccap, 6, inv_len, P);
+        else hipLaunchKernelGGL(k_tally_uniform<true>, dim3(tb), dim3(tt), lds, stream, R, H, err_bits, patch, ccap, 6, inv_len, P);
         HIP_TRY(hipGetLastError());
         return KBBQ_OK;
     }
@@ -1998,10 +2065,14 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
         e->side_turn ^= 1;
         // the batch that last used this side's scratch may still be in its walk on the side stream: this batch's scan
         // (engine's stream) overwrites that scratch, so the stream waits -- the host does not
-        if (e->side_busy[side]) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_side[side], 0));
+        if (e->side_busy[side]) HIP_TRY(hipStreamWaitEvent(e->stream, e->opt.tally_behind ? e->ev_walk[side] : e->ev_side[side], 0));
     } else {
         if ((rc = sync_engine(e))) return rc;              // both sides' scratch is free
     }
+    e->pass3_shared = overlap;
+    // (flags and patches: the set two batches back may still be read by that batch's tally)
+    const int flag_set = overlap ? e->flag_turn : 0;
+    if (overlap) e->flag_turn = (e->flag_turn + 1) % 3;
     HostBatchDone host_done(e, reads);
     ReadsDev R; int max_len;
     if ((rc = device_view(e, reads, &R, &max_len))) return rc;
@@ -2009,7 +2080,8 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
     // words of trusted mask per read: the staged kernels' NW; long reads: 8 per window of 512 k-mer starts
     const int NW = max_len <= 192 ? 3 : max_len <= 320 ? 5 : !long_reads ? 8 : 8 * ((std::max(1, max_len - e->p.k + 1) + 511) / 512);
     // scratch per side: trusted masks, dirty flags, work list, error bits, seq patches
-    const int s_tmask = side ? 10 : 3, s_dirty = side ? 11 : 4, s_list = side ? 12 : 5, s_err = side ? 8 : 6, s_patch = side ? 9 : 7;
+    const int s_tmask = side ? 10 : 3, s_dirty = side ? 11 : 4, s_list = side ? 12 : 5;
+    const int s_err = flag_set == 0 ? 6 : flag_set == 1 ? 8 : 24, s_patch = flag_set == 0 ? 7 : flag_set == 1 ? 9 : 25;
     if ((rc = ensure_scratch(e, s_tmask, R.n_reads * NW * 8))) return rc;
     if ((rc = ensure_scratch(e, s_dirty, R.n_reads))) return rc;
     if ((rc = ensure_scratch(e, s_list, R.n_reads * 4))) return rc;
@@ -2082,11 +2154,13 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
         else rc = launch_correct<512, 64>(e, R, list3, cnt3, tmask, NW, d_err, patch);
         if (rc) return rc;
     }
-    if ((rc = run_tally(e, R, d_err, patch, max_len, e->cur))) return rc;
     if (!(R.offcase && !long_reads)) HIP_TRY(hipMemsetAsync(e->d_counters + 6 + side, 0, 8, e->cur));
     hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(1), 0, e->cur, (const unsigned long long *)(e->d_counters + 4 * side),
                        (const unsigned long long *)(e->d_counters + 6 + side), e->d_totals);
     HIP_TRY(hipGetLastError());
+    // the side's masks, work list and counters are free from here; the tally only reads the flags and patches (three sets)
+    HIP_TRY(hipEventRecord(e->ev_walk[side], e->cur));
+    if ((rc = run_tally(e, R, d_err, patch, max_len, e->cur))) return rc;
     HIP_TRY(hipEventRecord(e->ev_side[side], e->cur));
     e->side_busy[side] = true;
     e->stats[2] += R.n_reads;
