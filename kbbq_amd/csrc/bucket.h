@@ -331,11 +331,9 @@ __global__ void __launch_bounds__(BK_THREADS) k_split(FiltDev F, BucketDev B, ui
 // One workgroup per subslice: the 64 KB of the filter go to LDS with coalesced 16-byte loads, every record ORs
 // its pattern in (look first: nine inserts in ten repeat an earlier one), the subslice is stored back.  The
 // pattern table (1 MiB) is read from L2.  A subslice without records is neither loaded nor stored.
-// APPLY_THREADS: 1024 when the kernel has the chip to itself; 512 (a quarter of a SIMD's registers per workgroup instead of
-// more than half) for a flush in the middle of pass 2, which must find room beside k_infer's resident workgroups (engine.hip:
-// Options::infer_blocks) -- a kernel that does not fit waits for the other stream's to end, and gets the gaps between its launches.
-template <int APPLY_THREADS>
-__global__ void __launch_bounds__(APPLY_THREADS, 2048 / APPLY_THREADS) k_apply(FiltDev F, BucketDev B) {
+constexpr int APPLY_THREADS = 1024;
+
+__global__ void __launch_bounds__(APPLY_THREADS) k_apply(FiltDev F, BucketDev B) {
     __shared__ ulonglong2 blk_l[SUB_BLOCKS];
     const uint32_t sub = blockIdx.x;
     const uint32_t n = min(B.l2_cnt[sub], B.cap2);

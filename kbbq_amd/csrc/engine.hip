@@ -103,13 +103,6 @@ struct Options {
     int scan_blocks = -1;             // KBBQ_SCAN_BLOCKS / kbbq_engine_tune("scan_blocks", n)
     int walk_blocks = -1;             // KBBQ_WALK_BLOCKS / "walk_blocks"
     int infer_blocks = 0;             // KBBQ_INFER_BLOCKS / "infer_blocks"
-    bool tally_behind = false;        // KBBQ_TALLY_BEHIND=1 / "tally_behind": 1 = the next batch but one waits for a batch's walk only, not
-                                      // for its tally (three sets of flag arrays).  Measured and lost (profiles/r04_ab_tally_behind.json:
-                                      // pass 3 1990 ms against 1507): the tally then runs beside a scan whose resident workgroups leave
-                                      // it one of its two per CU -- 7.7 ms instead of 1.05 -- and the next walk queues behind it
-    int tally_threads = 0;            // KBBQ_TALLY_THREADS / "tally_threads": 256 or 512 = k_tally_uniform in workgroups of that size (with tally_behind)
-    int apply_small = 0;              // KBBQ_APPLY_SMALL / "apply_small": 1 = k_apply in workgroups of 512 for the flushes in the middle of pass 2
-    int walk_regs = 0;                // KBBQ_WALK_REGS / "walk_regs": 1 = k_correct_wave built for four wavefronts per SIMD (128 registers, no spills)
 };
 
 struct kbbq_engine {
@@ -127,10 +120,6 @@ struct kbbq_engine {
     bool ins_pending[2] = {false, false};
     int draw_turn = 0;
     bool side_busy[2] = {false, false};     // a batch of pass 3 used that side since the totals were last read
-    // ... its error flags and patches exist three times: the tally of batch i (side stream, behind its walk) reads them while the
-    // scan of batch i+2 (same side, engine's stream) clears the set it will write -- that scan waits for walk i only (ev_walk)
-    hipEvent_t ev_walk[2] = {nullptr, nullptr};
-    int flag_turn = 0;
     bool pass3_shared = false;              // the batch being submitted shares the chip with its neighbours' kernels (grid caps)
     unsigned long long *d_totals = nullptr; // pass 3: [0] reads sent to the correction kernels, [1] Bloom queries there (k_add_counters)
     int side_turn = 0;
@@ -157,8 +146,8 @@ struct kbbq_engine {
     int8_t *d_dq_cycle = nullptr;
     int8_t *d_dq_dinuc = nullptr;
     // scratch
-    void *scratch[28] = {};
-    size_t scratch_bytes[28] = {};
+    void *scratch[24] = {};
+    size_t scratch_bytes[24] = {};
     unsigned long long *d_counters = nullptr;   // [0] work-list length, [1] correction queries, [2] scan total
     unsigned int *d_tickets = nullptr;          // chunk counters of the kernels that hand their reads out dynamically (ReadChunks): [0] k_infer, [1 + side] k_scan_trusted, [3 + side] k_correct_wave
     // Host batches: a ring of device staging slots owned by the engine and a copy stream.  A host batch is copied
@@ -699,9 +688,7 @@ int bucket_flush(kbbq_engine *e, int w, bool barrier = true) {
     }
     {
         Timed t(e, w ? "k_apply_trusted" : "k_apply_sampled", st);
-        // (a flush in the middle of pass 2 shares the chip with k_infer: the form that fits beside it)
-        if (w == 1 && !barrier && st != e->stream && e->opt.apply_small) hipLaunchKernelGGL(k_apply<512>, dim3(B.n_sub), dim3(512), 0, st, F, B);
-        else hipLaunchKernelGGL(k_apply<1024>, dim3(B.n_sub), dim3(1024), 0, st, F, B);
+        hipLaunchKernelGGL(k_apply, dim3(B.n_sub), dim3(APPLY_THREADS), 0, st, F, B);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemsetAsync(b.l1_cnt, 0, kL1CntBytes, st));
@@ -812,10 +799,6 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
         o.scan_blocks = env_int("KBBQ_SCAN_BLOCKS", o.scan_blocks);
         o.walk_blocks = env_int("KBBQ_WALK_BLOCKS", o.walk_blocks);
         o.infer_blocks = env_int("KBBQ_INFER_BLOCKS", o.infer_blocks);
-        o.walk_regs = env_int("KBBQ_WALK_REGS", o.walk_regs);
-        o.apply_small = env_int("KBBQ_APPLY_SMALL", o.apply_small);
-        o.tally_threads = env_int("KBBQ_TALLY_THREADS", o.tally_threads);
-        o.tally_behind = env_int("KBBQ_TALLY_BEHIND", 0) != 0;
     }
     e->K.k = params->k;
     e->K.shift = 2u * (unsigned)(params->k - 1);
@@ -836,7 +819,6 @@ int kbbq_engine_create(const kbbq_params *params, kbbq_engine **out) {
     for (int t = 0; t < 2 && he == hipSuccess; ++t) he = hipEventCreateWithFlags(&e->ev_ins[t], hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_side[0], hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_side[1], hipEventDisableTiming);
-    for (int t = 0; t < 2 && he == hipSuccess; ++t) he = hipEventCreateWithFlags(&e->ev_walk[t], hipEventDisableTiming);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->copy, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->bk.ev_flush, hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->bk.ev_est, hipEventDisableTiming);
@@ -944,7 +926,6 @@ void kbbq_engine_destroy(kbbq_engine *e) {
     if (e->ev_draw) hipEventDestroy(e->ev_draw);
     for (int t = 0; t < 2; ++t) if (e->ev_ins[t]) hipEventDestroy(e->ev_ins[t]);
     for (int i = 0; i < 2; ++i) if (e->ev_side[i]) hipEventDestroy(e->ev_side[i]);
-    for (int i = 0; i < 2; ++i) if (e->ev_walk[i]) hipEventDestroy(e->ev_walk[i]);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1007,17 +988,9 @@ int kbbq_engine_tune(kbbq_engine *e, const char *name, uint64_t value) {
         // (17 = the default: the measured setting for short reads, none otherwise)
         if (value > 17) return fail(KBBQ_EINVAL, "%s: 0 (as many as fit) to 16 workgroups per CU, 17 = default", name);
         (name[0] == 's' ? e->opt.scan_blocks : name[0] == 'w' ? e->opt.walk_blocks : e->opt.infer_blocks) = value == 17 ? (name[0] == 'i' ? 0 : -1) : (int)value;
-    } else if (!strcmp(name, "tally_behind")) {
-        ENGINE_DEVICE(e);
-        int rc = sync_engine(e);      // (the order of the events changes: between two runs)
-        if (rc) return rc;
-        e->opt.tally_behind = value != 0;
-    } else if (!strcmp(name, "walk_regs")) {
-        e->opt.walk_regs = value != 0;
-    } else if (!strcmp(name, "apply_small")) {
-        e->opt.apply_small = value != 0;
-    } else if (!strcmp(name, "tally_threads")) {
-        e->opt.tally_threads = (int)value;
+
+
+
     } else if (!strcmp(name, "infer_subset")) {
         e->opt.infer_subset = value != 0;      // (same results either way: an A/B switch between two runs)
     } else if (!strcmp(name, "pass2_side")) {
@@ -1944,10 +1917,6 @@ static int launch_correct_wave(kbbq_engine *e, ReadsDev R, const uint32_t *list,
     HIP_TRY(hipMemsetAsync(ticket, 0, 4, e->cur));
     Timed t(e, "k_correct_wave", e->cur);
     const int blocks = wave_grid(R.n_reads, e->pass3_shared ? shared_cap(e, e->opt.walk_blocks, 2, NB <= 5 ? 160 : 512) : 0);
-    if (e->opt.walk_regs)
-        hipLaunchKernelGGL((k_correct_wave<NB, NN, 4>), dim3(blocks), dim3(256), 0, e->cur, R, e->K, e->filt[1].dev(), list,
-                           (const unsigned long long *)e->cur_cnt, tmask, tw, err_bits, patch, e->cur_cnt, ticket);
-    else
     hipLaunchKernelGGL((k_correct_wave<NB, NN>), dim3(blocks), dim3(256), 0, e->cur, R, e->K, e->filt[1].dev(), list,
                        (const unsigned long long *)e->cur_cnt, tmask, tw, err_bits, patch, e->cur_cnt, ticket);
     HIP_TRY(hipGetLastError());
@@ -2028,12 +1997,8 @@ static int run_tally(kbbq_engine *e, const ReadsDev &R, const uint32_t *err_bits
         e->p.n_rg == 1) {
         const unsigned long long inv_len = ~0ULL / R.read_len + 1;      // ceil(2^64 / read_len): read_len is no power of two times... exact below
         Timed t(e, "k_tally", stream);
-        // (tally_threads: workgroups of 256 or 512, one per CU -- the form that finds room beside the next batches' scan and walk
-        // when the tally is left behind, Options::tally_behind)
-        const int tt = e->pass3_shared && (e->opt.tally_threads == 256 || e->opt.tally_threads == 512) ? e->opt.tally_threads : 1024;
-        const int tb = tt == 1024 ? blocks : (int)std::min<uint64_t>((groups + tt - 1) / tt, 256);
-        if (P.identity) hipLaunchKernelGGL(k_tally_uniform<false>, dim3(tb), dim3(tt), lds, stream, R, H, err_bits, patch, ccap, 6, inv_len, P);
-        else hipLaunchKernelGGL(k_tally_uniform<true>, dim3(tb), dim3(tt), lds, stream, R, H, err_bits, patch, ccap, 6, inv_len, P);
+        if (P.identity) hipLaunchKernelGGL(k_tally_uniform<false>, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, inv_len, P);
+        else hipLaunchKernelGGL(k_tally_uniform<true>, dim3(blocks), dim3(1024), lds, stream, R, H, err_bits, patch, ccap, 6, inv_len, P);
         HIP_TRY(hipGetLastError());
         return KBBQ_OK;
     }
@@ -2065,14 +2030,11 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
         e->side_turn ^= 1;
         // the batch that last used this side's scratch may still be in its walk on the side stream: this batch's scan
         // (engine's stream) overwrites that scratch, so the stream waits -- the host does not
-        if (e->side_busy[side]) HIP_TRY(hipStreamWaitEvent(e->stream, e->opt.tally_behind ? e->ev_walk[side] : e->ev_side[side], 0));
+        if (e->side_busy[side]) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_side[side], 0));
     } else {
         if ((rc = sync_engine(e))) return rc;              // both sides' scratch is free
     }
     e->pass3_shared = overlap;
-    // (flags and patches: the set two batches back may still be read by that batch's tally)
-    const int flag_set = overlap ? e->flag_turn : 0;
-    if (overlap) e->flag_turn = (e->flag_turn + 1) % 3;
     HostBatchDone host_done(e, reads);
     ReadsDev R; int max_len;
     if ((rc = device_view(e, reads, &R, &max_len))) return rc;
@@ -2080,8 +2042,7 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
     // words of trusted mask per read: the staged kernels' NW; long reads: 8 per window of 512 k-mer starts
     const int NW = max_len <= 192 ? 3 : max_len <= 320 ? 5 : !long_reads ? 8 : 8 * ((std::max(1, max_len - e->p.k + 1) + 511) / 512);
     // scratch per side: trusted masks, dirty flags, work list, error bits, seq patches
-    const int s_tmask = side ? 10 : 3, s_dirty = side ? 11 : 4, s_list = side ? 12 : 5;
-    const int s_err = flag_set == 0 ? 6 : flag_set == 1 ? 8 : 24, s_patch = flag_set == 0 ? 7 : flag_set == 1 ? 9 : 25;
+    const int s_tmask = side ? 10 : 3, s_dirty = side ? 11 : 4, s_list = side ? 12 : 5, s_err = side ? 8 : 6, s_patch = side ? 9 : 7;
     if ((rc = ensure_scratch(e, s_tmask, R.n_reads * NW * 8))) return rc;
     if ((rc = ensure_scratch(e, s_dirty, R.n_reads))) return rc;
     if ((rc = ensure_scratch(e, s_list, R.n_reads * 4))) return rc;
@@ -2154,13 +2115,11 @@ int kbbq_errors_batch(kbbq_engine *e, const kbbq_reads *reads, uint64_t *errors_
         else rc = launch_correct<512, 64>(e, R, list3, cnt3, tmask, NW, d_err, patch);
         if (rc) return rc;
     }
+    if ((rc = run_tally(e, R, d_err, patch, max_len, e->cur))) return rc;
     if (!(R.offcase && !long_reads)) HIP_TRY(hipMemsetAsync(e->d_counters + 6 + side, 0, 8, e->cur));
     hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(1), 0, e->cur, (const unsigned long long *)(e->d_counters + 4 * side),
                        (const unsigned long long *)(e->d_counters + 6 + side), e->d_totals);
     HIP_TRY(hipGetLastError());
-    // the side's masks, work list and counters are free from here; the tally only reads the flags and patches (three sets)
-    HIP_TRY(hipEventRecord(e->ev_walk[side], e->cur));
-    if ((rc = run_tally(e, R, d_err, patch, max_len, e->cur))) return rc;
     HIP_TRY(hipEventRecord(e->ev_side[side], e->cur));
     e->side_busy[side] = true;
     e->stats[2] += R.n_reads;

@@ -774,10 +774,8 @@ __global__ void __launch_bounds__(BLOCK) k_correct(ReadsDev R, KParams K, FiltDe
 
 
 // ---- pass 3b (default): the correction walk, one read per WAVEFRONT (correct_wave.h) ----
-// MINW: wavefronts per SIMD the register budget allows for (5: 96 registers and a dozen spilled; 4: 128, none) -- beside
-// k_scan_trusted on the other stream the walk only gets two or three wave slots per SIMD anyway (engine.hip: walk_blocks)
-template <int NB, int NN, int MINW = 5>
-__global__ void __launch_bounds__(256, MINW) k_correct_wave(ReadsDev R, KParams K, FiltDev T, const uint32_t *list,
+template <int NB, int NN>
+__global__ void __launch_bounds__(256, 5) k_correct_wave(ReadsDev R, KParams K, FiltDev T, const uint32_t *list,
                                                        const unsigned long long *n_list, const uint64_t *tmask,
                                                        int tmask_words, uint32_t *err_bits, uint32_t *patch,
                                                        unsigned long long *stats, unsigned int *ticket) {
