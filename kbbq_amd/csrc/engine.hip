@@ -99,7 +99,9 @@ struct Options {
     // fills every wave slot keeps the other stream's kernel out until its own last read is done.
     // Measured on the 30x workload (profiles/r04_ab_pass3_grid_caps.json, r04_ab_grid_caps_b.json): pass 3 with four scan and two
     // walk workgroups per CU 1415 ms against 1568 ms uncapped; k_infer capped loses (its insert side needs more room than a cap
-    // that it tolerates leaves).  -1 = that setting for reads the three-word kernels take (up to 192 bases), none otherwise.
+    // that it tolerates leaves).  -1 = that setting for batches of equally long reads of up to 192 bases (no offsets array), none
+    // otherwise: the command line's batches (an offsets array, the general tally) lose with it -- pass 3 + model of a 3e10-base
+    // FASTQ 0.65 s against 0.56 uncapped (profiles/r04_e2e_3e10_caps.txt), the opposite of bench.py's batches at either size.
     int scan_blocks = -1;             // KBBQ_SCAN_BLOCKS / kbbq_engine_tune("scan_blocks", n)
     int walk_blocks = -1;             // KBBQ_WALK_BLOCKS / "walk_blocks"
     int infer_blocks = 0;             // KBBQ_INFER_BLOCKS / "infer_blocks"
@@ -500,9 +502,9 @@ inline int wave_grid(uint64_t n_reads, int per_cu = 0) {
     return (int)std::min<uint64_t>(blocks, 256 * (uint64_t)(per_cu > 0 ? per_cu : 16));
 }
 // ... the cap only while the other stream has work of the same pass (Options)
-inline int shared_cap(const kbbq_engine *e, int per_cu, int auto_value = 0, int max_len = 0) {
+inline int shared_cap(const kbbq_engine *e, int per_cu, int auto_value = 0, int max_len = 0, bool uniform = true) {
     if (e->opt.no_overlap) return 0;
-    return per_cu >= 0 ? per_cu : max_len <= 192 ? auto_value : 0;
+    return per_cu >= 0 ? per_cu : max_len <= 192 && uniform ? auto_value : 0;
 }
 
 // exclusive k-mer-position prefix for ragged batches (scratch slot 1); null for uniform ones
@@ -1865,10 +1867,10 @@ template <int NW> struct LaunchScan {
         HIP_TRY(hipMemsetAsync(ticket, 0, 4, e->cur));
         Timed t(e, "k_scan_trusted", e->cur);
         if (std::max(1, max_len - e->p.k + 1) <= (NW - 1) * 64)      // (NK: see k_infer)
-            hipLaunchKernelGGL((k_scan_trusted<NW, NW - 1>), dim3(wave_grid(R.n_reads, e->pass3_shared ? shared_cap(e, e->opt.scan_blocks, 4, max_len) : 0)), dim3(256), 0, e->cur, R, e->K,
+            hipLaunchKernelGGL((k_scan_trusted<NW, NW - 1>), dim3(wave_grid(R.n_reads, e->pass3_shared ? shared_cap(e, e->opt.scan_blocks, 4, max_len, !R.offsets) : 0)), dim3(256), 0, e->cur, R, e->K,
                                e->filt[1].dev(), tmask, dirty, err_bits, e->cur_cnt, fast, ticket);
         else
-            hipLaunchKernelGGL((k_scan_trusted<NW, NW>), dim3(wave_grid(R.n_reads, e->pass3_shared ? shared_cap(e, e->opt.scan_blocks, 4, max_len) : 0)), dim3(256), 0, e->cur, R, e->K,
+            hipLaunchKernelGGL((k_scan_trusted<NW, NW>), dim3(wave_grid(R.n_reads, e->pass3_shared ? shared_cap(e, e->opt.scan_blocks, 4, max_len, !R.offsets) : 0)), dim3(256), 0, e->cur, R, e->K,
                                e->filt[1].dev(), tmask, dirty, err_bits, e->cur_cnt, fast, ticket);
         HIP_TRY(hipGetLastError());
         return KBBQ_OK;
@@ -1916,7 +1918,7 @@ static int launch_correct_wave(kbbq_engine *e, ReadsDev R, const uint32_t *list,
     unsigned int *ticket = e->d_tickets + 3 + (e->cur_cnt != e->d_counters ? 1 : 0);      // per side of pass 3
     HIP_TRY(hipMemsetAsync(ticket, 0, 4, e->cur));
     Timed t(e, "k_correct_wave", e->cur);
-    const int blocks = wave_grid(R.n_reads, e->pass3_shared ? shared_cap(e, e->opt.walk_blocks, 2, NB <= 5 ? 160 : 512) : 0);
+    const int blocks = wave_grid(R.n_reads, e->pass3_shared ? shared_cap(e, e->opt.walk_blocks, 2, NB <= 5 ? 160 : 512, !R.offsets) : 0);
     hipLaunchKernelGGL((k_correct_wave<NB, NN>), dim3(blocks), dim3(256), 0, e->cur, R, e->K, e->filt[1].dev(), list,
                        (const unsigned long long *)e->cur_cnt, tmask, tw, err_bits, patch, e->cur_cnt, ticket);
     HIP_TRY(hipGetLastError());

@@ -91,3 +91,18 @@ def test_bucketed_equals_direct_on_a_filter_of_many_level1_buckets(records, monk
     assert int(b[2].ne(0).sum()) > 0
     if records:
         assert b[5]["bucket_flushes"][1] >= 2
+
+
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_schedules_of_pass_2_give_the_same_filters(mode, monkeypatch):
+    """KBBQ_PASS2_SIDE: pass 2 in order / its whole insert side on the side stream / only the emits there and every flush
+    alone on the engine's stream between two k_infer (the default): with flushes in the middle of the pass the trusted
+    filter, the counters and the hint bits are those of the direct path whichever stream ran what."""
+    d = common.make_dataset(seed=809, genome_len=300000, coverage=20, n_per_million=500)
+    approx = 700_000_000
+    a = _filters_after_two_passes(d, approx, False, monkeypatch)
+    monkeypatch.setenv("KBBQ_PASS2_SIDE", mode)
+    b = _filters_after_two_passes(d, approx, True, monkeypatch, 200000)
+    assert a[0] == b[0] and a[1] == b[1] and a[1] > 0
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    assert b[5]["bucket_flushes"][1] >= 2

@@ -590,7 +590,14 @@ def test_error_codes():
     assert ei.value.code == -1
     with pytest.raises(_lib.KbbqError):
         e.recalibrate(b)              # no delta-Q tables yet
+    # the schedule knobs: workgroups per CU 0..16 (17 = the engine's own choice), pass-2 modes 0..2
+    for knob, good, bad in ((b"scan_blocks", 4, 18), (b"walk_blocks", 17, 40), (b"infer_blocks", 0, 18), (b"pass2_side", 2, 3)):
+        assert L.kbbq_engine_tune(e.h, knob, good) == 0
+        assert L.kbbq_engine_tune(e.h, knob, bad) == -22
+    assert L.kbbq_engine_tune(e.h, b"no_such_knob", 1) == -22
     e.close()
+    p.bloom_seed, p.max_read_len = _lib.DEFAULT_BLOOM_SEED, (1 << 23)
+    assert L.kbbq_engine_create(ctypes.byref(p), ctypes.byref(h)) == -34   # longer than KBBQ_MAX_READ_LEN (2^23 - 1)
 
 
 def test_properties_at_scale_on_device_generated_reads():
@@ -717,11 +724,13 @@ def test_overlapped_and_in_order_pass3_agree_on_device_batches():
             "st = e.stats(); assert st['reads'] == 2 * n, st\n"
             "print('pass3 ok', st['corrected_reads'], st['correction_queries'])\n")
     outs = []
-    for extra in ({}, {"KBBQ_NO_OVERLAP": "1"}):
+    # (the default caps the scan at four and the walk at two workgroups per CU while both streams are in use; 0 = as many as
+    # fit, round 3's launches; 1 / 1: as little room as there is)
+    for extra in ({}, {"KBBQ_NO_OVERLAP": "1"}, {"KBBQ_SCAN_BLOCKS": "0", "KBBQ_WALK_BLOCKS": "0"}, {"KBBQ_SCAN_BLOCKS": "1", "KBBQ_WALK_BLOCKS": "1"}):
         out = subprocess.run([sys.executable, "-c", code], cwd=common.ROOT, env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "pass3 ok" in out.stdout, out.stdout + out.stderr
         outs.append(out.stdout.strip().splitlines()[-1])
-    assert outs[0] == outs[1]
+    assert len(set(outs)) == 1, outs
 
 
 def test_qualities_above_93_are_modelled_like_the_reference_s_growing_tables():
