@@ -99,9 +99,10 @@ struct Options {
     // fills every wave slot keeps the other stream's kernel out until its own last read is done.
     // Measured on the 30x workload (profiles/r04_ab_pass3_grid_caps.json, r04_ab_grid_caps_b.json): pass 3 with four scan and two
     // walk workgroups per CU 1415 ms against 1568 ms uncapped; k_infer capped loses (its insert side needs more room than a cap
-    // that it tolerates leaves).  -1 = that setting for batches of equally long reads of up to 192 bases (no offsets array), none
-    // otherwise: the command line's batches (an offsets array, the general tally) lose with it -- pass 3 + model of a 3e10-base
-    // FASTQ 0.65 s against 0.56 uncapped (profiles/r04_e2e_3e10_caps.txt), the opposite of bench.py's batches at either size.
+    // that it tolerates leaves).  -1 = that setting for batches of equally long reads of up to 192 bases (no offsets array: where it
+    // was measured), none otherwise.  It only pays when the two streams really run side by side: a host process whose streams
+    // outnumber the runtime's hardware queues (four by default) may find both of the engine's on one queue, and capped kernels
+    // in order are slower than uncapped ones -- GPU_MAX_HW_QUEUES; profiles/r04_e2e_3e10_hw_queues.txt.
     int scan_blocks = -1;             // KBBQ_SCAN_BLOCKS / kbbq_engine_tune("scan_blocks", n)
     int walk_blocks = -1;             // KBBQ_WALK_BLOCKS / "walk_blocks"
     int infer_blocks = 0;             // KBBQ_INFER_BLOCKS / "infer_blocks"

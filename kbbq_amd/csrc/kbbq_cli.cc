@@ -1094,6 +1094,10 @@ static int io_test(int argc, char *argv[]) {
 }
 
 int main(int argc, char *argv[]) {
+    // The runtime multiplexes a process's streams onto four hardware queues by default, and this process creates a dozen (reader,
+    // engine, writer, copies): the engine's two streams then shared one, and what was queued "side by side" ran in order -- pass 3
+    // of a 3e10-base file 0.55 s, with eight queues 0.47-0.50 (profiles/r04_e2e_3e10_hw_queues.txt).  Read once, at the first HIP call.
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     if (argc > 1 && std::string(argv[1]) == "--io-test") return io_test(argc, argv);
     int k = 32;
     long double alpha = 0;
