@@ -33,6 +33,12 @@ sys.path.insert(0, ROOT)
 np = torch = _lib = synth = EnginePeer = Exchange = shard_range = Engine = plan_parameters = None
 
 
+# The ROCm runtime spreads a process's streams over four hardware queues unless told otherwise; with torch's and RCCL's streams
+# beside the engine's three, two of the engine's can share one and then run in order (seen in the command line: DESIGN.md
+# section 4, "Hardware queues").  Read by the runtime at the first HIP call, so it is set before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
 def _imports():
     global np, torch, _lib, synth, EnginePeer, Exchange, shard_range, Engine, plan_parameters
     import numpy as np_
