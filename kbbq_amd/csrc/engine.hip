@@ -991,9 +991,6 @@ int kbbq_engine_tune(kbbq_engine *e, const char *name, uint64_t value) {
         // (17 = the default: the measured setting for short reads, none otherwise)
         if (value > 17) return fail(KBBQ_EINVAL, "%s: 0 (as many as fit) to 16 workgroups per CU, 17 = default", name);
         (name[0] == 's' ? e->opt.scan_blocks : name[0] == 'w' ? e->opt.walk_blocks : e->opt.infer_blocks) = value == 17 ? (name[0] == 'i' ? 0 : -1) : (int)value;
-
-
-
     } else if (!strcmp(name, "infer_subset")) {
         e->opt.infer_subset = value != 0;      // (same results either way: an A/B switch between two runs)
     } else if (!strcmp(name, "pass2_side")) {
@@ -1728,13 +1725,15 @@ template <int NW> struct LaunchTrusted {
             HIP_TRY(hipGetLastError());
         }
         if (bucket_on(e, 1)) {
-            // The insert side of pass 2 -- emit, and split + apply whenever the record buffers fill -- runs on the
-            // side stream: it is ALU-, streaming- and L2-bound, k_infer is bound by random HBM lines, so batch i's
-            // inserts run beside batch i+1's k_infer.  (Overflow records are inserted directly by the emit kernel:
-            // on the same stream as k_apply, so the two never touch the trusted filter at the same time; the direct
-            // inserts of long reads are ordered against that stream by events, kbbq_trusted_batch.)
-            // Measured +2.4 % on the 30x workload (profiles/r02_bench_full_i_{side,noside}.json); the exclusive duration
-            // of k_infer -- the kernel the roofline is quoted for -- comes from the in-order run (KBBQ_F_NO_OVERLAP).
+            // The emits of pass 2 run on the side stream: ALU-bound, beside the next batch's k_infer, which is bound by random
+            // HBM lines (the emit costs it about half of its own 1.8 ms).  A flush -- split + apply, whenever the record buffers
+            // fill -- runs where Options::pass2_side says: alone on the engine's stream between two k_infer (2, the default:
+            // k_apply and k_infer both wait for the L2's request path and only slow each other down), or on the side stream
+            // too (1, round 3's form).  (Overflow records are inserted directly by the emit kernel; emit and k_apply never
+            // touch the trusted filter at the same time in either mode: same stream, or ordered by events in bucket_flush.
+            // The direct inserts of long reads are ordered against the side stream by events, kbbq_trusted_batch.)
+            // The exclusive duration of k_infer -- the kernel the roofline is quoted for -- comes from the in-order run
+            // (KBBQ_F_NO_OVERLAP).
             const bool side = e->opt.pass2_side != 0 && !e->opt.no_overlap;
             e->bk.stream[1] = side ? e->stream2 : e->stream;
             if (side) {
