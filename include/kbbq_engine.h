@@ -153,8 +153,13 @@ int kbbq_engine_sync(kbbq_engine *e);
 /* Numeric knobs of an engine (tests and measurements; none changes a result): "bucket_records" = records gathered per
  * flush of the slice-bucketed inserts (before the first batch; KBBQ_BUCKET_RECORDS), "pass4_piece" = bases per piece of
  * the pass-4 pipeline of a host batch (KBBQ_PASS4_PIECE), "no_overlap" = 1 / 0: KBBQ_F_NO_OVERLAP switched on or off between
- * two runs (the call waits for everything queued; bench.py takes its exclusive kernel durations this way).  KBBQ_EINVAL for
- * an unknown name. */
+ * two runs (the call waits for everything queued; bench.py takes its exclusive kernel durations this way), "infer_subset"
+ * = 1 / 0 (KBBQ_INFER_SUBSET), "pass2_side" = 0 / 1 / 2: where the insert side of pass 2 runs (KBBQ_PASS2_SIDE; waits likewise),
+ * "scan_blocks" / "walk_blocks" / "infer_blocks" = workgroups per CU of the kernels that stay resident for a whole batch while
+ * the other stream has work (0 = as many as fit ... 16, 17 = the engine's own choice; KBBQ_SCAN_BLOCKS, KBBQ_WALK_BLOCKS,
+ * KBBQ_INFER_BLOCKS).  KBBQ_EINVAL for an unknown name or a value out of range.
+ * The engine runs kernels of neighbouring batches on two streams of its own: a host process with many streams should set
+ * GPU_MAX_HW_QUEUES >= 8 in its environment before its first HIP call, or the two may share a hardware queue. */
 int kbbq_engine_tune(kbbq_engine *e, const char *name, uint64_t value);
 /* hipStream_t of the engine, as void*. */
 void *kbbq_engine_stream(kbbq_engine *e);

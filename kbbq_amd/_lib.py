@@ -31,7 +31,7 @@ KBBQ_F_PASS2_INORDER = 64
 KBBQ_F_NO_PASS4_PIPELINE = 128
 DEFAULT_BLOOM_SEED = 0xA5A5A5A55A5A5A5A
 NQ = 256
-MAX_READ_LEN = 512
+MAX_READ_LEN = (1 << 23) - 1      # KBBQ_MAX_READ_LEN (include/kbbq_engine.h)
 
 
 class Params(ctypes.Structure):
