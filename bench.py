@@ -79,10 +79,11 @@ def kernel_source_sha16():
 # kernels that share the chip with a kernel of the neighbouring batch on the other stream (pass 1: draw beside insert;
 # pass 3: walk + tally beside scan): their event durations are not exclusive costs
 PASS3_KERNELS = ("k_draw_mask", "k_insert_sampled", "k_emit_sampled", "k_scan_trusted", "k_compact", "k_correct_wave", "k_correct", "k_tally")
-# the insert side of pass 2 runs on the side stream beside k_infer (default since round 3; KBBQ_PASS2_SIDE=0 puts it behind):
-# pass 2's durations are shared too
-if os.environ.get("KBBQ_PASS2_SIDE", "1") not in ("", "0"):
-    PASS3_KERNELS += ("k_infer", "k_emit_trusted", "k_split_trusted", "k_apply_trusted")
+# the emits of pass 2 run on the side stream beside k_infer (KBBQ_PASS2_SIDE=2, the default since round 4; 1: split and apply
+# as well, round 3's default; 0: everything in order): those kernels' durations are shared too
+_side = os.environ.get("KBBQ_PASS2_SIDE", "2")
+if _side not in ("", "0"):
+    PASS3_KERNELS += ("k_infer", "k_emit_trusted") + (("k_split_trusted", "k_apply_trusted") if _side == "1" else ())
 
 
 def run_step(e, xch, batches, ordinals, out_buf, hints, pass_ms=None):
